@@ -1,0 +1,992 @@
+/*
+ * ppp_oracle.cpp -- CPU oracle for the polishing-path hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ppp_oracle.h).  Single-threaded, dependency
+ * free restatement of the reference semantics.  File:line citations are
+ * relative to the reference tree (tsai0507/PolishPathPlanning @ v1).
+ *
+ * PARITY UNPINNED: no reference test / golden vector exists for this path and
+ * the reference cannot be compiled here (needs PCL >= 1.11, GSL >= 2.0,
+ * Eigen3 -- none installed, no network).  The third-party arithmetic is
+ * restated from the published algorithms of the pinned-by-usage versions:
+ *   - PCL 1.12 (code uses pcl::Indices + pcl::make_shared => >= 1.11;
+ *     Ubuntu 22.04 ships 1.12.1): PassThrough, KdTreeFLANN (exact NN,
+ *     flann::L2_Simple<float>), NormalEstimation (radius search,
+ *     computeMeanAndCovarianceMatrix shifted by the first neighbour,
+ *     pcl::eigen33, flipNormalTowardsViewpoint), getMinMax3D.
+ *   - GSL >= 2.0 interpolation/steffen.c (gsl_interp_steffen).
+ *   - Eigen 3.3/3.4: Matrix3f::eulerAngles(2,1,0), AngleAxisf products
+ *     (quaternion route), Matrix4f products.
+ * Build with -ffp-contract=off: every float expression below is evaluated
+ * with one rounding per operation, in the order written.
+ *
+ * Known reference defect handled here (SURVEY.md App. B + DESIGN.md B.12):
+ * postion_smooth() (path_translation_alg.cpp:114-141) stores float but sums
+ * the un-rounded double deltas, so its `change < 1e-5` test can never be met
+ * once 3*W*ulp/4 > 1e-5 (W >~ 250): the reference spins forever.  The oracle
+ * (and the product) stop at the first sweep k >= 2 whose change is >= 0.9 x
+ * the previous sweep's change (the geometric decay has hit the float floor),
+ * or at `smooth_max_sweeps`, whichever comes first.
+ */
+#include "ppp_oracle.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <vector>
+#include <math.h>
+
+namespace {
+
+/* pcl::PointXYZRGB is 32 bytes: xyz + pad, rgba + pad. */
+struct Pt {
+    float x, y, z, pad0;
+    uint32_t rgba;
+    float pad1[3];
+};
+static_assert(sizeof(Pt) == 32, "PointXYZRGB layout");
+
+inline float dist2(const float *a, const float *b)
+{
+    /* flann::L2_Simple<float>: result += diff*diff over x, y, z in order */
+    float r = 0.f, d;
+    d = a[0] - b[0]; r += d * d;
+    d = a[1] - b[1]; r += d * d;
+    d = a[2] - b[2]; r += d * d;
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* Exact kd-tree (stand-in for pcl::KdTreeFLANN).  */
+/* Results: ascending (distance, index); ties resolve to lowest index. */
+/* ------------------------------------------------------------------ */
+class KdTree {
+public:
+    void build(const Pt *pts, const int *ids, int n)
+    {
+        pts_ = pts;
+        /* local id = position in ids (like the per-slice sub-clouds cloudEl / cloudEr) */
+        if (ids) sub_.assign(ids, ids + n);
+        else sub_.clear();
+        order_.resize(n);
+        for (int i = 0; i < n; ++i) order_[i] = i;
+        nodes_.clear();
+        if (n > 0) { nodes_.reserve(2 * n / kLeaf + 8); build_rec(0, n); }
+    }
+    bool empty() const { return order_.empty(); }
+    /* returns local id (position in ids, or cloud index if ids == nullptr) */
+    int nearest(const float *q, float *d2out = nullptr) const
+    {
+        float best = std::numeric_limits<float>::infinity();
+        int bi = -1;
+        if (!nodes_.empty()) nn_rec(0, q, best, bi);
+        if (d2out) *d2out = best;
+        return bi;
+    }
+    void radius(const float *q, float r, std::vector<std::pair<float, int>> &out) const
+    {
+        out.clear();
+        if (nodes_.empty()) return;
+        rad_rec(0, q, r * r, out);
+        std::sort(out.begin(), out.end());
+    }
+private:
+    static constexpr int kLeaf = 12;
+    struct Node { int lo, hi, dim; float split; int left, right; };
+    const Pt *pts_ = nullptr;
+    std::vector<int> sub_, order_;
+    std::vector<Node> nodes_;
+
+    const float *p(int local) const { return &pts_[sub_.empty() ? local : sub_[local]].x; }
+
+    int build_rec(int lo, int hi)
+    {
+        int me = (int)nodes_.size();
+        nodes_.push_back({lo, hi, -1, 0.f, -1, -1});
+        if (hi - lo <= kLeaf) return me;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = lo; i < hi; ++i) {
+            const float *c = p(order_[i]);
+            for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
+        }
+        int dim = 0;
+        if (mx[1] - mn[1] > mx[dim] - mn[dim]) dim = 1;
+        if (mx[2] - mn[2] > mx[dim] - mn[dim]) dim = 2;
+        if (!(mx[dim] > mn[dim])) return me; /* all coincident: keep as a (big) leaf */
+        int mid = (lo + hi) / 2;
+        std::nth_element(order_.begin() + lo, order_.begin() + mid, order_.begin() + hi,
+                         [&](int a, int b) {
+                             float ca = p(a)[dim], cb = p(b)[dim];
+                             return ca < cb || (ca == cb && a < b);
+                         });
+        float split = p(order_[mid])[dim];
+        int l = build_rec(lo, mid);
+        int r = build_rec(mid, hi);
+        nodes_[me].dim = dim; nodes_[me].split = split; nodes_[me].left = l; nodes_[me].right = r;
+        return me;
+    }
+    void nn_rec(int ni, const float *q, float &best, int &bi) const
+    {
+        const Node &n = nodes_[ni];
+        if (n.dim < 0) {
+            for (int i = n.lo; i < n.hi; ++i) {
+                int id = order_[i];
+                float d = dist2(q, p(id));
+                if (d < best || (d == best && id < bi)) { best = d; bi = id; }
+            }
+            return;
+        }
+        float diff = q[n.dim] - n.split;
+        int near = diff < 0 ? n.left : n.right, far = diff < 0 ? n.right : n.left;
+        nn_rec(near, q, best, bi);
+        if (diff * diff <= best) nn_rec(far, q, best, bi);
+    }
+    void rad_rec(int ni, const float *q, float r2, std::vector<std::pair<float, int>> &out) const
+    {
+        const Node &n = nodes_[ni];
+        if (n.dim < 0) {
+            for (int i = n.lo; i < n.hi; ++i) {
+                int id = order_[i];
+                float d = dist2(q, p(id));
+                if (d <= r2) out.emplace_back(d, id); /* flann radiusSearch: dist <= radius^2 */
+            }
+            return;
+        }
+        float diff = q[n.dim] - n.split;
+        int near = diff < 0 ? n.left : n.right, far = diff < 0 ? n.right : n.left;
+        rad_rec(near, q, r2, out);
+        if (diff * diff <= r2) rad_rec(far, q, r2, out);
+    }
+};
+
+/* ------------------------------------------------------------------ */
+/* GSL steffen.c                                  */
+/* ------------------------------------------------------------------ */
+inline double steffen_copysign(double x, double y)
+{
+    if ((x < 0 && y > 0) || (x > 0 && y < 0)) return -x;
+    return x;
+}
+
+struct Steffen {
+    std::vector<double> x, a, b, c, d;
+    void init(const double *xs, const double *ys, int n)
+    {
+        x.assign(xs, xs + n);
+        a.assign(n, 0); b.assign(n, 0); c.assign(n, 0); d.assign(n, 0);
+        std::vector<double> yp(n);
+        double h0 = xs[1] - xs[0];
+        double s0 = (ys[1] - ys[0]) / h0;
+        yp[0] = s0;
+        for (int i = 1; i < n - 1; ++i) {
+            double hi = xs[i + 1] - xs[i];
+            double him1 = xs[i] - xs[i - 1];
+            double si = (ys[i + 1] - ys[i]) / hi;
+            double sim1 = (ys[i] - ys[i - 1]) / him1;
+            double pi = (sim1 * hi + si * him1) / (him1 + hi);
+            yp[i] = (steffen_copysign(1.0, sim1) + steffen_copysign(1.0, si)) *
+                    std::min(fabs(sim1), std::min(fabs(si), 0.5 * fabs(pi)));
+        }
+        yp[n - 1] = (ys[n - 1] - ys[n - 2]) / (xs[n - 1] - xs[n - 2]);
+        for (int i = 0; i < n - 1; ++i) {
+            double hi = xs[i + 1] - xs[i];
+            double si = (ys[i + 1] - ys[i]) / hi;
+            a[i] = (yp[i] + yp[i + 1] - 2 * si) / hi / hi;
+            b[i] = (3 * si - 2 * yp[i] - yp[i + 1]) / hi;
+            c[i] = yp[i];
+            d[i] = ys[i];
+        }
+    }
+    /* gsl_interp_bsearch(x_array, x, 0, size-1) */
+    int bsearch(double xq) const
+    {
+        size_t ilo = 0, ihi = x.size() - 1;
+        while (ihi > ilo + 1) {
+            size_t i = (ihi + ilo) / 2;
+            if (x[i] > xq) ihi = i; else ilo = i;
+        }
+        return (int)ilo;
+    }
+    bool in_domain(double xq) const { return !(xq < x.front() || xq > x.back()); }
+    double eval(double xq) const
+    {
+        int i = bsearch(xq);
+        double delta = xq - x[i];
+        return d[i] + delta * (c[i] + delta * (b[i] + delta * a[i]));
+    }
+};
+
+/* include/Spline.h:7-51 */
+struct Spline {
+    std::vector<double> y, x, z;
+    Steffen yx, yz;
+    double small_y = 0, big_y = 0;
+    void fit()
+    {
+        int n = (int)y.size();
+        yx.init(y.data(), x.data(), n);
+        yz.init(y.data(), z.data(), n);
+        small_y = y.front(); big_y = y.back();
+    }
+    void point(double yy, double out[3]) const { out[0] = yx.eval(yy); out[1] = yy; out[2] = yz.eval(yy); }
+};
+
+/* ------------------------------------------------------------------ */
+/* pcl::eigen33 (smallest eigenvalue form), SURVEY.md App. A.4         */
+/* ------------------------------------------------------------------ */
+void compute_roots2(float b, float c, float roots[3])
+{
+    roots[0] = 0.f;
+    float d = float(b * b - 4.0 * c); /* Scalar (b * b - 4.0 * c): double intermediate */
+    if (d < 0.0) d = 0.0;
+    float sd = std::sqrt(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+
+void compute_roots(const float m[3][3], float roots[3])
+{
+    float c0 = m[0][0] * m[1][1] * m[2][2] + 2.f * m[0][1] * m[0][2] * m[1][2] -
+               m[0][0] * m[1][2] * m[1][2] - m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+    float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] +
+               m[1][1] * m[2][2] - m[1][2] * m[1][2];
+    float c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::abs(c0) < std::numeric_limits<float>::epsilon()) {
+        compute_roots2(c2, c1, roots);
+        return;
+    }
+    const float s_inv3 = float(1.0 / 3.0);
+    const float s_sqrt3 = std::sqrt(3.0f);
+    float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.f) a_over_3 = 0.f;
+    float half_b = 0.5f * (c0 + c2_over_3 * (2.f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.f) q = 0.f;
+    float rho = std::sqrt(-a_over_3);
+    float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
+    float cos_theta = std::cos(theta);
+    float sin_theta = std::sin(theta);
+    roots[0] = c2_over_3 + 2.f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    if (roots[1] >= roots[2]) {
+        std::swap(roots[1], roots[2]);
+        if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    }
+    if (roots[0] <= 0) compute_roots2(c2, c1, roots);
+}
+
+inline void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+void eigen33_smallest(const float cov[9], float *eigenvalue, float ev[3])
+{
+    float scale = 0.f;
+    for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(cov[i]));
+    if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+    float m[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = cov[3 * i + j] / scale;
+    float roots[3];
+    compute_roots(m, roots);
+    *eigenvalue = roots[0] * scale;
+    m[0][0] -= roots[0]; m[1][1] -= roots[0]; m[2][2] -= roots[0];
+    /* detail::getLargest3x3Eigenvector: largest of the three row cross products */
+    float cp[3][3];
+    cross3(m[0], m[1], cp[0]);
+    cross3(m[0], m[2], cp[1]);
+    cross3(m[1], m[2], cp[2]);
+    float len[3];
+    for (int i = 0; i < 3; ++i) len[i] = std::sqrt(cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1] + cp[i][2] * cp[i][2]);
+    int idx = 0; /* maxCoeff: first maximum */
+    if (len[1] > len[idx]) idx = 1;
+    if (len[2] > len[idx]) idx = 2;
+    for (int d = 0; d < 3; ++d) ev[d] = cp[idx][d] / len[idx];
+}
+
+/* ------------------------------------------------------------------ */
+/* Eigen restatements                             */
+/* ------------------------------------------------------------------ */
+struct Quat { float w, x, y, z; };
+inline Quat quat_axis(float angle, int axis)
+{   /* Quaternion = AngleAxis: ha = 0.5*angle; w = cos(ha); vec = sin(ha)*axis */
+    float ha = 0.5f * angle;
+    float s = std::sin(ha);
+    Quat q{std::cos(ha), 0.f, 0.f, 0.f};
+    (&q.x)[axis] = s * 1.0f;
+    return q;
+}
+inline Quat quat_mul(const Quat &a, const Quat &b)
+{
+    return Quat{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+                a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+                a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+                a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+inline void quat_to_mat(const Quat &q, float R[3][3])
+{
+    const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
+    const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const float tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0][0] = 1.f - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+    R[1][0] = txy + twz; R[1][1] = 1.f - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1.f - (txx + tyy);
+}
+/* AngleAxisf(rz,Z)*AngleAxisf(ry,Y)*AngleAxisf(rx,X) assigned to a Matrix3f */
+inline void rot_zyx(float rx, float ry, float rz, float R[3][3])
+{
+    Quat q = quat_mul(quat_mul(quat_axis(rz, 2), quat_axis(ry, 1)), quat_axis(rx, 0));
+    quat_to_mat(q, R);
+}
+/* MatrixBase::eulerAngles(2,1,0): returns (e0,e1,e2) = (yaw,pitch,roll) */
+inline void euler_zyx(const float m[3][3], float e[3])
+{
+    const float kPi = 3.14159265358979323846f; /* Scalar(EIGEN_PI) */
+    e[0] = std::atan2(m[1][0], m[0][0]);
+    float c2 = std::sqrt(m[2][2] * m[2][2] + m[2][1] * m[2][1]);
+    if (e[0] < 0.f) {
+        e[0] += kPi;
+        e[1] = std::atan2(-m[2][0], -c2);
+    } else {
+        e[1] = std::atan2(-m[2][0], c2);
+    }
+    float s1 = std::sin(e[0]);
+    float c1 = std::cos(e[0]);
+    e[2] = std::atan2(s1 * m[0][2] - c1 * m[1][2], c1 * m[1][1] - s1 * m[0][1]);
+}
+
+/* path_translation_alg.cpp:3-35 */
+void handeye_transform(const float he[6], float wp[6])
+{
+    float HE[3][3], P[3][3];
+    rot_zyx(he[3], he[4], he[5], HE);
+    rot_zyx(wp[3], wp[4], wp[5], P);
+    float R[3][3], t[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            R[i][j] = HE[i][0] * P[0][j] + HE[i][1] * P[1][j] + HE[i][2] * P[2][j] + he[i] * 0.f;
+        t[i] = HE[i][0] * wp[0] + HE[i][1] * wp[1] + HE[i][2] * wp[2] + he[i] * 1.f;
+    }
+    float e[3];
+    euler_zyx(R, e);
+    wp[0] = t[0]; wp[1] = t[1]; wp[2] = t[2];
+    wp[3] = e[2]; wp[4] = e[1]; wp[5] = e[0];
+}
+
+/* path_translation_alg.cpp:192-202 */
+void pose_from_normal(const float n[3], float rpy[3])
+{
+    float A[3] = {-n[0], -n[1], -n[2]};
+    const float X[3] = {1.f, 0.f, 0.f};
+    float O[3], Nn[3];
+    cross3(A, X, O);
+    cross3(O, A, Nn);
+    float M[3][3];
+    for (int i = 0; i < 3; ++i) { M[i][0] = Nn[i]; M[i][1] = O[i]; M[i][2] = A[i]; }
+    float e[3];
+    euler_zyx(M, e);
+    rpy[0] = e[2]; rpy[1] = e[1]; rpy[2] = e[0];
+}
+
+/* path_translation_alg.cpp:114-141 (+ the stop rule documented at the top) */
+int position_smooth(std::vector<std::array<float, 6>> &list, int max_sweeps)
+{
+    std::vector<std::array<float, 6>> new_path(list);
+    double tolerance = 0.00001, change = tolerance, weight_data = 0.65, weight_smooth = 1 - weight_data;
+    double x_i, y_i, y_prev, y_next, y_i_saved;
+    int dim = 3, path_len = (int)list.size();
+    int sweeps = 0;
+    double prev_change = INFINITY;
+    while (change >= tolerance) {
+        change = 0;
+        for (int i = 1; i < path_len - 1; i++) {
+            for (int j = 0; j < dim; j++) {
+                x_i = list[i][j];
+                y_i = new_path[i][j];
+                y_prev = new_path[i - 1][j];
+                y_next = new_path[i + 1][j];
+                y_i_saved = y_i;
+                y_i += (weight_data * (x_i - y_i) + weight_smooth * (y_next + y_prev - 2 * y_i));
+                new_path[i][j] = (float)y_i;
+                change += fabs(y_i - y_i_saved);
+            }
+        }
+        ++sweeps;
+        if (sweeps >= 2 && change >= 0.9 * prev_change) break; /* float floor reached */
+        if (sweeps >= max_sweeps) break;
+        prev_change = change;
+    }
+    list = std::move(new_path);
+    return sweeps;
+}
+
+/* path_translation_alg.cpp:37-86.  `oob` is set when the B.6 read past the list is hit;
+   the offending do-while pass is then skipped (the reference has UB there). */
+void reduce_rpy(std::vector<std::array<float, 6>> &W, const std::vector<int> &Index, double RPYres, int *oob)
+{
+    if (RPYres <= 2) return;
+    int preId = 0, lastId = 0, res = (int)RPYres;
+    const int n = (int)W.size();
+    for (int id = 0; id < (int)Index.size(); id++) {
+        do {
+            double dr[3];
+            lastId = preId + res;
+            if (lastId >= n) { if (oob) *oob = 1; break; }
+            for (size_t D = 3; D < 6; D++) {
+                if (W[lastId][D] * W[preId][D] >= 0) {
+                    dr[D - 3] = (W[lastId][D] - W[preId][D]) / res;
+                } else {
+                    double no1, no2;
+                    if (W[lastId][D] < 0) {
+                        no2 = W[preId][D];
+                        no1 = 2 * M_PI + W[lastId][D];
+                    } else {
+                        no2 = 2 * M_PI + W[preId][D];
+                        no1 = W[lastId][D];
+                    }
+                    dr[D - 3] = std::abs(W[lastId][D] - W[preId][D]) < std::abs(no1 - no2)
+                                    ? (W[lastId][D] - W[preId][D]) : (no1 - no2);
+                    dr[D - 3] /= res;
+                }
+            }
+            for (int wi = 1; wi < res; wi++) {
+                W[preId + wi][3] = float(dr[0] + W[preId + wi - 1][3]);
+                W[preId + wi][4] = float(dr[1] + W[preId + wi - 1][4]);
+                W[preId + wi][5] = float(dr[2] + W[preId + wi - 1][5]);
+            }
+            preId = lastId;
+        } while ((preId + res) <= Index[id]);
+        if (preId != Index[id]) {
+            for (int i = preId + 1; i <= Index[id]; i++) {
+                W[i][3] = W[preId][3]; W[i][4] = W[preId][4]; W[i][5] = W[preId][5];
+            }
+        }
+        preId = Index[id] + 1;
+    }
+    for (auto &p : W)
+        for (int D = 3; D < 6; ++D) p[D] = p[D] > M_PI ? float(p[D] - 2 * M_PI) : p[D];
+}
+
+/* path_translation_alg.cpp:89-112 */
+void trans_flange(std::vector<std::array<float, 6>> &W, float EElen)
+{
+    const float ee[3] = {0.f, 0.f, -EElen};
+    for (auto &p : W) {
+        float R[3][3];
+        rot_zyx(p[3], p[4], p[5], R);
+        for (int i = 0; i < 3; ++i)
+            p[i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
+    }
+}
+
+} // namespace
+
+/* ====================================================================== */
+struct ppo_handle {
+    ppo_params P;
+    std::vector<Pt> cloud;
+    KdTree tree; bool tree_built = false;
+    std::vector<float> normals; /* 4 per point */
+    std::vector<uint8_t> normal_done;
+    std::vector<float> px;
+    std::vector<std::vector<int>> slice_idx;
+    std::vector<Spline> path_set;
+    std::vector<std::array<float, 6>> wp, wp_pre, wp_smooth;
+    std::vector<std::array<float, 3>> wp_xyz;
+    std::vector<std::array<float, 4>> wp_normal;
+    std::vector<int> wp_nn, tail;
+    int sweeps = 0, oob = 0;
+
+    void ensure_tree() { if (!tree_built) { tree.build(cloud.data(), nullptr, (int)cloud.size()); tree_built = true; } }
+    void rebuild_tree() { tree.build(cloud.data(), nullptr, (int)cloud.size()); tree_built = true; }
+
+    /* pcl::NormalEstimation::computeFeature for one point */
+    void point_normal(int idx, float out[4])
+    {
+        ensure_tree();
+        std::vector<std::pair<float, int>> nb;
+        const Pt &q = cloud[idx];
+        tree.radius(&q.x, P.normal_radius, nb);
+        const float nanv = std::numeric_limits<float>::quiet_NaN();
+        if (nb.size() < 3) { out[0] = out[1] = out[2] = out[3] = nanv; return; }
+        /* computeMeanAndCovarianceMatrix (PCL 1.12): shift by the first neighbour */
+        const Pt &K = cloud[nb[0].second];
+        float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (auto &e : nb) {
+            const Pt &c = cloud[e.second];
+            float x = c.x - K.x, y = c.y - K.y, z = c.z - K.z;
+            accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+            accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+            accu[6] += x; accu[7] += y; accu[8] += z;
+        }
+        float cnt = (float)nb.size();
+        for (int i = 0; i < 9; ++i) accu[i] /= cnt;
+        float cov[9];
+        cov[0] = accu[0] - accu[6] * accu[6];
+        cov[1] = accu[1] - accu[6] * accu[7];
+        cov[2] = accu[2] - accu[6] * accu[8];
+        cov[4] = accu[3] - accu[7] * accu[7];
+        cov[5] = accu[4] - accu[7] * accu[8];
+        cov[8] = accu[5] - accu[8] * accu[8];
+        cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+        float ev, n[3];
+        eigen33_smallest(cov, &ev, n);
+        float eig_sum = cov[0] + cov[4] + cov[8];
+        float curv = eig_sum != 0 ? std::abs(ev / eig_sum) : 0.f;
+        /* flipNormalTowardsViewpoint: vp = sensor origin, NOT scaled by the x1000 */
+        float vx = P.viewpoint[0] - q.x, vy = P.viewpoint[1] - q.y, vz = P.viewpoint[2] - q.z;
+        float cos_theta = vx * n[0] + vy * n[1] + vz * n[2];
+        if (cos_theta < 0) { n[0] *= -1; n[1] *= -1; n[2] *= -1; }
+        out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; out[3] = curv;
+    }
+    void estimate_normal_all()
+    {   /* path_slicing_alg.cpp:141-150: a fresh search tree + every point */
+        size_t n = cloud.size();
+        normals.assign(4 * n, 0.f);
+        normal_done.assign(n, 1);
+        rebuild_tree();
+        for (size_t i = 0; i < n; ++i) point_normal((int)i, &normals[4 * i]);
+    }
+    const float *normal_lazy(int idx)
+    {
+        if (normals.size() != 4 * cloud.size()) { normals.assign(4 * cloud.size(), 0.f); normal_done.assign(cloud.size(), 0); }
+        if (!normal_done[idx]) { point_normal(idx, &normals[4 * idx]); normal_done[idx] = 1; }
+        return &normals[4 * idx];
+    }
+
+    void minmax(float mn[3], float mx[3]) const
+    {   /* pcl::getMinMax3D: finite points only */
+        for (int d = 0; d < 3; ++d) { mn[d] = std::numeric_limits<float>::max(); mx[d] = -std::numeric_limits<float>::max(); }
+        for (const Pt &p : cloud) {
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+            mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
+        }
+    }
+
+    std::vector<float> slice_positions() const
+    {
+        float mn[3], mx[3];
+        minmax(mn, mx);
+        const float min_x = mn[0], max_x = mx[0];
+        const double toolRadius = P.tool_radius;
+        int step_size = int(toolRadius * 2);
+        std::vector<float> out;
+        if (step_size <= 0) return out;
+        switch (P.walk) {
+        case PPO_WALK_SECTPATH: { /* path_slicing_alg.cpp:308-330 */
+            std::vector<float> front;
+            float loc = (min_x + max_x) / 2 - step_size;
+            while (loc > min_x) { front.insert(front.begin(), loc); loc -= step_size; }
+            out = front;
+            loc = (min_x + max_x) / 2;
+            while (loc < max_x) { out.push_back(loc); loc += step_size; }
+            break;
+        }
+        case PPO_WALK_CENTER_INT: { /* path_dynamic_alg.cpp:308-372, Path_Generate_Algorithm.h:112 */
+            int imin = (int)min_x, imax = (int)max_x;
+            std::vector<float> front, back;
+            int loc = (imax + imin) / 2;
+            loc -= step_size;
+            while (imax > loc && loc > imin) { front.push_back((float)loc); loc -= step_size; }
+            loc = (imax + imin) / 2 + step_size;
+            while (imax > loc && loc > imin) { back.push_back((float)loc); loc += step_size; }
+            out.assign(front.rbegin(), front.rend());
+            out.push_back((min_x + max_x) / 2);
+            out.insert(out.end(), back.begin(), back.end());
+            break;
+        }
+        case PPO_WALK_SDIR_INT: { /* dynamic_alg_sdir.cpp:349-374 */
+            int loc = int(min_x + toolRadius);
+            out.push_back((float)loc);
+            loc += step_size;
+            while (loc < max_x) { out.push_back((float)loc); loc += step_size; }
+            break;
+        }
+        case PPO_WALK_V1_CONTACT: { /* Path_Generation.cpp:711-725 */
+            float locateX = float(min_x + toolRadius);
+            while (locateX < max_x) { out.push_back(locateX); locateX += step_size; }
+            break;
+        }
+        case PPO_WALK_V1_SLICING: { /* Path_Generation.cpp:295-304 */
+            float x = min_x;
+            x += step_size / 2;
+            while (x < max_x) { out.push_back(x); x += step_size; }
+            break;
+        }
+        }
+        return out;
+    }
+
+    /* pcl::PassThrough on "x", limits [-2+position, 2+position] (App. A.2) */
+    std::vector<int> ranged_x_index(int position) const
+    {
+        std::vector<int> indices;
+        const float lo = float(-2 + position), hi = float(2 + position);
+        const int n = (int)cloud.size();
+        for (int i = 0; i < n; ++i) {
+            const Pt &p = cloud[i];
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            if (p.x < lo || p.x > hi) continue;
+            indices.push_back(i);
+        }
+        return indices;
+    }
+
+    /* one pass bucketing of all slices (fast mode; same lists as ranged_x_index) */
+    void bucket_slices(const std::vector<float> &planes, std::vector<std::vector<int>> &lists) const
+    {
+        int S = (int)planes.size();
+        lists.assign(S, {});
+        std::vector<float> lo(S), hi(S);
+        for (int s = 0; s < S; ++s) { int pos = (int)planes[s]; lo[s] = float(-2 + pos); hi[s] = float(2 + pos); }
+        const int n = (int)cloud.size();
+        for (int i = 0; i < n; ++i) {
+            const Pt &p = cloud[i];
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            /* first slice whose hi >= x (hi ascending) */
+            int s = int(std::lower_bound(hi.begin(), hi.end(), p.x) - hi.begin());
+            for (; s < S && lo[s] <= p.x; ++s)
+                if (!(p.x < lo[s] || p.x > hi[s])) lists[s].push_back(i);
+        }
+    }
+
+    /* returns node map or error (<0) */
+    int insert_point(const std::vector<int> &indices, float plane_x, std::map<double, std::array<double, 2>> &Node)
+    {
+        std::vector<int> El, Er;
+        for (int i : indices) {
+            float distance2plane = (cloud[i].x - plane_x) * 1.f + (cloud[i].y - 0.f) * 0.f + (cloud[i].z - 0.f) * 0.f;
+            if (distance2plane > 0) El.push_back(i);
+            else if (distance2plane < 0) Er.push_back(i);
+        }
+        std::vector<int> left_pair, right_pair;
+        if (P.pairing == PPO_PAIR_KD) {
+            /* path_slicing_alg.cpp:184-210 */
+            if (El.empty()) { Node.clear(); return 0; }
+            if (Er.empty()) return -1; /* empty FLANN tree: the reference crashes */
+            KdTree treeEl, treeEr;
+            treeEl.build(cloud.data(), El.data(), (int)El.size());
+            treeEr.build(cloud.data(), Er.data(), (int)Er.size());
+            for (int i = 0; i < (int)El.size(); i++) {
+                const Pt &pl = cloud[El[i]];
+                int r = treeEr.nearest(&pl.x);
+                const Pt &pr = cloud[Er[r]];
+                /* kdtree.nearestKSearch(pr,1) on the full cloud returns pr itself (or a
+                   coordinate duplicate: same values either way) */
+                right_pair.push_back(Er[r]);
+                int l = treeEl.nearest(&pr.x);
+                left_pair.push_back(El[l]);
+            }
+        } else {
+            /* Path_Generation.cpp:129-179 */
+            std::vector<int> El_flag(El.size(), 0), Er_flag(Er.size(), 0);
+            int rp_index = 0;
+            for (int i = 0; i < int(El.size()); i++) {
+                if (El_flag[i] == 0) {
+                    if (Er.empty()) return -1; /* compare.begin() on an empty map */
+                    /* std::map<float,int> compare; compare[norm] = j  => smallest norm, last j */
+                    float best = 0; int bj = -1;
+                    for (int j = 0; j < int(Er.size()); j++) {
+                        float vx = cloud[El[i]].x - cloud[Er[j]].x;
+                        float vy = cloud[El[i]].y - cloud[Er[j]].y;
+                        float vz = cloud[El[i]].z - cloud[Er[j]].z;
+                        float nrm = std::sqrt(vx * vx + (vy * vy + vz * vz)); /* Vector3f::norm() */
+                        if (bj < 0 || nrm <= best) { best = nrm; bj = j; }
+                    }
+                    if (Er_flag[bj] == 0) {
+                        rp_index = Er[bj];
+                        right_pair.push_back(rp_index);
+                        Er_flag[bj] = 1;
+                    } else
+                        continue;
+                    best = 0; bj = -1;
+                    for (int j = 0; j < int(El.size()); j++) {
+                        float vx = cloud[rp_index].x - cloud[El[j]].x;
+                        float vy = cloud[rp_index].y - cloud[El[j]].y;
+                        float vz = cloud[rp_index].z - cloud[El[j]].z;
+                        float nrm = std::sqrt(vx * vx + (vy * vy + vz * vz));
+                        if (bj < 0 || nrm <= best) { best = nrm; bj = j; }
+                    }
+                    if (El_flag[bj] == 0) {
+                        left_pair.push_back(El[bj]);
+                        El_flag[bj] = 1;
+                    }
+                }
+            }
+        }
+        Node.clear();
+        for (int i = 0; i < (int)left_pair.size(); i++) {
+            int index_right = right_pair[i], index_left = left_pair[i];
+            float t = (plane_x - cloud[index_right].x) / (cloud[index_left].x - cloud[index_right].x);
+            float ix = plane_x;
+            float iy = cloud[index_right].y + t * (cloud[index_left].y - cloud[index_right].y);
+            float iz = cloud[index_right].z + t * (cloud[index_left].z - cloud[index_right].z);
+            Node[(double)iy] = {(double)ix, (double)iz};
+        }
+        return (int)Node.size();
+    }
+
+    int gen_path()
+    {
+        path_set.clear();
+        slice_idx.clear();
+        bool derived = (P.walk == PPO_WALK_CENTER_INT || P.walk == PPO_WALK_SDIR_INT);
+        if (P.reference_complexity) {
+            /* path_dynamic_alg.cpp:343-344 / path_slicing_alg.cpp:295 */
+            if (derived) estimate_normal_all();
+            rebuild_tree();
+        }
+        px = slice_positions();
+        int S = (int)px.size();
+        if (!P.reference_complexity) bucket_slices(px, slice_idx);
+        else slice_idx.resize(S);
+        path_set.resize(S);
+        for (int s = 0; s < S; ++s) {
+            /* OnePath / path_track: rangedX_index(int(plane_point[0])) */
+            if (P.reference_complexity) slice_idx[s] = ranged_x_index((int)px[s]);
+            std::map<double, std::array<double, 2>> Node;
+            int m = insert_point(slice_idx[s], px[s], Node);
+            if (m < 3) return -(1 + s); /* gsl_spline_alloc / FLANN would abort */
+            Spline &sp = path_set[s];
+            for (auto &kv : Node) { sp.y.push_back(kv.first); sp.x.push_back(kv.second[0]); sp.z.push_back(kv.second[1]); }
+            sp.fit();
+        }
+        return S;
+    }
+
+    int get_path()
+    {
+        wp.clear(); wp_pre.clear(); wp_smooth.clear(); wp_xyz.clear(); wp_normal.clear(); wp_nn.clear(); tail.clear();
+        sweeps = 0; oob = 0;
+        /* path_translation_alg.cpp:149-150 */
+        std::vector<const Spline *> kept;
+        int S = (int)path_set.size();
+        int first = P.drop_ends ? 1 : 0, last = P.drop_ends ? S - 1 : S;
+        for (int s = first; s < last; ++s) kept.push_back(&path_set[s]);
+        /* :156-169, invTransAlign = identity (Alignment = false) */
+        std::vector<std::vector<std::array<float, 3>>> lists;
+        int flag = 1;
+        for (const Spline *path : kept) {
+            std::vector<std::array<float, 3>> one;
+            double dy = path->small_y + P.trim;
+            while (dy < path->big_y - P.trim) {
+                double p[3];
+                path->point(dy, p);
+                one.push_back({(float)p[0], (float)p[1], (float)p[2]});
+                dy += P.path_resolution;
+            }
+            if (flag == -1) std::reverse(one.begin(), one.end());
+            lists.push_back(one);
+            flag *= -1;
+        }
+        /* :173-174 */
+        if (P.reference_complexity) { rebuild_tree(); estimate_normal_all(); }
+        else ensure_tree();
+        for (auto &one : lists) {
+            for (auto &q : one) {
+                int id = tree.nearest(q.data());
+                const float *N = P.reference_complexity ? &normals[4 * (size_t)id] : normal_lazy(id);
+                float rpy[3];
+                pose_from_normal(N, rpy);
+                std::array<float, 6> w;
+                if (P.change_range) w = {q[0] / 1000, q[1] / 1000, q[2] / 1000, rpy[0], rpy[1], rpy[2]};
+                else w = {q[0], q[1], q[2], rpy[0], rpy[1], rpy[2]};
+                handeye_transform(P.handeye, w.data());
+                wp.push_back(w);
+                wp_xyz.push_back(q);
+                wp_nn.push_back(id);
+                wp_normal.push_back({N[0], N[1], N[2], N[3]});
+            }
+            tail.push_back((int)wp.size() - 1);
+        }
+        wp_pre = wp;
+        if (P.smooth && wp.size() > 0) sweeps = position_smooth(wp, P.smooth_max_sweeps);
+        wp_smooth = wp;
+        reduce_rpy(wp, tail, P.rpy_resolution, &oob);
+        trans_flange(wp, P.ee_length);
+        return (int)wp.size();
+    }
+};
+
+/* ====================================================================== */
+extern "C" {
+
+void ppo_default_params(ppo_params *p)
+{   /* config.txt:1-13 and Path_Generate_Algorithm.h:43-48 */
+    memset(p, 0, sizeof(*p));
+    p->tool_radius = 12; p->path_resolution = 7; p->rpy_resolution = 7; p->ee_length = 0.3f;
+    p->change_range = 1; p->pairing = PPO_PAIR_KD; p->walk = PPO_WALK_CENTER_INT;
+    p->trim = 10; p->drop_ends = 1; p->smooth = 1;
+    const float he[6] = {-0.764091f, 0.025886f, 0.663790f, -3.1270175f, -0.040124f, -1.6063578f};
+    memcpy(p->handeye, he, sizeof(he));
+    p->normal_radius = 2.5f;
+    p->reference_complexity = 0;
+    p->smooth_max_sweeps = 200;
+}
+
+ppo_handle *ppo_create(const float *xyz, size_t n, size_t stride, const ppo_params *p)
+{
+    ppo_handle *h = new ppo_handle();
+    h->P = *p;
+    h->cloud.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        Pt &q = h->cloud[i];
+        q.x = xyz[i * stride + 0]; q.y = xyz[i * stride + 1]; q.z = xyz[i * stride + 2];
+        q.pad0 = 1.f; q.rgba = 0x00ffffffu; q.pad1[0] = q.pad1[1] = q.pad1[2] = 0.f;
+        if (p->change_range) { q.x *= 1000; q.y *= 1000; q.z *= 1000; } /* path_slicing_alg.cpp:19-23 */
+    }
+    return h;
+}
+void ppo_destroy(ppo_handle *h) { delete h; }
+size_t ppo_num_points(const ppo_handle *h) { return h->cloud.size(); }
+void ppo_get_points(const ppo_handle *h, float *o)
+{
+    for (size_t i = 0; i < h->cloud.size(); ++i) { o[3 * i] = h->cloud[i].x; o[3 * i + 1] = h->cloud[i].y; o[3 * i + 2] = h->cloud[i].z; }
+}
+void ppo_minmax(const ppo_handle *h, float mn[3], float mx[3]) { h->minmax(mn, mx); }
+
+int ppo_slice_positions(const ppo_handle *h, float *px, int cap)
+{
+    std::vector<float> v = h->slice_positions();
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) px[i] = v[i];
+    return (int)v.size();
+}
+int ppo_ranged_x_index(const ppo_handle *h, int position, int *out, int cap)
+{
+    std::vector<int> v = h->ranged_x_index(position);
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+int ppo_insert_point(ppo_handle *h, const int *indices, int n, float plane_x, double *y, double *x, double *z, int cap)
+{
+    std::vector<int> idx(indices, indices + n);
+    std::map<double, std::array<double, 2>> Node;
+    int m = h->insert_point(idx, plane_x, Node);
+    if (m < 0) return m;
+    int k = 0;
+    for (auto &kv : Node) {
+        if (k < cap) { y[k] = kv.first; x[k] = kv.second[0]; z[k] = kv.second[1]; }
+        ++k;
+    }
+    return m;
+}
+int ppo_gen_path(ppo_handle *h) { return h->gen_path(); }
+int ppo_num_slices(const ppo_handle *h) { return (int)h->path_set.size(); }
+int ppo_get_nodes(const ppo_handle *h, int s, double *y, double *x, double *z, int cap)
+{
+    const Spline &sp = h->path_set[s];
+    int m = (int)sp.y.size();
+    for (int i = 0; i < m && i < cap; ++i) { y[i] = sp.y[i]; x[i] = sp.x[i]; z[i] = sp.z[i]; }
+    return m;
+}
+int ppo_get_slice_indices(const ppo_handle *h, int s, int *out, int cap)
+{
+    const std::vector<int> &v = h->slice_idx[s];
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+int ppo_eval_spline(const ppo_handle *h, int s, const double *y, int k, double *xyz)
+{
+    const Spline &sp = h->path_set[s];
+    int rc = 0;
+    for (int i = 0; i < k; ++i) {
+        if (!sp.yx.in_domain(y[i])) { xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = NAN; rc = -1; continue; }
+        sp.point(y[i], &xyz[3 * i]);
+    }
+    return rc;
+}
+int ppo_get_path(ppo_handle *h) { return h->get_path(); }
+int ppo_num_waypoints(const ppo_handle *h) { return (int)h->wp.size(); }
+static void copy6(const std::vector<std::array<float, 6>> &v, float *o) { for (size_t i = 0; i < v.size(); ++i) memcpy(o + 6 * i, v[i].data(), 24); }
+void ppo_get_waypoints(const ppo_handle *h, float *o) { copy6(h->wp, o); }
+void ppo_get_waypoints_presmooth(const ppo_handle *h, float *o) { copy6(h->wp_pre, o); }
+void ppo_get_waypoints_smoothed(const ppo_handle *h, float *o) { copy6(h->wp_smooth, o); }
+int ppo_get_tail_index(const ppo_handle *h, int *tail, int cap)
+{
+    for (int i = 0; i < (int)h->tail.size() && i < cap; ++i) tail[i] = h->tail[i];
+    return (int)h->tail.size();
+}
+void ppo_get_waypoints_xyz(const ppo_handle *h, float *o) { for (size_t i = 0; i < h->wp_xyz.size(); ++i) memcpy(o + 3 * i, h->wp_xyz[i].data(), 12); }
+void ppo_get_waypoint_nn(const ppo_handle *h, int *nn) { for (size_t i = 0; i < h->wp_nn.size(); ++i) nn[i] = h->wp_nn[i]; }
+void ppo_get_waypoint_normals(const ppo_handle *h, float *o) { for (size_t i = 0; i < h->wp_normal.size(); ++i) memcpy(o + 4 * i, h->wp_normal[i].data(), 16); }
+int ppo_smooth_sweeps(const ppo_handle *h) { return h->sweeps; }
+int ppo_rpy_oob(const ppo_handle *h) { return h->oob; }
+
+void ppo_estimate_normals(ppo_handle *h, float *n4)
+{
+    h->estimate_normal_all();
+    memcpy(n4, h->normals.data(), h->normals.size() * sizeof(float));
+}
+void ppo_normal_at(ppo_handle *h, int idx, float n4[4]) { h->point_normal(idx, n4); }
+int ppo_nearest(ppo_handle *h, const float q[3], float *d2) { h->ensure_tree(); return h->tree.nearest(q, d2); }
+int ppo_radius_search(ppo_handle *h, const float q[3], float r, int *out, int cap)
+{
+    h->ensure_tree();
+    std::vector<std::pair<float, int>> nb;
+    h->tree.radius(q, r, nb);
+    for (int i = 0; i < (int)nb.size() && i < cap; ++i) out[i] = nb[i].second;
+    return (int)nb.size();
+}
+
+int ppo_steffen(int n, const double *xs, const double *ys, const double *xq, int k, double *out)
+{
+    if (n < 3) return -1; /* steffen min_size = 3 */
+    for (int i = 1; i < n; ++i) if (!(xs[i] > xs[i - 1])) return -2;
+    Steffen st; st.init(xs, ys, n);
+    int rc = 0;
+    for (int i = 0; i < k; ++i) {
+        if (!st.in_domain(xq[i])) { out[i] = NAN; rc = -3; continue; }
+        out[i] = st.eval(xq[i]);
+    }
+    return rc;
+}
+void ppo_eigen33(const float cov[9], float *ev, float vec[3]) { eigen33_smallest(cov, ev, vec); }
+void ppo_euler_zyx(const float m[9], float e[3])
+{
+    float M[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[i][j] = m[3 * i + j];
+    euler_zyx(M, e);
+}
+void ppo_handeye(const float he[6], float wp[6]) { handeye_transform(he, wp); }
+void ppo_pose_from_normal(const float n[3], float rpy[3]) { pose_from_normal(n, rpy); }
+int ppo_position_smooth(float *wp6, int n, int max_sweeps)
+{
+    std::vector<std::array<float, 6>> v(n);
+    for (int i = 0; i < n; ++i) memcpy(v[i].data(), wp6 + 6 * i, 24);
+    int s = position_smooth(v, max_sweeps);
+    for (int i = 0; i < n; ++i) memcpy(wp6 + 6 * i, v[i].data(), 24);
+    return s;
+}
+int ppo_reduce_rpy(float *wp6, int n, const int *tail, int ntail, double rpy_res)
+{
+    std::vector<std::array<float, 6>> v(n);
+    for (int i = 0; i < n; ++i) memcpy(v[i].data(), wp6 + 6 * i, 24);
+    std::vector<int> t(tail, tail + ntail);
+    int oob = 0;
+    reduce_rpy(v, t, rpy_res, &oob);
+    for (int i = 0; i < n; ++i) memcpy(wp6 + 6 * i, v[i].data(), 24);
+    return oob;
+}
+void ppo_trans_flange(float *wp6, int n, float ee_len)
+{
+    std::vector<std::array<float, 6>> v(n);
+    for (int i = 0; i < n; ++i) memcpy(v[i].data(), wp6 + 6 * i, 24);
+    trans_flange(v, ee_len);
+    for (int i = 0; i < n; ++i) memcpy(wp6 + 6 * i, v[i].data(), 24);
+}
+
+} /* extern "C" */
