@@ -1,0 +1,159 @@
+/*
+ * ppp_hip.h -- C ABI of the MI355X (gfx950) polishing-path engine.
+ *
+ * This is the drop-in boundary: the reference's planner classes
+ * (include/Path_Generate.h, include/Path_Generate_Algorithm.h,
+ * include/robot_path.h of tsai0507/PolishPathPlanning) keep their public
+ * methods and forward the arithmetic to these entry points; see
+ * INTEGRATION.md for the binding a maintainer adds.  Plain C types only, an
+ * opaque handle, caller-allocated outputs (two-call size query: pass cap = 0
+ * to learn the count), `int` status everywhere (0 = ok, < 0 = error; nothing
+ * throws or aborts across the boundary).  One handle = one device + one HIP
+ * stream; distinct handles may be used from distinct threads.
+ *
+ * Each entry point cites the reference code it replaces (file:line relative
+ * to the reference tree).
+ */
+#ifndef PPP_HIP_H
+#define PPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ppp_handle_s *ppp_handle;
+
+/* status codes */
+enum {
+    PPP_OK = 0,
+    PPP_ERR_ARG = -1,          /* bad argument / call order                                  */
+    PPP_ERR_HIP = -2,          /* a HIP runtime call failed (ppp_last_error has the text)     */
+    PPP_ERR_NO_DEVICE = -3,    /* no gfx950 device: the engine has no CPU fallback            */
+    PPP_ERR_SLICE = -4,        /* a slice has an empty side or < 3 nodes: the reference aborts
+                                  there; ppp_failed_slice() names it     */
+    PPP_ERR_CAPACITY = -5,     /* an internal capacity was exceeded (reported, never silent)  */
+    PPP_ERR_DOMAIN = -6,       /* spline evaluated outside [miny, bigy] (GSL_EDOM)            */
+    PPP_ERR_UNSUPPORTED = -7,  /* option outside the hot-path scope (e.g. Alignment=true)     */
+    PPP_ERR_IO = -8
+};
+
+/* insert_point flavour */
+enum { PPP_PAIR_KD = 0,      /* src/Path_Alg/path_slicing_alg.cpp:164-237 (connect, connect1, contour) */
+       PPP_PAIR_BRUTE = 1    /* src/Path_Generation.cpp:107-206 (./main)                                */ };
+
+/* slice-position walk */
+enum { PPP_WALK_SECTPATH = 0,   /* SectPath::GenPath, path_slicing_alg.cpp:308-330        */
+       PPP_WALK_CENTER_INT = 1, /* path_generater::GenPath + thread_worker,
+                                   path_dynamic_alg.cpp:308-372 (connect)                  */
+       PPP_WALK_SDIR_INT = 2,   /* dynamic_alg_sdir.cpp:349-374 (connect1)                */
+       PPP_WALK_V1_CONTACT = 3, /* Contact_Path_Generation, Path_Generation.cpp:711-725   */
+       PPP_WALK_V1_SLICING = 4  /* slicing_method, Path_Generation.cpp:295-304            */ };
+
+/* All config.txt keys (config.txt:1-13) + the compile-time constants of the reference. */
+typedef struct ppp_params {
+    double tool_radius;       /* Tool_Radius                                                  */
+    double path_resolution;   /* PathResolution                                               */
+    double rpy_resolution;    /* RPYresolution                                                */
+    float  ee_length;         /* End effector length (m)                                      */
+    int    change_range;      /* ChangeRange                                                  */
+    int    pairing;           /* PPP_PAIR_*                                                   */
+    int    walk;              /* PPP_WALK_*                                                   */
+    double trim;              /* 10: path_translation_alg.cpp:158-159; 5: contour_alg.cpp:496 */
+    int    drop_ends;         /* 1: path_translation_alg.cpp:149-150                          */
+    int    smooth;            /* 1: postion_smooth() applied (path_translation_alg.cpp:212)   */
+    float  handeye[6];        /* HANDEYEx..rz (Path_Generate_Algorithm.h:43-48)               */
+    float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
+    int    smooth_max_sweeps; /* cap of the smoothing loop                   */
+    int    alignment;         /* Alignment / Smooth / RemoveOutlier: must be 0 (next rows)    */
+    int    dynamic_adjustment;/* Dynamic_adjustment: must be 0          */
+} ppp_params;
+
+void ppp_default_params(ppp_params *p);
+
+/* ---- lifetime ---- */
+int ppp_create(int device_id, ppp_handle *out);
+int ppp_destroy(ppp_handle h);
+const char *ppp_last_error(ppp_handle h);
+const char *ppp_version(void);
+
+int ppp_set_params(ppp_handle h, const ppp_params *p);
+
+/* Replaces the constructors' load + scale loop (path_slicing_alg.cpp:10-25,
+ * Path_Generation.cpp:8-34, path_dynamic_alg.cpp:12-28): takes the points as read from
+ * the PCD (xyz every `stride_bytes`: 32 = pcl::PointXYZRGB, 16, or 12 packed), applies
+ * the x1000 when change_range is set, keeps the cloud resident in HBM.
+ * viewpoint = PCD VIEWPOINT translation (cloud.sensor_origin_), NULL = origin. */
+int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_bytes, const float *viewpoint);
+/* same, the buffer already lives on this handle's device */
+int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
+int ppp_num_points(ppp_handle h, size_t *n);
+
+/* ---- whole hot path, asynchronous on the handle's stream ---- */
+/* GenPath(): getMinMax3D + slice walk + rangedX_index + insert_point + Spline for every
+ * slice (path_slicing_alg.cpp:290-342, path_dynamic_alg.cpp:337-372 with Adjust=false,
+ * Path_Generation.cpp:282-304,659-727 without the dynamic adjustment). */
+int ppp_gen_path_async(ppp_handle h);
+/* getPath(): path_translation_alg.cpp:144-214 (sampling, normals, pose, HandEye, smoothing,
+ * reduceRPY, TransFlangeposition); the list stays in HBM. */
+int ppp_get_path_async(ppp_handle h);
+/* waits for the stream, then reports deferred device-side errors */
+int ppp_sync(ppp_handle h);
+int ppp_failed_slice(ppp_handle h);
+
+/* ---- results (each call synchronises the handle's stream) ---- */
+int ppp_num_slices(ppp_handle h, int *S);
+int ppp_num_waypoints(ppp_handle h, size_t *W);
+/* WayPointsList: W x 6 floats (x y z roll pitch yaw), what getPath writes to pathFile
+ * (path_translation_alg.cpp:216-228) */
+int ppp_get_waypoints(ppp_handle h, float *out6, size_t cap, size_t *W);
+/* device pointer of the same list (valid until the next ppp_get_path_async / destroy) */
+int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W);
+/* TailIndex (path_translation_alg.cpp:177,210) */
+int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n);
+
+/* pcl::getMinMax3D (path_slicing_alg.cpp:303) */
+int ppp_minmax(ppp_handle h, float mn[3], float mx[3]);
+/* plane x of every slice in Path_set order */
+int ppp_get_slice_positions(ppp_handle h, float *px, size_t cap, size_t *S);
+/* rangedX_index result of slice s, ascending cloud indices */
+int ppp_get_slice_indices(ppp_handle h, int s, int *out, size_t cap, size_t *n);
+/* Spline knots of slice s (ascending y): what OnePath / path_track feed to Spline() */
+int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t cap, size_t *m);
+/* Spline::point(y) of slice s (include/Spline.h:22-25): xyz[3*i..] */
+int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz);
+
+/* ---- single-call mirrors of the reference's public methods ---- */
+/* rangedX_index(int position) (path_slicing_alg.cpp:152-162, Path_Generation.cpp:94-104) */
+int ppp_ranged_x_index(ppp_handle h, int position, int *out, size_t cap, size_t *n);
+/* insert_point(indices, PlanePoint) (path_slicing_alg.cpp:164-237 / Path_Generation.cpp:107-206);
+ * returns the MAP flattened in key order */
+int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x,
+                     double *y, double *x, double *z, size_t cap, size_t *m);
+/* estimate_normal() (path_slicing_alg.cpp:141-150) evaluated at the given cloud indices:
+ * out4 = nx ny nz curvature */
+int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4);
+/* kdtree.nearestKSearch(q, 1) on the whole cloud for k query points */
+int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx);
+
+/* ---- intermediate stages of getPath, for stage-by-stage parity tests ---- */
+enum { PPP_STAGE_WP_XYZ = 0,      /* W x 3 float: sampled points, mm (path_translation_alg.cpp:156-169) */
+       PPP_STAGE_WP_NN = 1,       /* W int: nearest cloud index (:189)                                  */
+       PPP_STAGE_WP_NORMAL = 2,   /* W x 4 float: normal + curvature (:190)                             */
+       PPP_STAGE_WP_PRESMOOTH = 3,/* W x 6 float: after HandEyeTransform (:208)                         */
+       PPP_STAGE_WP_SMOOTHED = 4  /* W x 6 float: after postion_smooth (:212)                           */ };
+int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *count);
+int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
+
+/* ---- measurement ---- */
+/* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
+int ppp_enable_timing(ppp_handle h, int on);
+/* names: cap entries of 48 chars; ms: last recorded duration of each kernel */
+int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

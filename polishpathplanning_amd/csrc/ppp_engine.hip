@@ -1,0 +1,751 @@
+/*
+ * ppp_engine.hip -- host side of the C ABI declared in include/ppp_hip.h.
+ *
+ * One handle = one device, one HIP stream, one resident cloud.  All device memory is
+ * allocated when the cloud / parameters are set (the "plan"); the two hot calls
+ * ppp_gen_path_async / ppp_get_path_async only enqueue kernels -- no allocation, no host
+ * synchronisation -- so a caller may overlap handles, capture them, or time them.
+ * There is no CPU fallback: without a HIP device every entry point fails loudly.
+ */
+#include "ppp_kernels.h"
+#include "../../include/ppp_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define PPP_VERSION_STR "polishpathplanning_amd 0.1 (gfx950)"
+
+namespace {
+
+struct KTimer {
+    std::string name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool used = false;
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (n == 0) n = 1;
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct ppp_handle_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    ppp_params P;
+    float vp[3] = {0, 0, 0};
+    size_t n = 0;
+    bool have_cloud = false, planned = false, index_built = false, gen_done = false, path_done = false;
+    int max_lds = 65536;
+
+    /* plan */
+    int B = 1, slab_cap = 4096, S_cap = 1, capb = 2048, W_cap = 1, node_cap = 1;
+    float h_mn[3] = {0, 0, 0}, h_mx[3] = {0, 0, 0};
+    int h_nvalid = 0;
+
+    DevBuf<float> X, Y, Z;
+    DevBuf<float4> unsorted4, sorted4;
+    DevBuf<int> slab_cnt, slab_start, slab_cursor;
+    DevBuf<float> slab_xmin, slab_xmax;
+    DevBuf<DevMeta> meta;
+    DevBuf<float> px, lo, hi;
+    DevBuf<float> node_y, node_z;
+    DevBuf<int> node_start, node_cnt, band_cnt;
+    DevBuf<int> wp_cnt, wp_off, tail;
+    DevBuf<float4> wp_xyz, wp_normal;
+    DevBuf<int> wp_nn;
+    DevBuf<float> wp_pre, wp_smooth, wp_out, sx, ya, yb;
+    DevBuf<char> scratch; /* API staging */
+
+    DevMeta hmeta;
+    bool timing = false;
+    std::vector<KTimer> timers;
+
+    ~ppp_handle_s()
+    {
+        (void)hipSetDevice(device);
+        X.release(); Y.release(); Z.release(); unsorted4.release(); sorted4.release();
+        slab_cnt.release(); slab_start.release(); slab_cursor.release(); slab_xmin.release(); slab_xmax.release();
+        meta.release(); px.release(); lo.release(); hi.release(); node_y.release(); node_z.release();
+        node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
+        wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
+        sx.release(); ya.release(); yb.release(); scratch.release();
+        for (auto &t : timers) { if (t.e0) (void)hipEventDestroy(t.e0); if (t.e1) (void)hipEventDestroy(t.e1); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int fail(ppp_handle h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCHK(h, expr)                                                                               \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(h, PPP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+DevParams dev_params(const ppp_handle h)
+{
+    DevParams D;
+    memset(&D, 0, sizeof(D));
+    D.tool_radius = h->P.tool_radius; D.path_resolution = h->P.path_resolution; D.rpy_resolution = h->P.rpy_resolution;
+    D.trim = h->P.trim; D.ee_length = h->P.ee_length; D.normal_radius = h->P.normal_radius;
+    memcpy(D.handeye, h->P.handeye, sizeof(D.handeye));
+    memcpy(D.viewpoint, h->vp, sizeof(D.viewpoint));
+    D.change_range = h->P.change_range; D.pairing = h->P.pairing; D.walk = h->P.walk; D.drop_ends = h->P.drop_ends;
+    D.smooth = h->P.smooth; D.smooth_max_sweeps = h->P.smooth_max_sweeps;
+    return D;
+}
+
+KTimer *timer_for(ppp_handle h, const char *name)
+{
+    for (auto &t : h->timers) if (t.name == name) return &t;
+    h->timers.emplace_back();
+    KTimer &t = h->timers.back();
+    t.name = name;
+    (void)hipEventCreate(&t.e0);
+    (void)hipEventCreate(&t.e1);
+    return &t;
+}
+
+/* launch helper: optional hipEvent bracket on the handle's stream */
+#define LAUNCH(h, name, kern, grid, block, shmem, ...)                                                \
+    do {                                                                                              \
+        KTimer *_t = (h)->timing ? timer_for((h), name) : nullptr;                                    \
+        if (_t) (void)hipEventRecord(_t->e0, (h)->stream);                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (h)->stream, __VA_ARGS__);         \
+        if (_t) { (void)hipEventRecord(_t->e1, (h)->stream); _t->used = true; }                       \
+        hipError_t _le = hipGetLastError();                                                           \
+        if (_le != hipSuccess) return fail((h), PPP_ERR_HIP, std::string(name) + ": " + hipGetErrorString(_le)); \
+    } while (0)
+
+int validate_params(ppp_handle h, const ppp_params *p)
+{
+    if (!(p->tool_radius > 0) || (int)(p->tool_radius * 2) <= 0) return fail(h, PPP_ERR_ARG, "Tool_Radius must give an integer step >= 1");
+    if (!(p->path_resolution > 0)) return fail(h, PPP_ERR_ARG, "PathResolution must be > 0");
+    if (!(p->trim >= 0)) return fail(h, PPP_ERR_ARG, "trim must be >= 0");
+    if (p->pairing != PPP_PAIR_KD && p->pairing != PPP_PAIR_BRUTE) return fail(h, PPP_ERR_ARG, "pairing");
+    if (p->walk < 0 || p->walk > 4) return fail(h, PPP_ERR_ARG, "walk");
+    if (!(p->normal_radius > 0)) return fail(h, PPP_ERR_ARG, "normal_radius");
+    if (p->smooth_max_sweeps < 1) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps");
+    if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
+    if (p->dynamic_adjustment) return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment is outside the hot path (SURVEY.md 8f rank 1)");
+    return PPP_OK;
+}
+
+/* sizes every workspace from the resident cloud + parameters; no kernel of the hot path allocates */
+int make_plan(ppp_handle h)
+{
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    const int n = (int)h->n;
+    /* x-slabs: ~1024 points each, histogram must fit LDS */
+    int B = (h->h_nvalid + 1023) / 1024;
+    B = std::max(1, std::min(B, 8192));
+    h->B = B;
+    h->slab_cap = 4096;
+    /* exact slice count from the cached bounds (the device recomputes the same walk) */
+    int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
+    if (S >= PPP_WALK_HARD_MAX) return fail(h, PPP_ERR_CAPACITY, "slice walk does not terminate");
+    h->S_cap = std::max(1, S);
+    /* band capacity: expected points in a 4 mm band, x2 margin, power of two in [1024, 4096] */
+    double range = (double)h->h_mx[0] - (double)h->h_mn[0];
+    double expect = range > 0 ? (double)h->h_nvalid * 4.0 / range : (double)h->h_nvalid;
+    int capb = 1024;
+    while (capb < 4096 && capb < 2.0 * expect) capb <<= 1;
+    h->capb = capb;
+    /* waypoints: every kept slice samples at most (yrange - 2 trim)/res + 1 points */
+    double yr = (double)h->h_mx[1] - (double)h->h_mn[1];
+    double per = std::max(0.0, (yr - 2 * h->P.trim)) / h->P.path_resolution + 2.0;
+    double wc = per * (double)h->S_cap;
+    if (wc > 2.0e8) return fail(h, PPP_ERR_CAPACITY, "waypoint bound too large");
+    h->W_cap = std::max(1, (int)wc);
+    /* nodes: one per left-side band point at most; bands may overlap when step < 5 */
+    int step = (int)(h->P.tool_radius * 2);
+    double overlap = step >= 5 ? 1.0 : 5.0 / std::max(1, step) + 1.0;
+    h->node_cap = std::max(16, (int)std::min(2.0e9, overlap * (double)n + 16));
+
+    HIPCHK(h, h->unsorted4.ensure(n)); HIPCHK(h, h->sorted4.ensure(n));
+    HIPCHK(h, h->slab_cnt.ensure(B)); HIPCHK(h, h->slab_start.ensure(B + 1)); HIPCHK(h, h->slab_cursor.ensure(B));
+    HIPCHK(h, h->slab_xmin.ensure(B)); HIPCHK(h, h->slab_xmax.ensure(B));
+    HIPCHK(h, h->px.ensure(h->S_cap)); HIPCHK(h, h->lo.ensure(h->S_cap)); HIPCHK(h, h->hi.ensure(h->S_cap));
+    HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
+    HIPCHK(h, h->node_start.ensure(h->S_cap)); HIPCHK(h, h->node_cnt.ensure(h->S_cap)); HIPCHK(h, h->band_cnt.ensure(h->S_cap));
+    HIPCHK(h, h->wp_cnt.ensure(h->S_cap)); HIPCHK(h, h->wp_off.ensure(h->S_cap + 1)); HIPCHK(h, h->tail.ensure(h->S_cap));
+    HIPCHK(h, h->wp_xyz.ensure(h->W_cap)); HIPCHK(h, h->wp_normal.ensure(h->W_cap)); HIPCHK(h, h->wp_nn.ensure(h->W_cap));
+    HIPCHK(h, h->wp_pre.ensure(6 * (size_t)h->W_cap)); HIPCHK(h, h->wp_smooth.ensure(6 * (size_t)h->W_cap));
+    HIPCHK(h, h->wp_out.ensure(6 * (size_t)h->W_cap));
+    HIPCHK(h, h->sx.ensure(3 * (size_t)h->W_cap)); HIPCHK(h, h->ya.ensure(3 * (size_t)h->W_cap)); HIPCHK(h, h->yb.ensure(3 * (size_t)h->W_cap));
+    h->planned = true;
+    h->index_built = false; h->gen_done = false; h->path_done = false;
+    return PPP_OK;
+}
+
+/* a2 + a3 + the x-slab index (generalised slice binning) */
+int enqueue_index(ppp_handle h)
+{
+    const int n = (int)h->n;
+    DevParams D = dev_params(h);
+    LAUNCH(h, "k_reset", k_reset, 1, 64, 0, h->meta.p);
+    int g = std::max(1, std::min((n + 255) / 256, 2048));
+    LAUNCH(h, "k_minmax", k_minmax, g, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->meta.p);
+    LAUNCH(h, "k_setup", k_setup, 1, 64, 0, h->meta.p, D, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B);
+    HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * h->B, h->stream));
+    size_t hist_lds = sizeof(int) * (size_t)h->B;
+    int gh = std::max(1, std::min((n + 256 * 16 - 1) / (256 * 16), 1024));
+    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, h->meta.p, h->slab_cnt.p);
+    LAUNCH(h, "k_slab_scan", k_slab_scan, 1, 1024, 0, h->slab_cnt.p, h->slab_start.p, h->slab_cursor.p, h->B);
+    int chunk = 4096;
+    int gs = std::max(1, (n + chunk - 1) / chunk);
+    LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
+           h->slab_cursor.p, h->unsorted4.p);
+    size_t sort_lds = (size_t)h->slab_cap * 10;
+    LAUNCH(h, "k_slab_sort", k_slab_sort, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap);
+    h->index_built = true;
+    return PPP_OK;
+}
+
+int fetch_meta(ppp_handle h)
+{
+    HIPCHK(h, hipMemcpyAsync(&h->hmeta, h->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
+int map_dev_err(ppp_handle h)
+{
+    switch (h->hmeta.err) {
+    case DERR_NONE: return PPP_OK;
+    case DERR_SLICE: {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "slice %d has an empty side or fewer than 3 spline nodes (the reference aborts here)", h->hmeta.err_slice);
+        return fail(h, PPP_ERR_SLICE, buf);
+    }
+    case DERR_CAPACITY: return fail(h, PPP_ERR_CAPACITY, "device capacity exceeded (slab / band / node / waypoint buffer)");
+    case DERR_DOMAIN: return fail(h, PPP_ERR_DOMAIN, "spline evaluated outside its knots");
+    case DERR_QUERY: return fail(h, PPP_ERR_DOMAIN, "non-finite waypoint handed to the nearest-neighbour query");
+    }
+    return fail(h, PPP_ERR_HIP, "unknown device error");
+}
+
+int ensure_ready(ppp_handle h, bool need_gen, bool need_path)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (need_gen && !h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
+    if (need_path && !h->path_done) return fail(h, PPP_ERR_ARG, "call ppp_get_path_async first");
+    int rc = fetch_meta(h);
+    if (rc) return rc;
+    return PPP_OK;
+}
+
+int ensure_index(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    if (!h->index_built) { int rc = enqueue_index(h); if (rc) return rc; }
+    return PPP_OK;
+}
+
+int slice_lds_ok(ppp_handle h, int capb) { return slice_lds_bytes(capb) + 1024 <= (size_t)h->max_lds; }
+
+int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+{
+    if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
+    h->n = n;
+    if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
+    HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
+    if (n) {
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, raw_dev, stride_bytes, (int)n,
+                           h->P.change_range, h->X.p, h->Y.p, h->Z.p);
+        HIPCHK(h, hipGetLastError());
+    }
+    /* cache the bounds for the plan (sizing only; the hot path recomputes them on device) */
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, h->stream, h->meta.p);
+    int g = std::max(1, std::min(((int)n + 255) / 256, 2048));
+    hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->meta.p);
+    HIPCHK(h, hipGetLastError());
+    int rc = fetch_meta(h);
+    if (rc) return rc;
+    h->h_nvalid = h->hmeta.n_valid;
+    for (int d = 0; d < 3; ++d) {
+        h->h_mn[d] = h->h_nvalid ? ord2f(h->hmeta.mn_ord[d]) : 3.402823466e+38f;
+        h->h_mx[d] = h->h_nvalid ? ord2f(h->hmeta.mx_ord[d]) : -3.402823466e+38f;
+    }
+    h->have_cloud = true;
+    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
+    return make_plan(h);
+}
+
+} // namespace
+
+extern "C" {
+
+void ppp_default_params(ppp_params *p)
+{   /* config.txt:1-13, Path_Generate_Algorithm.h:43-48 */
+    memset(p, 0, sizeof(*p));
+    p->tool_radius = 12; p->path_resolution = 7; p->rpy_resolution = 7; p->ee_length = 0.3f;
+    p->change_range = 1; p->pairing = PPP_PAIR_KD; p->walk = PPP_WALK_CENTER_INT;
+    p->trim = 10; p->drop_ends = 1; p->smooth = 1;
+    const float he[6] = {-0.764091f, 0.025886f, 0.663790f, -3.1270175f, -0.040124f, -1.6063578f};
+    memcpy(p->handeye, he, sizeof(he));
+    p->normal_radius = 2.5f;
+    p->smooth_max_sweeps = 200;
+    p->alignment = 0; p->dynamic_adjustment = 0;
+}
+
+const char *ppp_version(void) { return PPP_VERSION_STR; }
+
+int ppp_create(int device_id, ppp_handle *out)
+{
+    if (!out) return PPP_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PPP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return PPP_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return PPP_ERR_HIP;
+    ppp_handle h = new ppp_handle_s();
+    h->device = device_id;
+    ppp_default_params(&h->P);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PPP_ERR_HIP; }
+    if (h->meta.ensure(1) != hipSuccess) { delete h; return PPP_ERR_HIP; }
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) h->max_lds = lds;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+        h->max_lds = std::max(h->max_lds, 160 * 1024); /* CDNA4: one workgroup may own the CU's whole LDS */
+    /* kernels with > 64 KiB of dynamic LDS opt in explicitly */
+    (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    *out = h;
+    return PPP_OK;
+}
+
+int ppp_destroy(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+    return PPP_OK;
+}
+
+const char *ppp_last_error(ppp_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int ppp_set_params(ppp_handle h, const ppp_params *p)
+{
+    if (!h || !p) return PPP_ERR_ARG;
+    int rc = validate_params(h, p);
+    if (rc) return rc;
+    bool rescale = h->have_cloud && (p->change_range != h->P.change_range);
+    h->P = *p;
+    if (rescale) return fail(h, PPP_ERR_ARG, "ChangeRange changed after the cloud was set: set the cloud again");
+    if (h->have_cloud) { HIPCHK(h, hipSetDevice(h->device)); return make_plan(h); }
+    return PPP_OK;
+}
+
+int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_bytes, const float *viewpoint)
+{
+    if (!h || (!xyz_host && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t bytes = n * stride_bytes;
+    HIPCHK(h, h->scratch.ensure(bytes));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(h->scratch.p, xyz_host, bytes, hipMemcpyHostToDevice, h->stream));
+    return set_cloud_common(h, h->scratch.p, n, stride_bytes, viewpoint);
+}
+
+int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+{
+    if (!h || (!xyz_dev && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
+}
+
+int ppp_num_points(ppp_handle h, size_t *n)
+{
+    if (!h || !n) return PPP_ERR_ARG;
+    *n = h->n;
+    return PPP_OK;
+}
+
+int ppp_gen_path_async(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
+    int rc = enqueue_index(h);
+    if (rc) return rc;
+    LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+           h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+           h->band_cnt.p);
+    h->gen_done = true;
+    h->path_done = false;
+    return PPP_OK;
+}
+
+int ppp_get_path_async(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
+    DevParams D = dev_params(h);
+    LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
+           h->wp_off.p, h->tail.p, h->W_cap);
+    int nk = std::max(1, h->S_cap);
+    LAUNCH(h, "k_eval", k_eval, nk, 256, 0, h->meta.p, D, h->px.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p,
+           h->wp_cnt.p, h->wp_off.p, h->wp_xyz.p);
+    int gw = std::max(1, (h->W_cap + 63) / 64);
+    LAUNCH(h, "k_pose", k_pose, gw, 64, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p,
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
+    /* the smoothed list is written twice: wp_smooth stays inspectable, wp_out is finished in place */
+    LAUNCH(h, "k_smooth", k_smooth, 1, 1024, 0, h->meta.p, D, h->sx.p, h->ya.p, h->yb.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+    int gr = std::max(1, (h->S_cap + 63) / 64);
+    LAUNCH(h, "k_rpy", k_rpy, gr, 64, 0, h->meta.p, D, h->tail.p, h->wp_out.p);
+    LAUNCH(h, "k_final", k_final, gw, 64, 0, h->meta.p, D, h->wp_out.p, h->wp_out.p);
+    h->path_done = true;
+    return PPP_OK;
+}
+
+int ppp_sync(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = fetch_meta(h);
+    if (rc) return rc;
+    return map_dev_err(h);
+}
+
+int ppp_failed_slice(ppp_handle h) { return (h && h->hmeta.err == DERR_SLICE) ? h->hmeta.err_slice : -1; }
+
+int ppp_num_slices(ppp_handle h, int *S)
+{
+    int rc = ensure_ready(h, true, false);
+    if (rc) return rc;
+    *S = h->hmeta.S;
+    return PPP_OK;
+}
+
+int ppp_num_waypoints(ppp_handle h, size_t *W)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    *W = (size_t)h->hmeta.W;
+    return PPP_OK;
+}
+
+int ppp_get_waypoints(ppp_handle h, float *out6, size_t cap, size_t *W)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    size_t w = (size_t)h->hmeta.W;
+    if (W) *W = w;
+    if (out6 && cap) {
+        size_t k = std::min(cap, w);
+        if (k) HIPCHK(h, hipMemcpy(out6, h->wp_out.p, k * 24, hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    if (dptr) *dptr = h->wp_out.p;
+    if (W) *W = (size_t)h->hmeta.W;
+    return PPP_OK;
+}
+
+int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    size_t nk = (size_t)h->hmeta.nkept;
+    if (n) *n = nk;
+    if (tail && cap) {
+        size_t k = std::min(cap, nk);
+        if (k) HIPCHK(h, hipMemcpy(tail, h->tail.p, k * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+int ppp_minmax(ppp_handle h, float mn[3], float mx[3])
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d) { mn[d] = h->hmeta.mn[d]; mx[d] = h->hmeta.mx[d]; }
+    return PPP_OK;
+}
+
+int ppp_get_slice_positions(ppp_handle h, float *px, size_t cap, size_t *S)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    size_t s = (size_t)h->hmeta.S;
+    if (S) *S = s;
+    if (px && cap) {
+        size_t k = std::min(cap, s);
+        if (k) HIPCHK(h, hipMemcpy(px, h->px.p, k * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, size_t *n)
+{
+    int capb = 4096;
+    if (!slice_lds_ok(h, capb)) return fail(h, PPP_ERR_CAPACITY, "LDS too small");
+    HIPCHK(h, h->scratch.ensure(sizeof(int) * (size_t)capb));
+    LAUNCH(h, "k_band_indices", k_band_indices, 1, 256, slice_lds_bytes(capb), h->sorted4.p, h->slab_start.p, h->meta.p, lo, hi,
+           capb, (int *)h->scratch.p, capb);
+    int rc = fetch_meta(h);
+    if (rc) return rc;
+    if (n) *n = (size_t)h->hmeta.api_cnt;
+    if (h->hmeta.api_flag) return fail(h, PPP_ERR_CAPACITY, "band larger than the LDS capacity (4096 points)");
+    if (out && cap) {
+        size_t k = std::min(cap, (size_t)h->hmeta.api_cnt);
+        if (k) HIPCHK(h, hipMemcpy(out, h->scratch.p, k * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+int ppp_ranged_x_index(ppp_handle h, int position, int *out, size_t cap, size_t *n)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    return band_indices(h, (float)(-2 + position), (float)(2 + position), out, cap, n);
+}
+
+int ppp_get_slice_indices(ppp_handle h, int s, int *out, size_t cap, size_t *n)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
+    float lohi[2];
+    HIPCHK(h, hipMemcpy(&lohi[0], h->lo.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&lohi[1], h->hi.p + s, 4, hipMemcpyDeviceToHost));
+    return band_indices(h, lohi[0], lohi[1], out, cap, n);
+}
+
+int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t cap, size_t *m)
+{
+    int rc = ensure_ready(h, true, false);
+    if (rc) return rc;
+    if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
+    int st = 0, cnt = 0;
+    float pxs = 0;
+    HIPCHK(h, hipMemcpy(&st, h->node_start.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&cnt, h->node_cnt.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&pxs, h->px.p + s, 4, hipMemcpyDeviceToHost));
+    if (m) *m = (size_t)cnt;
+    size_t k = std::min(cap, (size_t)cnt);
+    if (k && (y || z || x)) {
+        std::vector<float> fy(k), fz(k);
+        HIPCHK(h, hipMemcpy(fy.data(), h->node_y.p + st, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(fz.data(), h->node_z.p + st, k * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; ++i) {
+            if (y) y[i] = (double)fy[i];
+            if (x) x[i] = (double)pxs;
+            if (z) z[i] = (double)fz[i];
+        }
+    }
+    return PPP_OK;
+}
+
+int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz)
+{
+    int rc = ensure_ready(h, true, false);
+    if (rc) return rc;
+    if (s < 0 || s >= h->hmeta.S || !y || !xyz) return fail(h, PPP_ERR_ARG, "bad arguments");
+    if (!k) return PPP_OK;
+    HIPCHK(h, h->scratch.ensure(k * 32));
+    double *dq = (double *)h->scratch.p, *dout = dq + k;
+    HIPCHK(h, hipMemcpyAsync(dq, y, k * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->meta.p->api_flag, 0, 4, h->stream));
+    LAUNCH(h, "k_eval_api", k_eval_api, (unsigned)((k + 127) / 128), 128, 0, h->meta.p, h->px.p, h->node_y.p, h->node_z.p,
+           h->node_start.p, h->node_cnt.p, s, dq, (int)k, dout);
+    HIPCHK(h, hipMemcpyAsync(xyz, dout, k * 24, hipMemcpyDeviceToHost, h->stream));
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    if (h->hmeta.api_flag == DERR_DOMAIN) return fail(h, PPP_ERR_DOMAIN, "y outside [miny, bigy] (GSL_EDOM)");
+    return PPP_OK;
+}
+
+int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, double *y, double *x, double *z, size_t cap,
+                     size_t *m)
+{
+    if (!h || (!indices && n)) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    int capb = 4096;
+    if (n > (size_t)capb) return fail(h, PPP_ERR_CAPACITY, "insert_point: more than 4096 indices in one band");
+    if (!slice_lds_ok(h, capb)) return fail(h, PPP_ERR_CAPACITY, "LDS too small");
+    HIPCHK(h, h->scratch.ensure((size_t)capb * 12));
+    int *didx = (int *)h->scratch.p;
+    float *dy = (float *)(didx + capb), *dz = dy + capb;
+    if (n) HIPCHK(h, hipMemcpyAsync(didx, indices, n * 4, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "k_insert_api", k_insert_api, 1, 256, slice_lds_bytes(capb), h->X.p, h->Y.p, h->Z.p, (int)h->n, didx, (int)n, plane_x,
+           h->P.pairing, capb, h->meta.p, dy, dz, capb);
+    int rc = fetch_meta(h);
+    if (rc) return rc;
+    if (h->hmeta.api_flag == DERR_SLICE) return fail(h, PPP_ERR_SLICE, "insert_point: empty right side (the reference crashes here)");
+    if (h->hmeta.api_flag) return fail(h, PPP_ERR_CAPACITY, "insert_point capacity");
+    size_t cnt = (size_t)h->hmeta.api_cnt;
+    if (m) *m = cnt;
+    size_t k = std::min(cap, cnt);
+    if (k) {
+        std::vector<float> fy(k), fz(k);
+        HIPCHK(h, hipMemcpy(fy.data(), dy, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(fz.data(), dz, k * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; ++i) {
+            if (y) y[i] = (double)fy[i];
+            if (x) x[i] = (double)plane_x;
+            if (z) z[i] = (double)fz[i];
+        }
+    }
+    return PPP_OK;
+}
+
+int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    if (!k) return PPP_OK;
+    if (!idx || !out4) return fail(h, PPP_ERR_ARG, "bad arguments");
+    HIPCHK(h, h->scratch.ensure(k * 20));
+    int *didx = (int *)h->scratch.p;
+    float *dout = (float *)(didx + k);
+    HIPCHK(h, hipMemcpyAsync(didx, idx, k * 4, hipMemcpyHostToDevice, h->stream));
+    DevParams D = dev_params(h);
+    LAUNCH(h, "k_normals_api", k_normals_api, (unsigned)((k + 63) / 64), 64, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
+           h->slab_xmin.p, h->slab_xmax.p, h->X.p, h->Y.p, h->Z.p, (int)h->n, didx, (int)k, dout);
+    HIPCHK(h, hipMemcpyAsync(out4, dout, k * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
+int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    if (!k) return PPP_OK;
+    if (!q_xyz || !idx) return fail(h, PPP_ERR_ARG, "bad arguments");
+    HIPCHK(h, h->scratch.ensure(k * 16));
+    float *dq = (float *)h->scratch.p;
+    int *dout = (int *)(dq + 3 * k);
+    HIPCHK(h, hipMemcpyAsync(dq, q_xyz, k * 12, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "k_nearest_api", k_nearest_api, (unsigned)((k + 63) / 64), 64, 0, h->meta.p, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+           h->slab_xmax.p, dq, (int)k, dout);
+    HIPCHK(h, hipMemcpyAsync(idx, dout, k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
+int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *count)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    size_t W = (size_t)h->hmeta.W;
+    if (count) *count = W;
+    if (!out || !cap_bytes || !W) return PPP_OK;
+    const void *src = nullptr;
+    size_t elem = 0;
+    std::vector<float> tmp;
+    switch (stage) {
+    case PPP_STAGE_WP_XYZ: {
+        std::vector<float4> t4(W);
+        HIPCHK(h, hipMemcpy(t4.data(), h->wp_xyz.p, W * 16, hipMemcpyDeviceToHost));
+        tmp.resize(3 * W);
+        for (size_t i = 0; i < W; ++i) { tmp[3 * i] = t4[i].x; tmp[3 * i + 1] = t4[i].y; tmp[3 * i + 2] = t4[i].z; }
+        memcpy(out, tmp.data(), std::min(cap_bytes, W * 12));
+        return PPP_OK;
+    }
+    case PPP_STAGE_WP_NN: src = h->wp_nn.p; elem = 4; break;
+    case PPP_STAGE_WP_NORMAL: src = h->wp_normal.p; elem = 16; break;
+    case PPP_STAGE_WP_PRESMOOTH: src = h->wp_pre.p; elem = 24; break;
+    case PPP_STAGE_WP_SMOOTHED: src = h->wp_smooth.p; elem = 24; break;
+    default: return fail(h, PPP_ERR_ARG, "unknown stage");
+    }
+    HIPCHK(h, hipMemcpy(out, src, std::min(cap_bytes, W * elem), hipMemcpyDeviceToHost));
+    return PPP_OK;
+}
+
+int ppp_smooth_sweeps(ppp_handle h, int *sweeps)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    *sweeps = h->hmeta.sweeps;
+    return PPP_OK;
+}
+
+int ppp_enable_timing(ppp_handle h, int on)
+{
+    if (!h) return PPP_ERR_ARG;
+    h->timing = on != 0;
+    for (auto &t : h->timers) t.used = false;
+    return PPP_OK;
+}
+
+int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_t *n)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    size_t k = 0;
+    for (auto &t : h->timers) {
+        if (!t.used) continue;
+        if (k < cap) {
+            float v = 0.f;
+            if (hipEventElapsedTime(&v, t.e0, t.e1) != hipSuccess) v = -1.f;
+            if (ms) ms[k] = v;
+            if (names) { strncpy(names + 48 * k, t.name.c_str(), 47); names[48 * k + 47] = 0; }
+        }
+        ++k;
+    }
+    if (n) *n = k;
+    return PPP_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,348 @@
+"""ctypes binding of the gfx950 engine (libppp_hip.so, C ABI in include/ppp_hip.h).
+
+This module is plumbing only: every number comes from the HIP kernels.  There is no
+CPU fallback -- if the shared library is missing or no MI355X is visible, construction
+raises.  The oracle under oracle/ is never imported from here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppp_hip.so")
+
+PAIR_KD, PAIR_BRUTE = 0, 1
+WALK_SECTPATH, WALK_CENTER_INT, WALK_SDIR_INT, WALK_V1_CONTACT, WALK_V1_SLICING = range(5)
+STAGE_WP_XYZ, STAGE_WP_NN, STAGE_WP_NORMAL, STAGE_WP_PRESMOOTH, STAGE_WP_SMOOTHED = range(5)
+
+OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_SLICE, ERR_CAPACITY, ERR_DOMAIN, ERR_UNSUPPORTED, ERR_IO = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class PPPError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ppp error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("tool_radius", C.c_double),
+        ("path_resolution", C.c_double),
+        ("rpy_resolution", C.c_double),
+        ("ee_length", C.c_float),
+        ("change_range", C.c_int),
+        ("pairing", C.c_int),
+        ("walk", C.c_int),
+        ("trim", C.c_double),
+        ("drop_ends", C.c_int),
+        ("smooth", C.c_int),
+        ("handeye", C.c_float * 6),
+        ("normal_radius", C.c_float),
+        ("smooth_max_sweeps", C.c_int),
+        ("alignment", C.c_int),
+        ("dynamic_adjustment", C.c_int),
+    ]
+
+
+EXPORTS = [
+    "ppp_default_params", "ppp_create", "ppp_destroy", "ppp_last_error", "ppp_version", "ppp_set_params",
+    "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async",
+    "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
+    "ppp_get_waypoints_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
+    "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
+    "ppp_normals_at", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
+    "ppp_get_kernel_times",
+]
+
+
+def build(force=False):
+    """Compile the HIP engine for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+    newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "ppp_hip.h")))
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads libppp_hip.so (never builds implicitly: a missing library is an error)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PPPError(ERR_NO_DEVICE, "libppp_hip.so is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        vp, sz = C.c_void_p, C.c_size_t
+        fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)
+        szp = C.POINTER(C.c_size_t)
+        L.ppp_default_params.argtypes = [C.POINTER(Params)]
+        L.ppp_default_params.restype = None
+        L.ppp_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ppp_destroy.argtypes = [vp]
+        L.ppp_last_error.argtypes = [vp]
+        L.ppp_last_error.restype = C.c_char_p
+        L.ppp_version.restype = C.c_char_p
+        L.ppp_set_params.argtypes = [vp, C.POINTER(Params)]
+        L.ppp_set_cloud.argtypes = [vp, vp, sz, sz, fp]
+        L.ppp_set_cloud_device.argtypes = [vp, vp, sz, sz, fp]
+        L.ppp_num_points.argtypes = [vp, szp]
+        L.ppp_gen_path_async.argtypes = [vp]
+        L.ppp_get_path_async.argtypes = [vp]
+        L.ppp_sync.argtypes = [vp]
+        L.ppp_failed_slice.argtypes = [vp]
+        L.ppp_num_slices.argtypes = [vp, ip]
+        L.ppp_num_waypoints.argtypes = [vp, szp]
+        L.ppp_get_waypoints.argtypes = [vp, fp, sz, szp]
+        L.ppp_get_waypoints_device.argtypes = [vp, C.POINTER(vp), szp]
+        L.ppp_get_tail_index.argtypes = [vp, ip, sz, szp]
+        L.ppp_minmax.argtypes = [vp, fp, fp]
+        L.ppp_get_slice_positions.argtypes = [vp, fp, sz, szp]
+        L.ppp_get_slice_indices.argtypes = [vp, C.c_int, ip, sz, szp]
+        L.ppp_get_nodes.argtypes = [vp, C.c_int, dp, dp, dp, sz, szp]
+        L.ppp_eval_spline.argtypes = [vp, C.c_int, dp, sz, dp]
+        L.ppp_ranged_x_index.argtypes = [vp, C.c_int, ip, sz, szp]
+        L.ppp_insert_point.argtypes = [vp, ip, sz, C.c_float, dp, dp, dp, sz, szp]
+        L.ppp_normals_at.argtypes = [vp, ip, sz, fp]
+        L.ppp_nearest.argtypes = [vp, fp, sz, ip]
+        L.ppp_get_stage.argtypes = [vp, C.c_int, vp, sz, szp]
+        L.ppp_smooth_sweeps.argtypes = [vp, ip]
+        L.ppp_enable_timing.argtypes = [vp, C.c_int]
+        L.ppp_get_kernel_times.argtypes = [vp, C.c_char_p, fp, sz, szp]
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    p = Params()
+    lib().ppp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "handeye":
+            for j, x in enumerate(v):
+                p.handeye[j] = x
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+    return p
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Engine:
+    """One planner handle on one MI355X (one HIP stream, one resident cloud)."""
+
+    def __init__(self, device=0, params=None, **kw):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.ppp_create(int(device), C.byref(self.h))
+        if rc:
+            self.h = None
+            raise PPPError(rc, "ppp_create failed (no gfx950 device? there is no CPU fallback)")
+        self.params = params if params is not None else default_params(**kw)
+        self._chk(self.L.ppp_set_params(self.h, C.byref(self.params)))
+
+    def _chk(self, rc):
+        if rc:
+            raise PPPError(rc, self.L.ppp_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.ppp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if k == "handeye":
+                for j, x in enumerate(v):
+                    self.params.handeye[j] = x
+            else:
+                setattr(self.params, k, v)
+        self._chk(self.L.ppp_set_params(self.h, C.byref(self.params)))
+
+    # -- cloud (constructor of the reference classes) --
+    def set_cloud(self, xyz, viewpoint=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+        self._chk(self.L.ppp_set_cloud(self.h, xyz.ctypes.data, xyz.shape[0], xyz.shape[1] * 4, vp))
+        self.n = xyz.shape[0]
+
+    def set_cloud_device(self, dptr, n, stride_bytes, viewpoint=None):
+        vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+        self._chk(self.L.ppp_set_cloud_device(self.h, C.c_void_p(dptr), n, stride_bytes, vp))
+        self.n = n
+
+    # -- hot path --
+    def gen_path_async(self):
+        self._chk(self.L.ppp_gen_path_async(self.h))
+
+    def get_path_async(self):
+        self._chk(self.L.ppp_get_path_async(self.h))
+
+    def sync(self):
+        self._chk(self.L.ppp_sync(self.h))
+
+    def gen_path(self):
+        """GenPath(): returns S."""
+        self.gen_path_async()
+        self.sync()
+        return self.num_slices()
+
+    def get_path(self):
+        """getPath(): returns W."""
+        self.get_path_async()
+        self.sync()
+        return self.num_waypoints()
+
+    def failed_slice(self):
+        return self.L.ppp_failed_slice(self.h)
+
+    # -- results --
+    def num_slices(self):
+        s = C.c_int()
+        self._chk(self.L.ppp_num_slices(self.h, C.byref(s)))
+        return s.value
+
+    def num_waypoints(self):
+        w = C.c_size_t()
+        self._chk(self.L.ppp_num_waypoints(self.h, C.byref(w)))
+        return w.value
+
+    def waypoints(self):
+        W = self.num_waypoints()
+        out = np.empty((W, 6), np.float32)
+        w = C.c_size_t()
+        self._chk(self.L.ppp_get_waypoints(self.h, _f(out), W, C.byref(w)))
+        return out
+
+    def waypoints_device(self):
+        p = C.c_void_p()
+        w = C.c_size_t()
+        self._chk(self.L.ppp_get_waypoints_device(self.h, C.byref(p), C.byref(w)))
+        return p.value, w.value
+
+    def tail_index(self):
+        n = C.c_size_t()
+        self._chk(self.L.ppp_get_tail_index(self.h, None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), np.int32)
+        self._chk(self.L.ppp_get_tail_index(self.h, _i(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    def minmax(self):
+        mn = np.empty(3, np.float32)
+        mx = np.empty(3, np.float32)
+        self._chk(self.L.ppp_minmax(self.h, _f(mn), _f(mx)))
+        return mn, mx
+
+    def slice_positions(self):
+        S = C.c_size_t()
+        self._chk(self.L.ppp_get_slice_positions(self.h, None, 0, C.byref(S)))
+        px = np.empty(max(S.value, 1), np.float32)
+        self._chk(self.L.ppp_get_slice_positions(self.h, _f(px), S.value, C.byref(S)))
+        return px[:S.value]
+
+    def slice_indices(self, s):
+        cap = 4096
+        out = np.empty(cap, np.int32)
+        n = C.c_size_t()
+        self._chk(self.L.ppp_get_slice_indices(self.h, int(s), _i(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def ranged_x_index(self, position):
+        cap = 4096
+        out = np.empty(cap, np.int32)
+        n = C.c_size_t()
+        self._chk(self.L.ppp_ranged_x_index(self.h, int(position), _i(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def nodes(self, s):
+        m = C.c_size_t()
+        self._chk(self.L.ppp_get_nodes(self.h, int(s), None, None, None, 0, C.byref(m)))
+        k = max(m.value, 1)
+        y = np.empty(k); x = np.empty(k); z = np.empty(k)
+        self._chk(self.L.ppp_get_nodes(self.h, int(s), _d(y), _d(x), _d(z), m.value, C.byref(m)))
+        return y[:m.value], x[:m.value], z[:m.value]
+
+    def eval_spline(self, s, y):
+        y = np.ascontiguousarray(y, np.float64)
+        out = np.empty((len(y), 3))
+        rc = self.L.ppp_eval_spline(self.h, int(s), _d(y), len(y), _d(out))
+        if rc and rc != ERR_DOMAIN:
+            self._chk(rc)
+        return rc, out
+
+    def insert_point(self, indices, plane_x):
+        indices = np.ascontiguousarray(indices, np.int32)
+        cap = max(len(indices), 1)
+        y = np.empty(cap); x = np.empty(cap); z = np.empty(cap)
+        m = C.c_size_t()
+        rc = self.L.ppp_insert_point(self.h, _i(indices), len(indices), float(plane_x), _d(y), _d(x), _d(z), cap, C.byref(m))
+        if rc == ERR_SLICE:
+            return rc, None, None, None
+        self._chk(rc)
+        return m.value, y[:m.value], x[:m.value], z[:m.value]
+
+    def normals_at(self, idx):
+        idx = np.ascontiguousarray(idx, np.int32)
+        out = np.empty((len(idx), 4), np.float32)
+        self._chk(self.L.ppp_normals_at(self.h, _i(idx), len(idx), _f(out)))
+        return out
+
+    def nearest(self, q):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        out = np.empty(len(q), np.int32)
+        self._chk(self.L.ppp_nearest(self.h, _f(q), len(q), _i(out)))
+        return out
+
+    def stage(self, stage):
+        cnt = C.c_size_t()
+        self._chk(self.L.ppp_get_stage(self.h, stage, None, 0, C.byref(cnt)))
+        W = cnt.value
+        shape, dt = {STAGE_WP_XYZ: ((W, 3), np.float32), STAGE_WP_NN: ((W,), np.int32),
+                     STAGE_WP_NORMAL: ((W, 4), np.float32), STAGE_WP_PRESMOOTH: ((W, 6), np.float32),
+                     STAGE_WP_SMOOTHED: ((W, 6), np.float32)}[stage]
+        out = np.empty(shape, dt)
+        if W:
+            self._chk(self.L.ppp_get_stage(self.h, stage, out.ctypes.data, out.nbytes, C.byref(cnt)))
+        return out
+
+    def smooth_sweeps(self):
+        s = C.c_int()
+        self._chk(self.L.ppp_smooth_sweeps(self.h, C.byref(s)))
+        return s.value
+
+    # -- measurement --
+    def enable_timing(self, on=True):
+        self._chk(self.L.ppp_enable_timing(self.h, 1 if on else 0))
+
+    def kernel_times(self):
+        cap = 64
+        names = C.create_string_buffer(48 * cap)
+        ms = np.zeros(cap, np.float32)
+        n = C.c_size_t()
+        self._chk(self.L.ppp_get_kernel_times(self.h, names, _f(ms), cap, C.byref(n)))
+        out = {}
+        for k in range(n.value):
+            out[names.raw[48 * k:48 * k + 48].split(b"\0", 1)[0].decode()] = float(ms[k])
+        return out

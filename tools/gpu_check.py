@@ -1,0 +1,86 @@
+"""Developer tool: stage-by-stage comparison of the HIP engine with the CPU oracle on a GPU box.
+Usage: python tools/gpu_check.py [config ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from polishpathplanning_amd import engine, synth
+from oracle import ppo
+
+
+def check(name, pairing=0, walk=1, verbose=True):
+    pts, cfg = synth.make_config(name)
+    R = cfg["tool_radius"]
+    o = ppo.Oracle(pts, tool_radius=R, pairing=pairing, walk=walk)
+    t0 = time.time(); So = o.gen_path(); Wo = o.get_path(); t_or = time.time() - t0
+    e = engine.Engine(0, tool_radius=R, pairing=pairing, walk=walk)
+    e.set_cloud(pts)
+    e.enable_timing(True)
+    t0 = time.time(); e.gen_path_async(); e.get_path_async(); e.sync(); t_gpu = time.time() - t0
+    S = e.num_slices(); W = e.num_waypoints()
+    print(f"== {name} pairing={pairing} walk={walk}: N={len(pts)} S gpu/oracle {S}/{So}  W {W}/{Wo}  oracle {t_or:.3f}s gpu(first) {t_gpu*1e3:.2f}ms")
+    ok = (S == So) and (W == Wo)
+    mn, mx = e.minmax(); omn, omx = o.minmax()
+    ok &= np.array_equal(mn, omn) and np.array_equal(mx, omx)
+    px = e.slice_positions(); opx = o.slice_positions()
+    ok &= np.array_equal(px, opx)
+    bad_idx = bad_nodes = 0
+    for s in range(min(S, So)):
+        if s % max(1, S // 16) == 0:
+            gi = e.slice_indices(s); oi = o.slice_indices(s)
+            if not np.array_equal(gi, oi): bad_idx += 1
+        gy, gx, gz = e.nodes(s); oy, ox, oz = o.nodes(s)
+        if len(gy) != len(oy) or not (np.array_equal(gy, oy) and np.array_equal(gx, ox) and np.array_equal(gz, oz)):
+            bad_nodes += 1
+            if verbose and bad_nodes <= 3:
+                print("  node mismatch slice", s, len(gy), len(oy))
+    print(f"  slice index lists mismatching: {bad_idx}; node lists mismatching: {bad_nodes}")
+    ok &= bad_idx == 0 and bad_nodes == 0
+    if W == Wo and W > 0:
+        xyz = e.stage(engine.STAGE_WP_XYZ); oxyz = o.waypoints_xyz()
+        print("  wp_xyz max abs diff (mm):", np.abs(xyz - oxyz).max(), "bit-equal:", np.array_equal(xyz, oxyz))
+        nn = e.stage(engine.STAGE_WP_NN); onn = o.waypoint_nn()
+        print("  wp_nn mismatches:", int((nn != onn).sum()))
+        nrm = e.stage(engine.STAGE_WP_NORMAL); onrm = o.waypoint_normals()
+        dots = np.sum(nrm[:, :3] * onrm[:, :3], axis=1)
+        print("  normal max angle (rad):", float(np.arccos(np.clip(dots, -1, 1)).max()), "curv max diff", float(np.abs(nrm[:, 3] - onrm[:, 3]).max()))
+        pre = e.stage(engine.STAGE_WP_PRESMOOTH); opre = o.waypoints_presmooth()
+        print("  presmooth max diff pos(m)/rpy(rad):", float(np.abs(pre[:, :3] - opre[:, :3]).max()), float(np.abs(pre[:, 3:] - opre[:, 3:]).max()))
+        sm = e.stage(engine.STAGE_WP_SMOOTHED); osm = o.waypoints_smoothed()
+        print("  smoothed max diff pos(m):", float(np.abs(sm[:, :3] - osm[:, :3]).max()), "sweeps gpu/oracle", e.smooth_sweeps(), o.smooth_sweeps())
+        wp = e.waypoints(); owp = o.waypoints()
+        dpos = np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1)
+        drpy = np.abs(wp[:, 3:] - owp[:, 3:])
+        drpy = np.minimum(drpy, np.abs(drpy - 2 * np.pi))
+        print(f"  FINAL path L2 err: max {dpos.max():.3e} m rms {np.sqrt((dpos**2).mean()):.3e} m ; rpy max {drpy.max():.3e} rad")
+        ok &= dpos.max() <= 1e-4
+        ok &= np.array_equal(e.tail_index(), o.tail_index())
+    # steady-state timing
+    e.enable_timing(False)
+    for _ in range(3):
+        e.gen_path_async(); e.get_path_async()
+    e.sync()
+    t0 = time.time()
+    for _ in range(10):
+        e.gen_path_async(); e.get_path_async()
+    e.sync()
+    dt = (time.time() - t0) / 10
+    print(f"  steady state: {dt*1e3:.3f} ms per cloud -> {W/dt:.3e} waypoints/s ; cpu oracle(fast mode) {Wo/t_or:.3e} wp/s")
+    e.enable_timing(True)
+    e.gen_path_async(); e.get_path_async(); e.sync()
+    kt = e.kernel_times()
+    print("  kernel ms:", {k: round(v, 4) for k, v in kt.items()}, "sum", round(sum(kt.values()), 4))
+    print("  RESULT", "PASS" if ok else "FAIL")
+    return ok
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["tiny_5k", "small_40k", "cfg1_50k_s32", "cfg3_250k_s128", "cfg2_1m_s256"]
+    allok = True
+    for nme in names:
+        if ":" in nme:
+            nm, pr, wk = nme.split(":")
+            allok &= check(nm, int(pr), int(wk))
+        else:
+            allok &= check(nme)
+    print("ALL", "PASS" if allok else "FAIL")
+    sys.exit(0 if allok else 1)
