@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: polishing waypoints/s on the BASELINE.json configuration.
+
+One "step" = one full pass of the hot path (GenPath + getPath: a2..a15 of SURVEY.md section 8)
+over one synthetic workpiece cloud that is already resident in HBM, ending with the finished
+WayPointsList assembled on rank 0.  N = 1 runs configs[1] (1M-point wavy plate, 256 slices).
+N > 1 shards a batch of workpieces one per GPU (weak scaling, no data-path collective) and
+gathers the per-GPU robot paths to rank 0 over RCCL inside the timed region.
+
+Launch: python bench.py --gpus N --steps K --warmup W     (N > 1 via torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md "HBM3E peak BW"); 6290 GB/s measured copy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2_1m_s256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-passes", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from polishpathplanning_amd import engine, synth
+    from polishpathplanning_amd.robot_path import gather_robot_path
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic workpiece of this rank (untimed: generation + H2D) ----
+    base_seed = sorted(synth.CONFIGS).index(args.config) + 1
+    pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank)
+    eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+    eng.set_cloud(pts)
+    n_points = int(pts.shape[0])
+
+    # first pass: learn S and W, size the gather buffer
+    S = eng.gen_path()
+    W = eng.get_path()
+    if cfg.get("slices") and S != cfg["slices"]:
+        raise SystemExit("config %s produced %d slices, expected %d" % (args.config, S, cfg["slices"]))
+    send = torch.zeros((max(W, 1) + 64, 6), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.gen_path_async()
+        eng.get_path_async()
+        w = eng.copy_waypoints_to_device(send.data_ptr(), send.shape[0])  # waits for this handle's stream
+        blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev)
+        return w, blocks
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    w_local = 0
+    for _ in range(args.steps):
+        w_local, blocks = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ww = torch.tensor([float(w_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ww, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    w_total = float(ww.item())
+    value = w_total * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events on the engine's own stream ----
+        eng.enable_timing(True)
+        acc = {}
+        for _ in range(args.profile_passes):
+            eng.gen_path_async()
+            eng.get_path_async()
+            eng.sync()
+            for k, v in eng.kernel_times().items():
+                acc.setdefault(k, []).append(v)
+        eng.enable_timing(False)
+        kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+        dom = max(kern_ms, key=kern_ms.get)
+        alg_bytes = 12.0 * n_points + 24.0 * w_local  # xyz read once + waypoints written once
+        achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
+                    "algorithmic_bytes": alg_bytes,
+                    "pipeline_gbs": alg_bytes / (elapsed / args.steps) / 1e9}
+
+        # ---- CPU baseline: the oracle in reference-complexity mode on the node's host cores ----
+        cpu = None
+        err = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ppo
+            o = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1)
+            t1 = time.perf_counter()
+            o.gen_path()
+            wo = o.get_path()
+            t_cpu = time.perf_counter() - t1
+            cpu = {"value": wo / t_cpu, "unit": "waypoints/s", "cores": 1, "kind": "port",
+                   "sample": "1 full pass of %s (GenPath + getPath), single thread, reference-complexity "
+                             "mode: per-slice O(N) PassThrough scans, whole-cloud normal estimation twice" % args.config,
+                   "seconds": t_cpu, "host_cores_available": os.cpu_count()}
+            gw = eng.waypoints()
+            ow = o.waypoints()
+            if gw.shape == ow.shape and len(gw):
+                d = np.linalg.norm(gw[:, :3] - ow[:, :3], axis=1)
+                err = {"max_m": float(d.max()), "rms_m": float(np.sqrt((d ** 2).mean())), "waypoints_equal": True}
+            else:
+                err = {"waypoints_equal": False, "gpu": int(gw.shape[0]), "oracle": int(ow.shape[0])}
+
+        out = {
+            "metric": "polishing waypoints/sec for 1M-pt cloud, 256 slices; path L2 err vs ref",
+            "value": value, "unit": "waypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "points_per_workpiece": n_points, "slices": S,
+                       "waypoints_per_workpiece": int(w_local), "workpieces": world,
+                       "parallelism": "one workpiece per GPU, RCCL gather of robot_path to rank 0" if world > 1 else "single GPU",
+                       "pairing": "kd", "walk": "center_int (connect)", "tool_radius_mm": cfg["tool_radius"]},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "path_l2_err": err,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

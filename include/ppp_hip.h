@@ -111,6 +111,9 @@ int ppp_num_waypoints(ppp_handle h, size_t *W);
 int ppp_get_waypoints(ppp_handle h, float *out6, size_t cap, size_t *W);
 /* device pointer of the same list (valid until the next ppp_get_path_async / destroy) */
 int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W);
+/* copies the list into a caller-owned DEVICE buffer (e.g. a framework tensor used as the
+ * send buffer of the RCCL gather); asynchronous on the handle's stream after the count is known */
+int ppp_copy_waypoints_to_device(ppp_handle h, float *dst_dev, size_t cap, size_t *W);
 /* TailIndex (path_translation_alg.cpp:177,210) */
 int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n);
 

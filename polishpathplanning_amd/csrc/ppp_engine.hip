@@ -489,6 +489,22 @@ int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W)
     return PPP_OK;
 }
 
+int ppp_copy_waypoints_to_device(ppp_handle h, float *dst_dev, size_t cap, size_t *W)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    size_t w = (size_t)h->hmeta.W;
+    if (W) *W = w;
+    size_t k = std::min(cap, w);
+    if (k && dst_dev) {
+        HIPCHK(h, hipMemcpyAsync(dst_dev, h->wp_out.p, k * 24, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PPP_OK;
+}
+
 int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n)
 {
     int rc = ensure_ready(h, true, true);

@@ -50,7 +50,7 @@ EXPORTS = [
     "ppp_default_params", "ppp_create", "ppp_destroy", "ppp_last_error", "ppp_version", "ppp_set_params",
     "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async",
     "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
-    "ppp_get_waypoints_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
+    "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times",
@@ -99,6 +99,7 @@ def lib():
         L.ppp_num_waypoints.argtypes = [vp, szp]
         L.ppp_get_waypoints.argtypes = [vp, fp, sz, szp]
         L.ppp_get_waypoints_device.argtypes = [vp, C.POINTER(vp), szp]
+        L.ppp_copy_waypoints_to_device.argtypes = [vp, vp, sz, szp]
         L.ppp_get_tail_index.argtypes = [vp, ip, sz, szp]
         L.ppp_minmax.argtypes = [vp, fp, fp]
         L.ppp_get_slice_positions.argtypes = [vp, fp, sz, szp]
@@ -241,6 +242,11 @@ class Engine:
         w = C.c_size_t()
         self._chk(self.L.ppp_get_waypoints_device(self.h, C.byref(p), C.byref(w)))
         return p.value, w.value
+
+    def copy_waypoints_to_device(self, dptr, cap):
+        w = C.c_size_t()
+        self._chk(self.L.ppp_copy_waypoints_to_device(self.h, C.c_void_p(dptr), cap, C.byref(w)))
+        return w.value
 
     def tail_index(self):
         n = C.c_size_t()

@@ -1,0 +1,54 @@
+"""Assembly of the final robot_path from per-GPU waypoint blocks.
+
+Multi-GPU model: workpieces are independent, so a batch shards one
+workpiece per GPU with no data-path collective.  The only exchange is the variable-length
+gather of the finished W_g x 6 float blocks to rank 0 (the robot controller reads one file).
+Blocks are ~0.6 MB per workpiece: latency-bound on xGMI, so one count exchange plus one padded
+all-gather is used -- no ring reduction exists anywhere on the path.
+torch.distributed is plumbing here: backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
+"""
+import numpy as np
+
+
+def gather_robot_path(local_wp, dist=None, device=None):
+    """local_wp: torch tensor [W_local, 6] float32 on `device`.  Returns on rank 0 the list of
+    per-rank waypoint tensors in rank order (None elsewhere).  Works for world_size 1 without
+    a process group."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local_wp]
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    dev = local_wp.device if device is None else device
+    cnt = torch.tensor([local_wp.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, cnt)
+    counts = counts.cpu().tolist()
+    wmax = max(max(counts), 1)
+    send = torch.zeros((wmax, 6), dtype=torch.float32, device=dev)
+    send[: local_wp.shape[0]] = local_wp
+    recv = torch.empty((world * wmax, 6), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    if rank != 0:
+        return None
+    return [recv[r * wmax: r * wmax + counts[r]] for r in range(world)]
+
+
+def concat_robot_path(blocks):
+    """Rank-0 side: one W_total x 6 array, workpiece after workpiece."""
+    import torch
+    return torch.cat(list(blocks), dim=0) if len(blocks) else torch.zeros((0, 6))
+
+
+def write_path_file(path, wp6):
+    """The reference's pathFile format (path_translation_alg.cpp:216-228): six values per line,
+    each followed by one blank, default ostream precision (6 significant digits)."""
+    wp6 = np.asarray(wp6, dtype=np.float32)
+    with open(path, "w") as f:
+        for row in wp6:
+            f.write("".join(_ostream_float(v) + " " for v in row) + "\n")
+
+
+def _ostream_float(v):
+    # std::ostream << float with default flags == printf("%g")
+    return "%g" % float(v)

@@ -1,0 +1,289 @@
+"""Parity of the HIP hot path (through the C ABI) with the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for every integer / index / count stage and for the float stages that only
+involve the reference's own float operations (min/max, plane positions, band index lists,
+spline knots, sampled waypoints, nearest-neighbour ids); <= 1e-4 m (north_star) for the final
+floating-point waypoint list, whose normals / trigonometry go through different libm's.
+"""
+import numpy as np
+import pytest
+
+from polishpathplanning_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_M = 1e-4      # BASELINE.json north_star: "within 1e-4 m"
+TOL_RAD = 1e-4
+
+
+def run_pair(engine_mod, oracle_mod, pts, **params):
+    o = oracle_mod.Oracle(pts, **params)
+    e = engine_mod.Engine(0, **params)
+    e.set_cloud(pts)
+    return e, o
+
+
+def assert_full_parity(engine_mod, e, o, every_slice=True):
+    So = o.gen_path(); S = e.gen_path()
+    assert S == So
+    Wo = o.get_path(); W = e.get_path()
+    assert W == Wo
+    mn, mx = e.minmax(); omn, omx = o.minmax()
+    assert np.array_equal(mn, omn) and np.array_equal(mx, omx)
+    assert np.array_equal(e.slice_positions(), o.slice_positions())
+    step = 1 if every_slice else max(1, S // 24)
+    for s in range(0, S, step):
+        assert np.array_equal(e.slice_indices(s), o.slice_indices(s)), s
+    for s in range(S):
+        gy, gx, gz = e.nodes(s); oy, ox, oz = o.nodes(s)
+        assert np.array_equal(gy, oy) and np.array_equal(gx, ox) and np.array_equal(gz, oz), s
+    assert np.array_equal(e.tail_index(), o.tail_index())
+    if W == 0:
+        return
+    assert np.array_equal(e.stage(engine_mod.STAGE_WP_XYZ), o.waypoints_xyz())
+    assert np.array_equal(e.stage(engine_mod.STAGE_WP_NN), o.waypoint_nn())
+    n, on = e.stage(engine_mod.STAGE_WP_NORMAL), o.waypoint_normals()
+    ang = np.arctan2(np.linalg.norm(np.cross(n[:, :3], on[:, :3]), axis=1), np.sum(n[:, :3] * on[:, :3], axis=1))
+    assert ang.max() < 1e-4
+    pre, opre = e.stage(engine_mod.STAGE_WP_PRESMOOTH), o.waypoints_presmooth()
+    assert np.abs(pre[:, :3] - opre[:, :3]).max() <= 1e-6
+    sm, osm = e.stage(engine_mod.STAGE_WP_SMOOTHED), o.waypoints_smoothed()
+    assert np.abs(sm[:, :3] - osm[:, :3]).max() <= 1e-6
+    assert abs(e.smooth_sweeps() - o.smooth_sweeps()) <= 1
+    wp, owp = e.waypoints(), o.waypoints()
+    assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
+    d = np.abs(wp[:, 3:] - owp[:, 3:])
+    assert np.minimum(d, np.abs(d - 2 * np.pi)).max() <= TOL_RAD
+
+
+@pytest.mark.parametrize("name,pairing,walk", [
+    ("tiny_5k", 0, 1), ("tiny_5k", 1, 1), ("small_40k", 0, 1), ("small_40k", 1, 3), ("small_40k", 0, 0),
+    ("small_40k", 0, 2), ("small_40k", 1, 4), ("cfg1_50k_s32", 0, 1), ("cfg1_50k_s32", 1, 3),
+])
+def test_pipeline_parity(engine_mod, oracle_mod, name, pairing, walk):
+    pts, cfg = synth.make_config(name)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=cfg["tool_radius"], pairing=pairing, walk=walk)
+    assert_full_parity(engine_mod, e, o)
+
+
+@pytest.mark.parametrize("name", ["cfg3_250k_s128", "cfg2_1m_s256"])
+def test_baseline_configs_full_size(engine_mod, oracle_mod, name):
+    """BASELINE.json sizes: the oracle's fast mode still finishes in about a second."""
+    pts, cfg = synth.make_config(name)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=cfg["tool_radius"])
+    assert_full_parity(engine_mod, e, o, every_slice=False)
+    assert e.num_slices() == cfg["slices"]
+
+
+def test_contour_variant_trim5_no_drop_no_smooth(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0, trim=5.0, drop_ends=0, smooth=0, rpy_resolution=2.0)
+    assert_full_parity(engine_mod, e, o)
+    assert e.smooth_sweeps() == 0 == o.smooth_sweeps()
+
+
+def test_other_resolutions(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=9.0, path_resolution=3.3, rpy_resolution=4.0, ee_length=0.12)
+    assert_full_parity(engine_mod, e, o)
+
+
+def test_not_change_range(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("tiny_5k")
+    mm = (pts * 1000).astype(np.float32)
+    e, o = run_pair(engine_mod, oracle_mod, mm, tool_radius=6.0, change_range=0)
+    assert_full_parity(engine_mod, e, o)
+
+
+def test_rerun_is_bitwise_reproducible(engine_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    e.gen_path(); e.get_path()
+    a = e.waypoints().tobytes()
+    for _ in range(3):
+        e.gen_path(); e.get_path()
+        assert e.waypoints().tobytes() == a
+    e2 = engine_mod.Engine(0, tool_radius=6.0)
+    e2.set_cloud(pts[:, :3].copy())
+    e2.gen_path(); e2.get_path()
+    assert e2.waypoints().tobytes() == a
+
+
+def test_point_order_changes_nothing_but_indices(engine_mod):
+    """Property: a permutation of the cloud permutes indices only (no exact ties in the fixtures)."""
+    pts, cfg = synth.make_config("tiny_5k")
+    perm = np.random.default_rng(0).permutation(len(pts))
+    e1 = engine_mod.Engine(0, tool_radius=6.0); e1.set_cloud(pts); e1.gen_path(); e1.get_path()
+    e2 = engine_mod.Engine(0, tool_radius=6.0); e2.set_cloud(pts[perm]); e2.gen_path(); e2.get_path()
+    assert np.array_equal(e1.stage(engine_mod.STAGE_WP_XYZ), e2.stage(engine_mod.STAGE_WP_XYZ))
+    assert np.array_equal(perm[e2.stage(engine_mod.STAGE_WP_NN)], e1.stage(engine_mod.STAGE_WP_NN))
+    assert np.abs(e1.waypoints() - e2.waypoints()).max() < 1e-5
+
+
+def test_stride_32_pointxyzrgb_layout(engine_mod):
+    pts, cfg = synth.make_config("tiny_5k")
+    aos = np.zeros((len(pts), 8), np.float32)  # pcl::PointXYZRGB: xyz + pad, rgba + pad
+    aos[:, :3] = pts
+    aos[:, 3] = 1.0
+    aos[:, 4] = np.float32(2.3e-38)
+    a = engine_mod.Engine(0, tool_radius=6.0); a.set_cloud(pts); a.gen_path(); a.get_path()
+    b = engine_mod.Engine(0, tool_radius=6.0); b.set_cloud(aos); b.gen_path(); b.get_path()
+    assert a.waypoints().tobytes() == b.waypoints().tobytes()
+
+
+# ---------------- API mirrors of the reference's public methods ----------------
+def test_ranged_x_index_api(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    mn, mx = o.minmax()
+    for pos in [int(mn[0]) - 5, int(mn[0]), 77, 78, 300, int(mx[0]) + 1, int(mx[0]) + 9]:
+        assert np.array_equal(e.ranged_x_index(pos), o.ranged_x_index(pos)), pos
+
+
+@pytest.mark.parametrize("pairing", [0, 1])
+def test_insert_point_api_arbitrary_index_order(engine_mod, oracle_mod, pairing):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0, pairing=pairing)
+    rng = np.random.default_rng(3)
+    for px in [100.0, 250.6, 411.2]:
+        idx = o.ranged_x_index(int(px))
+        for order in (idx, idx[::-1].copy(), rng.permutation(idx)):  # El/Er order is the caller's order
+            m, y, x, z = e.insert_point(order, px)
+            om, oy, ox, oz = o.insert_point(order, px)
+            assert m == om and np.array_equal(y, oy) and np.array_equal(x, ox) and np.array_equal(z, oz)
+
+
+def test_insert_point_api_errors(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("tiny_5k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    idx = o.ranged_x_index(40)
+    assert e.insert_point(idx, -500.0)[0] == engine_mod.ERR_SLICE  # empty right side
+    m, y, x, z = e.insert_point(idx, 5000.0)                        # empty left side: empty map
+    assert m == 0
+    assert e.insert_point(np.zeros(0, np.int32), 40.0)[0] == 0
+
+
+def test_eval_spline_api(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    e.gen_path(); o.gen_path()
+    for s in [0, 7, e.num_slices() - 1]:
+        y, x, z = o.nodes(s)
+        q = np.concatenate([y[:5], np.linspace(y[0], y[-1], 257), [y[-1]]])
+        rc, got = e.eval_spline(s, q)
+        orc, want = o.eval_spline(s, q)
+        assert rc == 0 == orc and np.array_equal(got, want)   # same double operations, same order
+        rc, got = e.eval_spline(s, np.array([y[0] - 1e-9, y[-1] + 1.0, y[3]]))
+        assert rc == engine_mod.ERR_DOMAIN and np.isnan(got[0]).all() and np.isnan(got[1]).all() and not np.isnan(got[2]).any()
+
+
+def test_nearest_and_normals_api(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    cloud = o.points()
+    rng = np.random.default_rng(5)
+    q = cloud[rng.integers(0, len(cloud), 500)] + rng.normal(0, 1.5, (500, 3)).astype(np.float32)
+    q[:5] += 40.0  # far queries: the slab walk must keep going
+    got = e.nearest(q)
+    want = np.array([o.nearest(v)[0] for v in q])
+    assert np.array_equal(got, want)
+    idx = rng.integers(0, len(cloud), 400).astype(np.int32)
+    n = e.normals_at(idx)
+    on = np.stack([o.normal_at(i) for i in idx])
+    nan = np.isnan(on[:, 0])
+    assert np.array_equal(np.isnan(n[:, 0]), nan)
+    ang = np.arctan2(np.linalg.norm(np.cross(n[~nan, :3], on[~nan, :3]), axis=1), np.sum(n[~nan, :3] * on[~nan, :3], axis=1))
+    assert ang.max() < 1e-4 and np.abs(n[~nan, 3] - on[~nan, 3]).max() < 1e-5
+
+
+# ---------------- edge cases the domain has ----------------
+def test_nan_points_are_dropped_everywhere(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("tiny_5k")
+    pts = pts.copy()
+    pts[::97, 0] = np.nan
+    pts[5::131, 2] = np.inf
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    assert_full_parity(engine_mod, e, o)
+
+
+def test_slice_with_too_few_nodes_is_reported_not_aborted(engine_mod, oracle_mod):
+    # a cloud whose first band holds a single column of points: the reference would abort in GSL
+    pts = synth.make_plate(40, 30, seed=2)
+    keep = ~((pts[:, 0] * 1000 < 9.0) & (np.abs(pts[:, 1]) * 1000 > 3.0))
+    pts = pts[keep]
+    o = oracle_mod.Oracle(pts, tool_radius=3.0, walk=3)
+    rc = o.gen_path()
+    e = engine_mod.Engine(0, tool_radius=3.0, walk=3)
+    e.set_cloud(pts)
+    e.gen_path_async()
+    if rc < 0:
+        with pytest.raises(engine_mod.PPPError) as ei:
+            e.sync()
+        assert ei.value.code == engine_mod.ERR_SLICE and e.failed_slice() == -rc - 1
+    else:
+        e.sync()
+
+
+def test_empty_cloud(engine_mod):
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(np.zeros((0, 3), np.float32))
+    assert e.gen_path() == 0
+    assert e.get_path() == 0
+    assert e.waypoints().shape == (0, 6)
+
+
+def test_short_slices_take_the_sequential_rpy_path(engine_mod, oracle_mod):
+    # a narrow plate: every slice yields fewer than RPYres+1 waypoints (App. B.6 overlap quirk)
+    pts = synth.make_plate(120, 38, kind="wavy", amp=3.0, seed=7)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    assert_full_parity(engine_mod, e, o)
+    assert o.get_path() > 0 and np.diff(np.concatenate([[-1], o.tail_index()])).max() <= 7
+
+
+def test_unsupported_options_fail_loudly(engine_mod):
+    e = engine_mod.Engine(0)
+    with pytest.raises(engine_mod.PPPError) as ei:
+        e.set_params(dynamic_adjustment=1)
+    assert ei.value.code == engine_mod.ERR_UNSUPPORTED
+    with pytest.raises(engine_mod.PPPError):
+        e.set_params(alignment=1, dynamic_adjustment=0)
+    with pytest.raises(engine_mod.PPPError):
+        e.set_params(alignment=0, path_resolution=0.0)
+
+
+def test_call_order_errors(engine_mod):
+    e = engine_mod.Engine(0)
+    with pytest.raises(engine_mod.PPPError):
+        e.gen_path_async()          # no cloud
+    pts, cfg = synth.make_config("tiny_5k")
+    e.set_cloud(pts)
+    with pytest.raises(engine_mod.PPPError):
+        e.get_path_async()          # getPath before GenPath
+
+
+def test_params_change_replans(engine_mod, oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    e.gen_path(); e.get_path()
+    e.set_params(tool_radius=10.0, walk=0)
+    o = oracle_mod.Oracle(pts, tool_radius=10.0, walk=0)
+    assert_full_parity(engine_mod, e, o)
+
+
+def test_two_handles_interleaved(engine_mod, oracle_mod):
+    a_pts, _ = synth.make_config("tiny_5k")
+    b_pts, _ = synth.make_config("small_40k")
+    a = engine_mod.Engine(0, tool_radius=6.0); b = engine_mod.Engine(0, tool_radius=6.0)
+    a.set_cloud(a_pts); b.set_cloud(b_pts)
+    a.gen_path_async(); b.gen_path_async(); a.get_path_async(); b.get_path_async()
+    a.sync(); b.sync()
+    for eng, pts in ((a, a_pts), (b, b_pts)):
+        o = oracle_mod.Oracle(pts, tool_radius=6.0); o.gen_path(); o.get_path()
+        assert np.linalg.norm(eng.waypoints()[:, :3] - o.waypoints()[:, :3], axis=1).max() <= TOL_M
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
