@@ -1,0 +1,76 @@
+/*
+ * Path_Generate.h -- drop-in for the reference header of the same name (class path_generater,
+ * :33-75), the planner ./main links (src/main.cpp, src/Path_Generation.cpp): brute-force pairing
+ * (insert_point, Path_Generation.cpp:107-206) and the float walks of slicing_method (:282-321)
+ * and Contact_Path_Generation (:689-755).  The dynamic adjustment half of
+ * Contact_Path_Generation (compute_boundary / dynamic_adjust_path) is a "next" row
+ * (SURVEY.md 8f rank 1): the contact paths are produced without it and a note is printed.
+ */
+#ifndef PATH_GENERATION
+#define PATH_GENERATION
+
+#include <chrono>
+#include <fstream>
+#include <string>
+#include <vector>
+#include "Spline.h"
+
+class path_generater {
+public:
+    path_generater() {}
+    path_generater(std::string cloud_name, double Radius) : toolRadius(Radius), file_name(cloud_name)
+    {
+        ppp_params &p = planner.config().params;
+        p.tool_radius = Radius; p.pairing = PPP_PAIR_BRUTE; p.walk = PPP_WALK_V1_CONTACT; p.change_range = 1; /* always x1000, :28-30 */
+        planner.open(cloud_name);
+    }
+    ~path_generater() {}
+
+    void show() { planner.show_notice(); }
+    void voxel_down(const float, const float, const float) { note("voxel_down"); }
+    void trans2center() { note("trans2center"); }
+    void smooth() { note("smooth"); }
+    void Set_kdtree() {}
+    void estimate_normal() {}
+    void get_coverage() { note("get_coverage"); }
+
+    std::vector<int> rangedX_index(int position) { return planner.rangedX_index(position); }
+    std::map<double, std::vector<double>> insert_point(std::vector<int> indices, Eigen::Vector3f PlanePoint)
+    {
+        return planner.insert_point(indices, PlanePoint[0]);
+    }
+    /* Path_Generation.cpp:282-321: insert_point on every slice of the min+step/2 walk */
+    void slicing_method() { run(PPP_WALK_V1_SLICING, "use time: "); }
+    /* Path_Generation.cpp:689-755 without the dynamic adjustment */
+    void Contact_Path_Generation()
+    {
+        printf("Start Path Planning!\n");
+        run(PPP_WALK_V1_CONTACT, "Toal Using Time: ");
+        fprintf(stderr, "ppp: dynamic adjustment of the contact paths is not accelerated yet (SURVEY.md 8f rank 1)\n");
+    }
+    std::vector<Spline> &paths() { return Path_set; }
+
+private:
+    void run(int walk, const char *label)
+    {
+        auto t0 = std::chrono::high_resolution_clock::now();
+        planner.config().params.walk = walk;
+        if (!planner.apply_params() || !planner.gen_path()) return;
+        Path_set.clear();
+        int S = planner.num_slices();
+        for (int s = 0; s < S; ++s) Path_set.emplace_back(planner.handle(), s);
+        auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        std::cout << label << us << std::endl;
+        std::cout << "number of paths: " << S << std::endl;
+        std::ofstream outputFile("output.csv", std::ios::app); /* Path_Generation.cpp:312-320 */
+        if (outputFile.is_open()) outputFile << us << std::endl;
+    }
+    void note(const char *what) { fprintf(stderr, "ppp: %s() is outside the accelerated path (no-op)\n", what); }
+
+    ppp::Planner planner;
+    double toolRadius = 15;
+    std::vector<Spline> Path_set;
+    std::string file_name;
+};
+
+#endif

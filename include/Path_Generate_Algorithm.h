@@ -1,0 +1,136 @@
+/*
+ * Path_Generate_Algorithm.h -- drop-in for the reference header of the same name
+ * (class SectPath :57-98, class path_generater :102-135), used by src/connect.cpp and
+ * src/connect1.cpp.  Same public methods and constructor arguments; the arithmetic runs on the
+ * MI355X through include/ppp_hip.h.  Differences a caller can observe:
+ *   - show() prints a notice instead of opening a PCL viewer (visualisation is out of scope);
+ *   - Dynamic_adjustment / Alignment / Smooth / RemoveOutlier = true are reported and ignored
+ *     (SURVEY.md 8f "next" rows), the equal-spacing path is produced;
+ *   - conditions on which the reference aborts (GSL / FLANN) are reported on stderr instead.
+ * Build connect1's single-direction walk with -DPPP_SDIR (it links dynamic_alg_sdir.cpp in the
+ * reference, CMakeLists.txt:38-47).
+ */
+#ifndef PATH_CONNECT
+#define PATH_CONNECT
+
+#include <string>
+#include <vector>
+#include "Spline.h"
+
+#define HANDEYEx -0.764091
+#define HANDEYEy 0.025886
+#define HANDEYEz 0.663790
+#define HANDEYErx -3.1270175
+#define HANDEYEry -0.040124
+#define HANDEYErz -1.6063578
+
+/* Base class: equal spacing path + robot path (path_slicing_alg.cpp, path_translation_alg.cpp) */
+class SectPath {
+public:
+    SectPath() {}
+    SectPath(std::string configName, std::string CloudFileName) : cloud_name(CloudFileName)
+    {
+        read_config(configName);
+        planner.config().params.walk = PPP_WALK_SECTPATH;
+        init_common();
+        planner.open(cloud_name);
+    }
+    virtual ~SectPath() {}
+
+    void show() { planner.show_notice(); }
+    void estimate_normal() { /* normals are evaluated where getPath needs them (ppp_normals_at) */ }
+    virtual void GenPath()
+    {
+        printf("Start Path Planning!\n");
+        if (!planner.gen_path()) return;
+        build_path_set();
+        printf("Number of paths: %d\n", (int)Path_set.size());
+    }
+    void getPath()
+    {
+        /* Path_set.erase(begin) + pop_back (path_translation_alg.cpp:149-150) happen inside the engine */
+        std::cout << "Path number is " << (Path_set.size() >= 2 ? Path_set.size() - 2 : 0) << std::endl;
+        std::vector<float> wp;
+        if (!planner.get_path(wp)) return;
+        WayPointsList.assign(wp.size() / 6, std::vector<float>(6));
+        for (size_t w = 0; w < WayPointsList.size(); ++w)
+            for (int d = 0; d < 6; ++d) WayPointsList[w][d] = wp[6 * w + d];
+    }
+    const std::vector<std::vector<float>> &waypoints() const { return WayPointsList; }
+
+protected:
+    virtual void read_config(std::string filename)
+    {
+        ppp_read_config(filename.c_str(), &planner.config());
+        ppp_config &c = planner.config();
+        toolRadius = c.params.tool_radius; PathResolution = c.params.path_resolution; RPYres = c.params.rpy_resolution;
+        EElen = c.params.ee_length; ifChangeRange = c.params.change_range; ifAlign = c.alignment; ifSmooth = c.smooth_cloud;
+        ifRemove = c.remove_outlier; pathFile = c.path_file;
+        if (ifAlign || ifSmooth || ifRemove)
+            fprintf(stderr, "ppp: Alignment / Smooth / RemoveOutlier are outside the accelerated path and are ignored\n");
+    }
+    void init_common()
+    {
+        ppp_params &p = planner.config().params;
+        p.pairing = PPP_PAIR_KD; p.trim = 10; p.drop_ends = 1; p.smooth = 1;
+        const float he[6] = {(float)HANDEYEx, (float)HANDEYEy, (float)HANDEYEz, (float)HANDEYErx, (float)HANDEYEry, (float)HANDEYErz};
+        for (int i = 0; i < 6; ++i) p.handeye[i] = he[i];
+    }
+    void build_path_set()
+    {
+        Path_set.clear();
+        int S = planner.num_slices();
+        for (int s = 0; s < S; ++s) Path_set.emplace_back(planner.handle(), s);
+    }
+
+    /* Path planning Alg. */
+    std::vector<int> rangedX_index(int position) { return planner.rangedX_index(position); }
+    MAP insert_point(std::vector<int> indices, Eigen::Vector3f PlanePoint) { return planner.insert_point(indices, PlanePoint[0]); }
+
+    ppp::Planner planner;
+    double toolRadius = 12, PathResolution = 7, RPYres = 7;
+    float EElen = 0.3f;
+    bool ifAlign = false, ifSmooth = false, ifChangeRange = true, ifRemove = false;
+    std::vector<Spline> Path_set;
+    std::string cloud_name, pathFile;
+    std::vector<std::vector<float>> WayPointsList;
+};
+
+/* Derived class of the reference: dynamic adjustment (path_dynamic_alg.cpp / dynamic_alg_sdir.cpp) */
+class path_generater : public SectPath {
+public:
+    path_generater() {}
+    path_generater(std::string configName, std::string CloudFileName)
+    {
+        cloud_name = CloudFileName;
+        read_config(configName);
+#ifdef PPP_SDIR
+        planner.config().params.walk = PPP_WALK_SDIR_INT;   /* dynamic_alg_sdir.cpp:349-374 */
+#else
+        planner.config().params.walk = PPP_WALK_CENTER_INT; /* path_dynamic_alg.cpp:308-372 */
+#endif
+        init_common();
+        planner.open(cloud_name);
+    }
+    void GenPath() override
+    {
+        printf("Start Path Planning!\n");
+        if (!planner.gen_path()) return;
+        build_path_set();
+    }
+    typedef enum { left, right } Dir;
+
+private:
+    void read_config(std::string filename) override
+    {
+        SectPath::read_config(filename);
+        ppp_config &c = planner.config();
+        depth = c.depth; Adjust_Threshold = c.adjust_threshold; toolthickness = c.toolthickness; Adjust = c.dynamic_adjustment;
+        if (Adjust)
+            fprintf(stderr, "ppp: Dynamic_adjustment=true is not accelerated yet (SURVEY.md 8f rank 1): producing the equal-spacing path\n");
+    }
+    double depth = 0.01, Adjust_Threshold = 1, toolthickness = 10;
+    bool Adjust = false;
+};
+
+#endif

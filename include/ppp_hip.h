@@ -150,6 +150,27 @@ enum { PPP_STAGE_WP_XYZ = 0,      /* W x 3 float: sampled points, mm (path_trans
 int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *count);
 int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
 
+/* ---- host-side file formats of the reference (no device work) ---- */
+/* pcl::io::loadPCDFile<PointXYZRGB> (path_slicing_alg.cpp:10, Path_Generation.cpp:8): PCD v0.7,
+ * DATA ascii | binary, fields matched by name, x y z as F4 or F8.  *xyz receives n x 3 packed
+ * floats allocated by the library (release with ppp_free); viewpoint = the 7 VIEWPOINT numbers
+ * (tx ty tz qw qx qy qz).  binary_compressed -> PPP_ERR_UNSUPPORTED. */
+int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7]);
+int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary);
+void ppp_free(void *p);
+/* SectPath::read_config / path_generater::read_config (path_slicing_alg.cpp:32-67,
+ * path_dynamic_alg.cpp:34-75): same key set and parsing rules; absent keys keep config.txt's values */
+typedef struct ppp_config {
+    ppp_params params;
+    char path_file[512];      /* pathFile */
+    double depth, adjust_threshold, toolthickness;
+    int smooth_cloud, remove_outlier, alignment, dynamic_adjustment; /* parsed, outside the hot path */
+} ppp_config;
+void ppp_default_config(ppp_config *c);
+int ppp_read_config(const char *path, ppp_config *c);
+/* pathFile writer (path_translation_alg.cpp:216-228): "x y z r p y " per line, ostream defaults */
+int ppp_write_path_file(const char *path, const float *wp6, size_t W);
+
 /* ---- measurement ---- */
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
 int ppp_enable_timing(ppp_handle h, int on);

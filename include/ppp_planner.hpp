@@ -1,0 +1,156 @@
+/*
+ * ppp_planner.hpp -- shared plumbing of the drop-in planner classes (Path_Generate.h,
+ * Path_Generate_Algorithm.h, robot_path.h): owns one engine handle, loads the PCD, forwards
+ * every method to the C ABI of include/ppp_hip.h.  Header-only on purpose: the reference
+ * defines two different classes named path_generater (one per executable), so nothing here
+ * may live in a shared translation unit.
+ *
+ * Types in the public signatures: with Eigen available (-DPPP_WITH_EIGEN or <Eigen/Dense> on
+ * the include path) the real Eigen::Vector3f / Vector3d are used; otherwise the three-float
+ * stand-ins below, which cover what the reference's callers do with them (construct from
+ * three numbers, index with []).  PCL is not needed: the cloud lives in HBM.
+ */
+#ifndef PPP_PLANNER_HPP
+#define PPP_PLANNER_HPP
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ppp_hip.h"
+
+#if defined(PPP_WITH_EIGEN) || (defined(__has_include) && __has_include(<Eigen/Dense>))
+#include <Eigen/Dense>
+#else
+namespace Eigen {
+template <typename T>
+struct PppVec3 {
+    T v[3];
+    PppVec3() : v{0, 0, 0} {}
+    PppVec3(T a, T b, T c) : v{a, b, c} {}
+    T &operator[](int i) { return v[i]; }
+    const T &operator[](int i) const { return v[i]; }
+    T &operator()(int i) { return v[i]; }
+    const T &operator()(int i) const { return v[i]; }
+};
+typedef PppVec3<float> Vector3f;
+typedef PppVec3<double> Vector3d;
+} // namespace Eigen
+#endif
+
+typedef std::map<double, std::vector<double>> MAP; /* Path_Generate_Algorithm.h:53 */
+
+namespace ppp {
+
+/* One engine handle + the state every planner class of the reference keeps. */
+class Planner {
+public:
+    Planner() { ppp_default_config(&cfg_); }
+    ~Planner() { if (h_) ppp_destroy(h_); }
+    Planner(const Planner &) = delete;
+    Planner &operator=(const Planner &) = delete;
+
+    bool ok() const { return h_ != nullptr && loaded_; }
+    ppp_handle handle() const { return h_; }
+    ppp_config &config() { return cfg_; }
+
+    /* constructor body of the reference classes: load, recolour (no-op here), scale, keep */
+    bool open(const std::string &cloud_name)
+    {
+        if (!h_ && ppp_create(device_from_env(), &h_) != PPP_OK) {
+            std::fprintf(stderr, "ppp: no MI355X device available (the engine has no CPU fallback)\n");
+            h_ = nullptr;
+            return false;
+        }
+        if (!apply_params()) return false;
+        float *xyz = nullptr;
+        size_t n = 0;
+        float vp[7];
+        if (ppp_load_pcd(cloud_name.c_str(), &xyz, &n, vp) != PPP_OK) {
+            std::fprintf(stderr, "Cloudn't read file!\n"); /* path_slicing_alg.cpp:11 */
+            loaded_ = false;
+            return false;
+        }
+        int rc = ppp_set_cloud(h_, xyz, n, 12, vp);
+        ppp_free(xyz);
+        if (rc != PPP_OK) return report(rc);
+        loaded_ = true;
+        return true;
+    }
+    bool apply_params()
+    {
+        int rc = ppp_set_params(h_, &cfg_.params);
+        return rc == PPP_OK ? true : report(rc);
+    }
+    bool report(int rc) const
+    {
+        std::fprintf(stderr, "ppp error %d: %s\n", rc, h_ ? ppp_last_error(h_) : "no handle");
+        return false;
+    }
+    std::vector<int> rangedX_index(int position)
+    {
+        std::vector<int> out(4096);
+        size_t n = 0;
+        int rc = ppp_ranged_x_index(h_, position, out.data(), out.size(), &n);
+        if (rc != PPP_OK) { report(rc); n = 0; }
+        out.resize(n);
+        return out;
+    }
+    MAP insert_point(const std::vector<int> &indices, float plane_x)
+    {
+        MAP Node;
+        std::vector<double> y(indices.size() + 1), x(indices.size() + 1), z(indices.size() + 1);
+        size_t m = 0;
+        int rc = ppp_insert_point(h_, indices.data(), indices.size(), plane_x, y.data(), x.data(), z.data(), indices.size(), &m);
+        if (rc != PPP_OK) { report(rc); return Node; }
+        for (size_t i = 0; i < m; ++i) Node[y[i]] = {x[i], z[i]};
+        return Node;
+    }
+    bool gen_path()
+    {
+        int rc = ppp_gen_path_async(h_);
+        if (rc == PPP_OK) rc = ppp_sync(h_);
+        return rc == PPP_OK ? true : report(rc);
+    }
+    /* getPath(): returns the list and writes pathFile exactly like path_translation_alg.cpp:216-228 */
+    bool get_path(std::vector<float> &wp6)
+    {
+        int rc = ppp_get_path_async(h_);
+        if (rc == PPP_OK) rc = ppp_sync(h_);
+        if (rc != PPP_OK) return report(rc);
+        size_t W = 0;
+        ppp_num_waypoints(h_, &W);
+        wp6.resize(6 * W);
+        rc = ppp_get_waypoints(h_, wp6.data(), W, &W);
+        if (rc != PPP_OK) return report(rc);
+        std::cout << "!!!!! GOT PATH !!!!!" << std::endl;
+        if (ppp_write_path_file(cfg_.path_file, wp6.data(), W) == PPP_OK) std::cout << "File saved: " << cfg_.path_file << std::endl;
+        return true;
+    }
+    int num_slices()
+    {
+        int S = 0;
+        ppp_num_slices(h_, &S);
+        return S;
+    }
+    void show_notice() const
+    {   /* show() opens a VTK window in the reference (visualisation: outside the hot path) */
+        std::printf("show(): viewer not built; the cloud stays resident on the GPU\n");
+    }
+    static int device_from_env()
+    {
+        const char *e = std::getenv("PPP_DEVICE");
+        return e ? std::atoi(e) : 0;
+    }
+
+private:
+    ppp_handle h_ = nullptr;
+    ppp_config cfg_;
+    bool loaded_ = false;
+};
+
+} // namespace ppp
+#endif

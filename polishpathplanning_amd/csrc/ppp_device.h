@@ -103,6 +103,14 @@ __host__ __device__ inline int ppp_slice_walk(int walk, float min_x, float max_x
     return 0;
 }
 
+/* Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding
+   global store (s_waitcnt vmcnt(0)), which costs a memory round trip per sweep in kernels that
+   stream results out while they keep iterating in LDS. */
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /* ---- block-wide helpers (blockDim.x multiple of 64, <= 1024) ---- */
 template <typename T>
 __device__ inline T wave_sum(T v)

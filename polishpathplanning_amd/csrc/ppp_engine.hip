@@ -23,8 +23,8 @@ namespace {
 
 struct KTimer {
     std::string name;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool used = false;
+    std::vector<hipEvent_t> e0, e1; /* one pair per launch of this kernel in a pass */
+    int used = 0;
 };
 
 template <typename T>
@@ -71,7 +71,10 @@ struct ppp_handle_s {
     DevBuf<int> wp_cnt, wp_off, tail;
     DevBuf<float4> wp_xyz, wp_normal;
     DevBuf<int> wp_nn;
-    DevBuf<float> wp_pre, wp_smooth, wp_out, sx, ya, yb;
+    DevBuf<float> wp_pre, wp_smooth, wp_out, sx, snap;
+    DevBuf<MinMaxPart> mm_part;
+    DevBuf<double> sm_part;
+    int mm_grid = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
 
     DevMeta hmeta;
@@ -86,8 +89,8 @@ struct ppp_handle_s {
         meta.release(); px.release(); lo.release(); hi.release(); node_y.release(); node_z.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
-        sx.release(); ya.release(); yb.release(); scratch.release();
-        for (auto &t : timers) { if (t.e0) (void)hipEventDestroy(t.e0); if (t.e1) (void)hipEventDestroy(t.e1); }
+        sx.release(); snap.release(); mm_part.release(); sm_part.release(); scratch.release();
+        for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -121,22 +124,24 @@ DevParams dev_params(const ppp_handle h)
 
 KTimer *timer_for(ppp_handle h, const char *name)
 {
-    for (auto &t : h->timers) if (t.name == name) return &t;
-    h->timers.emplace_back();
-    KTimer &t = h->timers.back();
-    t.name = name;
-    (void)hipEventCreate(&t.e0);
-    (void)hipEventCreate(&t.e1);
-    return &t;
+    KTimer *t = nullptr;
+    for (auto &x : h->timers) if (x.name == name) { t = &x; break; }
+    if (!t) { h->timers.emplace_back(); t = &h->timers.back(); t->name = name; }
+    if ((size_t)t->used >= t->e0.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        t->e0.push_back(a); t->e1.push_back(b);
+    }
+    return t;
 }
 
 /* launch helper: optional hipEvent bracket on the handle's stream */
 #define LAUNCH(h, name, kern, grid, block, shmem, ...)                                                \
     do {                                                                                              \
         KTimer *_t = (h)->timing ? timer_for((h), name) : nullptr;                                    \
-        if (_t) (void)hipEventRecord(_t->e0, (h)->stream);                                            \
+        if (_t) (void)hipEventRecord(_t->e0[_t->used], (h)->stream);                                  \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (h)->stream, __VA_ARGS__);         \
-        if (_t) { (void)hipEventRecord(_t->e1, (h)->stream); _t->used = true; }                       \
+        if (_t) { (void)hipEventRecord(_t->e1[_t->used], (h)->stream); _t->used++; }                  \
         hipError_t _le = hipGetLastError();                                                           \
         if (_le != hipSuccess) return fail((h), PPP_ERR_HIP, std::string(name) + ": " + hipGetErrorString(_le)); \
     } while (0)
@@ -149,7 +154,7 @@ int validate_params(ppp_handle h, const ppp_params *p)
     if (p->pairing != PPP_PAIR_KD && p->pairing != PPP_PAIR_BRUTE) return fail(h, PPP_ERR_ARG, "pairing");
     if (p->walk < 0 || p->walk > 4) return fail(h, PPP_ERR_ARG, "walk");
     if (!(p->normal_radius > 0)) return fail(h, PPP_ERR_ARG, "normal_radius");
-    if (p->smooth_max_sweeps < 1) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps");
+    if (p->smooth_max_sweeps < 1 || p->smooth_max_sweeps > SM_MAXS) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps must be in [1, 512]");
     if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
     if (p->dynamic_adjustment) return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment is outside the hot path (SURVEY.md 8f rank 1)");
     return PPP_OK;
@@ -160,11 +165,18 @@ int make_plan(ppp_handle h)
 {
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     const int n = (int)h->n;
-    /* x-slabs: ~1024 points each, histogram must fit LDS */
-    int B = (h->h_nvalid + 1023) / 1024;
+    /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS */
+    int B = (h->h_nvalid + 639) / 640;
     B = std::max(1, std::min(B, 8192));
     h->B = B;
-    h->slab_cap = 4096;
+    {
+        double mean = (double)h->h_nvalid / B;
+        int cap = 1024;
+        while (cap < 4096 && cap < 1.5 * mean) cap <<= 1;
+        h->slab_cap = cap;
+    }
+    h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 512));
+    HIPCHK(h, h->mm_part.ensure(h->mm_grid));
     /* exact slice count from the cached bounds (the device recomputes the same walk) */
     int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
     if (S >= PPP_WALK_HARD_MAX) return fail(h, PPP_ERR_CAPACITY, "slice walk does not terminate");
@@ -196,7 +208,10 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->wp_xyz.ensure(h->W_cap)); HIPCHK(h, h->wp_normal.ensure(h->W_cap)); HIPCHK(h, h->wp_nn.ensure(h->W_cap));
     HIPCHK(h, h->wp_pre.ensure(6 * (size_t)h->W_cap)); HIPCHK(h, h->wp_smooth.ensure(6 * (size_t)h->W_cap));
     HIPCHK(h, h->wp_out.ensure(6 * (size_t)h->W_cap));
-    HIPCHK(h, h->sx.ensure(3 * (size_t)h->W_cap)); HIPCHK(h, h->ya.ensure(3 * (size_t)h->W_cap)); HIPCHK(h, h->yb.ensure(3 * (size_t)h->W_cap));
+    HIPCHK(h, h->sx.ensure(3 * (size_t)h->W_cap));
+    HIPCHK(h, h->snap.ensure(2 * (size_t)SM_K * 3 * (size_t)h->W_cap));
+    h->sm_tiles = smooth_tiles(h->W_cap);
+    HIPCHK(h, h->sm_part.ensure((size_t)(SM_MAXS + SM_K + 1) * h->sm_tiles));
     h->planned = true;
     h->index_built = false; h->gen_done = false; h->path_done = false;
     return PPP_OK;
@@ -207,11 +222,9 @@ int enqueue_index(ppp_handle h)
 {
     const int n = (int)h->n;
     DevParams D = dev_params(h);
-    LAUNCH(h, "k_reset", k_reset, 1, 64, 0, h->meta.p);
-    int g = std::max(1, std::min((n + 255) / 256, 2048));
-    LAUNCH(h, "k_minmax", k_minmax, g, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->meta.p);
-    LAUNCH(h, "k_setup", k_setup, 1, 64, 0, h->meta.p, D, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B);
-    HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * h->B, h->stream));
+    LAUNCH(h, "k_minmax", k_minmax, h->mm_grid, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p);
+    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
+           h->slab_cnt.p);
     size_t hist_lds = sizeof(int) * (size_t)h->B;
     int gh = std::max(1, std::min((n + 256 * 16 - 1) / (256 * 16), 1024));
     LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, h->meta.p, h->slab_cnt.p);
@@ -272,7 +285,10 @@ int ensure_index(ppp_handle h)
     return PPP_OK;
 }
 
-int slice_lds_ok(ppp_handle h, int capb) { return slice_lds_bytes(capb) + 1024 <= (size_t)h->max_lds; }
+int slice_lds_ok(ppp_handle h, int capb)
+{
+    return std::max(slice_lds_bytes(capb), slice_kd_lds_bytes(capb)) + 1024 <= (size_t)h->max_lds;
+}
 
 int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
 {
@@ -286,16 +302,21 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
         HIPCHK(h, hipGetLastError());
     }
     /* cache the bounds for the plan (sizing only; the hot path recomputes them on device) */
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, h->stream, h->meta.p);
-    int g = std::max(1, std::min(((int)n + 255) / 256, 2048));
-    hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->meta.p);
-    HIPCHK(h, hipGetLastError());
-    int rc = fetch_meta(h);
-    if (rc) return rc;
-    h->h_nvalid = h->hmeta.n_valid;
-    for (int d = 0; d < 3; ++d) {
-        h->h_mn[d] = h->h_nvalid ? ord2f(h->hmeta.mn_ord[d]) : 3.402823466e+38f;
-        h->h_mx[d] = h->h_nvalid ? ord2f(h->hmeta.mx_ord[d]) : -3.402823466e+38f;
+    {
+        int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 512));
+        HIPCHK(h, h->mm_part.ensure(g));
+        hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p);
+        HIPCHK(h, hipGetLastError());
+        std::vector<MinMaxPart> parts(g);
+        HIPCHK(h, hipMemcpyAsync(parts.data(), h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->h_nvalid = 0;
+        for (int d = 0; d < 3; ++d) { h->h_mn[d] = INFINITY; h->h_mx[d] = -INFINITY; }
+        for (auto &r : parts) {
+            h->h_nvalid += r.cnt;
+            for (int d = 0; d < 3; ++d) { h->h_mn[d] = std::min(h->h_mn[d], r.mn[d]); h->h_mx[d] = std::max(h->h_mx[d], r.mx[d]); }
+        }
+        if (!h->h_nvalid) for (int d = 0; d < 3; ++d) { h->h_mn[d] = 3.402823466e+38f; h->h_mx[d] = -3.402823466e+38f; }
     }
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
@@ -315,7 +336,7 @@ void ppp_default_params(ppp_params *p)
     const float he[6] = {-0.764091f, 0.025886f, 0.663790f, -3.1270175f, -0.040124f, -1.6063578f};
     memcpy(p->handeye, he, sizeof(he));
     p->normal_radius = 2.5f;
-    p->smooth_max_sweeps = 200;
+    p->smooth_max_sweeps = 64;
     p->alignment = 0; p->dynamic_adjustment = 0;
 }
 
@@ -341,6 +362,8 @@ int ppp_create(int device_id, ppp_handle *out)
         h->max_lds = std::max(h->max_lds, 160 * 1024); /* CDNA4: one workgroup may own the CU's whole LDS */
     /* kernels with > 64 KiB of dynamic LDS opt in explicitly */
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_slice_kd, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     *out = h;
@@ -403,9 +426,15 @@ int ppp_gen_path_async(ppp_handle h)
     if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
     int rc = enqueue_index(h);
     if (rc) return rc;
-    LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
-           h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
-           h->band_cnt.p);
+    if (h->P.pairing == PPP_PAIR_KD) {
+        LAUNCH(h, "k_slice_kd", k_slice_kd, h->S_cap, 256, slice_kd_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
+               h->px.p, h->lo.p, h->hi.p, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+               h->band_cnt.p);
+    } else {
+        LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+               h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+               h->band_cnt.p);
+    }
     h->gen_done = true;
     h->path_done = false;
     return PPP_OK;
@@ -425,11 +454,15 @@ int ppp_get_path_async(ppp_handle h)
     int gw = std::max(1, (h->W_cap + 63) / 64);
     LAUNCH(h, "k_pose", k_pose, gw, 64, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
-    /* the smoothed list is written twice: wp_smooth stays inspectable, wp_out is finished in place */
-    LAUNCH(h, "k_smooth", k_smooth, 1, 1024, 0, h->meta.p, D, h->sx.p, h->ya.p, h->yb.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
-    int gr = std::max(1, (h->S_cap + 63) / 64);
-    LAUNCH(h, "k_rpy", k_rpy, gr, 64, 0, h->meta.p, D, h->tail.p, h->wp_out.p);
-    LAUNCH(h, "k_final", k_final, gw, 64, 0, h->meta.p, D, h->wp_out.p, h->wp_out.p);
+    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
+    {
+        int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
+        for (int b = 0; b <= nb; ++b)
+            LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
+                   h->snap.p, h->sm_part.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+    }
+    LAUNCH(h, "k_rpy_short", k_rpy_short, 1, 64, 0, h->meta.p, D, h->tail.p, h->wp_out.p);
+    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
     h->path_done = true;
     return PPP_OK;
 }
@@ -740,7 +773,7 @@ int ppp_enable_timing(ppp_handle h, int on)
 {
     if (!h) return PPP_ERR_ARG;
     h->timing = on != 0;
-    for (auto &t : h->timers) t.used = false;
+    for (auto &t : h->timers) t.used = 0;
     return PPP_OK;
 }
 
@@ -754,12 +787,16 @@ int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_
         if (!t.used) continue;
         if (k < cap) {
             float v = 0.f;
-            if (hipEventElapsedTime(&v, t.e0, t.e1) != hipSuccess) v = -1.f;
-            if (ms) ms[k] = v;
+            for (int q = 0; q < t.used; ++q) {
+                float one = 0.f;
+                if (hipEventElapsedTime(&one, t.e0[q], t.e1[q]) == hipSuccess) v += one;
+            }
+            if (ms) ms[k] = v; /* sum over this kernel's launches since the last reset */
             if (names) { strncpy(names + 48 * k, t.name.c_str(), 47); names[48 * k + 47] = 0; }
         }
         ++k;
     }
+    for (auto &t : h->timers) t.used = 0; /* the next pass starts a fresh sum */
     if (n) *n = k;
     return PPP_OK;
 }

@@ -1,0 +1,206 @@
+/*
+ * ppp_io.cpp -- host-side file formats of the reference: PCD v0.7 in, config.txt in,
+ * pathFile out.  No device code; part of libppp_hip.so so the drop-in classes (ppp_host.cpp)
+ * and the bindings share one implementation.
+ */
+#include "../../include/ppp_hip.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+struct Field { std::string name; int size = 4; char type = 'F'; int count = 1; int offset = 0; };
+
+double read_scalar(const unsigned char *p, int size, char type)
+{
+    if (type == 'F') {
+        if (size == 4) { float v; memcpy(&v, p, 4); return v; }
+        if (size == 8) { double v; memcpy(&v, p, 8); return v; }
+    } else if (type == 'I') {
+        if (size == 1) { int8_t v; memcpy(&v, p, 1); return v; }
+        if (size == 2) { int16_t v; memcpy(&v, p, 2); return v; }
+        if (size == 4) { int32_t v; memcpy(&v, p, 4); return v; }
+        if (size == 8) { int64_t v; memcpy(&v, p, 8); return (double)v; }
+    } else if (type == 'U') {
+        if (size == 1) { uint8_t v; memcpy(&v, p, 1); return v; }
+        if (size == 2) { uint16_t v; memcpy(&v, p, 2); return v; }
+        if (size == 4) { uint32_t v; memcpy(&v, p, 4); return v; }
+        if (size == 8) { uint64_t v; memcpy(&v, p, 8); return (double)v; }
+    }
+    return NAN;
+}
+} // namespace
+
+extern "C" {
+
+void ppp_free(void *p) { free(p); }
+
+int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
+{
+    if (!path || !xyz || !n) return PPP_ERR_ARG;
+    *xyz = nullptr; *n = 0;
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return PPP_ERR_IO;
+    std::vector<Field> fields;
+    size_t points = 0, width = 0, height = 1;
+    bool have_points = false;
+    float vp[7] = {0, 0, 0, 1, 0, 0, 0};
+    std::string data_kind, line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "VERSION") continue;
+        if (key == "FIELDS" || key == "COLUMNS") { std::string nm; while (ls >> nm) { Field fd; fd.name = nm; fields.push_back(fd); } }
+        else if (key == "SIZE") { for (auto &fd : fields) ls >> fd.size; }
+        else if (key == "TYPE") { for (auto &fd : fields) ls >> fd.type; }
+        else if (key == "COUNT") { for (auto &fd : fields) ls >> fd.count; }
+        else if (key == "WIDTH") ls >> width;
+        else if (key == "HEIGHT") ls >> height;
+        else if (key == "VIEWPOINT") { for (int i = 0; i < 7; ++i) ls >> vp[i]; }
+        else if (key == "POINTS") { ls >> points; have_points = true; }
+        else if (key == "DATA") { ls >> data_kind; break; }
+    }
+    if (!have_points) points = width * height;
+    if (fields.empty() || data_kind.empty()) return PPP_ERR_IO;
+    int off = 0, ix = -1, iy = -1, iz = -1;
+    for (size_t i = 0; i < fields.size(); ++i) {
+        fields[i].offset = off;
+        off += fields[i].size * std::max(1, fields[i].count);
+        if (fields[i].name == "x") ix = (int)i;
+        if (fields[i].name == "y") iy = (int)i;
+        if (fields[i].name == "z") iz = (int)i;
+    }
+    if (ix < 0 || iy < 0 || iz < 0) return PPP_ERR_IO;
+    float *out = (float *)malloc(sizeof(float) * 3 * std::max<size_t>(points, 1));
+    if (!out) return PPP_ERR_IO;
+    if (data_kind == "ascii") {
+        size_t got = 0;
+        while (got < points && std::getline(f, line)) {
+            if (line.empty()) continue;
+            std::istringstream ls(line);
+            std::string tok;
+            float v[3] = {NAN, NAN, NAN};
+            for (size_t i = 0; i < fields.size(); ++i) {
+                for (int c = 0; c < std::max(1, fields[i].count); ++c) {
+                    if (!(ls >> tok)) break;
+                    if (c == 0 && ((int)i == ix || (int)i == iy || (int)i == iz)) {
+                        float val = (float)strtod(tok.c_str(), nullptr); /* accepts nan / inf */
+                        v[(int)i == ix ? 0 : ((int)i == iy ? 1 : 2)] = val;
+                    }
+                }
+            }
+            memcpy(out + 3 * got, v, 12);
+            ++got;
+        }
+        if (got != points) { free(out); return PPP_ERR_IO; }
+    } else if (data_kind == "binary") {
+        std::vector<unsigned char> rec((size_t)off * points);
+        f.read((char *)rec.data(), (std::streamsize)rec.size());
+        if ((size_t)f.gcount() != rec.size()) { free(out); return PPP_ERR_IO; }
+        for (size_t i = 0; i < points; ++i) {
+            const unsigned char *p = rec.data() + i * off;
+            out[3 * i + 0] = (float)read_scalar(p + fields[ix].offset, fields[ix].size, fields[ix].type);
+            out[3 * i + 1] = (float)read_scalar(p + fields[iy].offset, fields[iy].size, fields[iy].type);
+            out[3 * i + 2] = (float)read_scalar(p + fields[iz].offset, fields[iz].size, fields[iz].type);
+        }
+    } else {
+        free(out);
+        return PPP_ERR_UNSUPPORTED; /* binary_compressed (LZF): SURVEY.md 8f rank 3 */
+    }
+    *xyz = out; *n = points;
+    if (viewpoint) memcpy(viewpoint, vp, sizeof(vp));
+    return PPP_OK;
+}
+
+int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
+{
+    if (!path || (!xyz && n) || stride_floats < 3) return PPP_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return PPP_ERR_IO;
+    const float dvp[7] = {0, 0, 0, 1, 0, 0, 0};
+    const float *vp = viewpoint ? viewpoint : dvp;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n");
+    fprintf(f, "WIDTH %zu\nHEIGHT 1\nVIEWPOINT %g %g %g %g %g %g %g\nPOINTS %zu\nDATA %s\n", n, vp[0], vp[1], vp[2], vp[3], vp[4], vp[5],
+            vp[6], n, binary ? "binary" : "ascii");
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = xyz + i * stride_floats;
+        if (binary) fwrite(p, 4, 3, f);
+        else fprintf(f, "%.9g %.9g %.9g\n", p[0], p[1], p[2]);
+    }
+    fclose(f);
+    return PPP_OK;
+}
+
+void ppp_default_config(ppp_config *c)
+{   /* config.txt:1-13 */
+    memset(c, 0, sizeof(*c));
+    ppp_default_params(&c->params);
+    snprintf(c->path_file, sizeof(c->path_file), "WayPoints_test2.txt");
+    c->depth = 0.01; c->adjust_threshold = 1; c->toolthickness = 10;
+    c->smooth_cloud = 0; c->remove_outlier = 0; c->alignment = 0; c->dynamic_adjustment = 1;
+}
+
+int ppp_read_config(const char *path, ppp_config *c)
+{
+    if (!path || !c) return PPP_ERR_ARG;
+    std::ifstream cFile(path);
+    if (!cFile.is_open()) {
+        std::cerr << "Couldn't open config file for reading.\n"; /* path_slicing_alg.cpp:36 */
+        return PPP_ERR_IO;
+    }
+    std::string line;
+    while (std::getline(cFile, line)) {
+        line.erase(std::remove_if(line.begin(), line.end(), [](unsigned char ch) { return std::isspace(ch); }), line.end());
+        auto pos = line.find("=");
+        if (line.empty() || line[0] == '#' || pos == std::string::npos) continue;
+        std::string name = line.substr(0, pos), value = line.substr(pos + 1);
+        try {
+            if (name == "pathFile") snprintf(c->path_file, sizeof(c->path_file), "%s", value.c_str());
+            else if (name == "Tool_Radius") c->params.tool_radius = std::stod(value);
+            else if (name == "depth") c->depth = std::stod(value);
+            else if (name == "Adjust_Threshold") c->adjust_threshold = std::stod(value);
+            else if (name == "toolthickness") c->toolthickness = std::stod(value);
+            else if (name == "PathResolution") c->params.path_resolution = std::stod(value);
+            else if (name == "RPYresolution") c->params.rpy_resolution = std::stod(value);
+            else if (name == "Endeffectorlength") c->params.ee_length = (float)std::stod(value);
+            else if (name == "Alignment") c->alignment = value == "true";
+            else if (name == "Smooth") c->smooth_cloud = value == "true";
+            else if (name == "ChangeRange") c->params.change_range = value == "true";
+            else if (name == "RemoveOutlier") c->remove_outlier = value == "true";
+            else if (name == "Dynamic_adjustment") c->dynamic_adjustment = value == "true";
+        } catch (...) {
+            return PPP_ERR_ARG; /* std::stod would have thrown out of the reference's constructor */
+        }
+    }
+    return PPP_OK;
+}
+
+int ppp_write_path_file(const char *path, const float *wp6, size_t W)
+{
+    if (!path || (!wp6 && W)) return PPP_ERR_ARG;
+    std::ofstream outputFile(path);
+    if (!outputFile.is_open()) {
+        std::cerr << "Unable to open file: " << path << std::endl;
+        return PPP_ERR_IO;
+    }
+    for (size_t w = 0; w < W; ++w) {
+        for (int i = 0; i < 6; i++) outputFile << wp6[6 * w + i] << " ";
+        outputFile << std::endl;
+    }
+    outputFile.close();
+    return PPP_OK;
+}
+
+} /* extern "C" */

@@ -23,6 +23,7 @@ struct DevMeta {
     int err, err_slice;
     int sweeps, any_short, rpy_oob;
     int node_cursor;
+    int smooth_done;
     int B;
     float slab_x0, slab_invw;
     int api_cnt, api_flag;
@@ -68,23 +69,31 @@ __global__ void k_ingest(const char *raw, size_t stride, int n, int scale, float
     X[i] = x; Y[i] = y; Z[i] = z;
 }
 
-__global__ void k_reset(DevMeta *m)
-{
-    if (threadIdx.x == 0) {
-        for (int d = 0; d < 3; ++d) { m->mn_ord[d] = 0xffffffffu; m->mx_ord[d] = 0u; }
-        m->n_valid = 0; m->S = 0; m->first_kept = 0; m->nkept = 0; m->W = 0;
-        m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
-        m->node_cursor = 0; m->api_cnt = 0; m->api_flag = 0;
-    }
-}
+struct MinMaxPart { float mn[3], mx[3]; int cnt, pad; };
 
-/* a2: pcl::getMinMax3D (path_slicing_alg.cpp:303, path_dynamic_alg.cpp:345) */
+/* a2: pcl::getMinMax3D (path_slicing_alg.cpp:303, path_dynamic_alg.cpp:345).  One partial per
+   workgroup, no atomics (same-address atomics serialise at ~11 ns each on this part). */
 __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
-                                                const float *__restrict__ Z, int n, DevMeta *m)
+                                                const float *__restrict__ Z, int n, MinMaxPart *part)
 {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int n4 = n >> 2;
+    const float4 *X4 = (const float4 *)X, *Y4 = (const float4 *)Y, *Z4 = (const float4 *)Z;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 x = X4[i], y = Y4[i], z = Z4[i];
+        const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w}, zs[4] = {z.x, z.y, z.z, z.w};
+        for (int k = 0; k < 4; ++k) {
+            if (xs[k] == xs[k]) {
+                mn[0] = fminf(mn[0], xs[k]); mx[0] = fmaxf(mx[0], xs[k]);
+                mn[1] = fminf(mn[1], ys[k]); mx[1] = fmaxf(mx[1], ys[k]);
+                mn[2] = fminf(mn[2], zs[k]); mx[2] = fmaxf(mx[2], zs[k]);
+                cnt++;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int i = (n4 << 2) + threadIdx.x;
         float x = X[i];
         if (x == x) {
             float y = Y[i], z = Z[i];
@@ -102,43 +111,72 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
     if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int c = 0;
-        for (int w = 0; w < 4; ++w) c += s_cnt[w];
-        if (c) {
-            for (int d = 0; d < 3; ++d) {
-                float a = INFINITY, b = -INFINITY;
-                for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
-                atomicMin(&m->mn_ord[d], f2ord(a));
-                atomicMax(&m->mx_ord[d], f2ord(b));
-            }
-            atomicAdd(&m->n_valid, c);
+        MinMaxPart r;
+        r.cnt = 0; r.pad = 0;
+        for (int w = 0; w < 4; ++w) r.cnt += s_cnt[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            r.mn[d] = a; r.mx[d] = b;
         }
+        part[blockIdx.x] = r;
     }
 }
 
-/* a3: slice walk + PassThrough limits (rangedX_index(int), path_slicing_alg.cpp:152-158,247) */
-__global__ void k_setup(DevMeta *m, DevParams P, float *px, float *lo, float *hi, int S_cap, int B)
+/* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
+   rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
+__global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
+                                               float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt)
 {
-    if (threadIdx.x != 0) return;
-    for (int d = 0; d < 3; ++d) {
-        if (m->n_valid) { m->mn[d] = ord2f(m->mn_ord[d]); m->mx[d] = ord2f(m->mx_ord[d]); }
-        else { m->mn[d] = 3.402823466e+38f; m->mx[d] = -3.402823466e+38f; } /* getMinMax3D init */
+    __shared__ float s_mn[3][4], s_mx[3][4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_S;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        MinMaxPart r = part[i];
+        cnt += r.cnt;
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], r.mn[d]); mx[d] = fmaxf(mx[d], r.mx[d]); }
     }
-    int S = m->n_valid ? ppp_slice_walk(P.walk, m->mn[0], m->mx[0], P.tool_radius, px, S_cap) : 0;
-    if (S > S_cap) { set_err(m, DERR_CAPACITY, -1); S = S_cap; }
-    for (int s = 0; s < S; ++s) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) slab_cnt[b] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w = 0; w < 4; ++w) c += s_cnt[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            /* getMinMax3D starts from +-FLT_MAX */
+            m->mn[d] = c ? a : 3.402823466e+38f;
+            m->mx[d] = c ? b : -3.402823466e+38f;
+            m->mn_ord[d] = f2ord(m->mn[d]); m->mx_ord[d] = f2ord(m->mx[d]);
+        }
+        m->n_valid = c;
+        m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
+        m->node_cursor = 0; m->api_cnt = 0; m->api_flag = 0; m->smooth_done = -1;
+        int S = c ? ppp_slice_walk(P.walk, m->mn[0], m->mx[0], P.tool_radius, px, S_cap) : 0;
+        if (S > S_cap) { set_err(m, DERR_CAPACITY, -1); S = S_cap; }
+        m->S = S;
+        m->first_kept = P.drop_ends ? 1 : 0;
+        int nk = P.drop_ends ? S - 2 : S;
+        m->nkept = nk < 0 ? 0 : nk;
+        m->B = B;
+        m->slab_x0 = m->mn[0];
+        float range = m->mx[0] - m->mn[0];
+        m->slab_invw = (c && range > 0.f) ? (float)B / range : 0.f;
+        s_S = S;
+    }
+    __syncthreads();
+    const int S = s_S;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
         int position = (int)px[s];
         lo[s] = (float)(-2 + position);
         hi[s] = (float)(2 + position);
     }
-    m->S = S;
-    m->first_kept = P.drop_ends ? 1 : 0;
-    int nk = P.drop_ends ? S - 2 : S;
-    m->nkept = nk < 0 ? 0 : nk;
-    m->B = B;
-    m->slab_x0 = m->mn[0];
-    float range = m->mx[0] - m->mn[0];
-    m->slab_invw = (m->n_valid && range > 0.f) ? (float)B / range : 0.f;
 }
 
 /* ------------------------------------------------------------------ */
@@ -523,6 +561,174 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
     flatten_nodes(L, ncand, node_y + s_base, node_z + s_base, tot, s_scr);
 }
 
+/* ------------------------------------------------------------------ */
+/* kd flavour, fast path (path_slicing_alg.cpp:164-237).  The band is   */
+/* sorted once by (side, y) in LDS; both nearest-neighbour queries of   */
+/* every left point are then windowed scans around a binary search      */
+/* (exact: a candidate is skipped only when dy*dy alone exceeds the     */
+/* best distance).  El order only matters through the map's last-writer */
+/* rule, which is carried as the query's cloud index in the sort key.   */
+/* ------------------------------------------------------------------ */
+struct SliceKdLds {
+    float4 *a4;
+    u64 *keys, *ckeys;
+    float *candz;
+    u16 *cpay;
+};
+__host__ __device__ inline size_t slice_kd_lds_bytes(int capb) { return (size_t)capb * (16 + 8 + 8 + 4 + 2); }
+__device__ inline SliceKdLds carve_slice_kd_lds(char *raw, int capb)
+{
+    SliceKdLds L;
+    L.a4 = (float4 *)raw;
+    L.keys = (u64 *)(L.a4 + capb);
+    L.ckeys = L.keys + capb;
+    L.candz = (float *)(L.ckeys + capb);
+    L.cpay = (u16 *)(L.candz + capb);
+    return L;
+}
+#define KD_Y(k) ((u32)((k) >> 16))
+#define KD_POS(k) ((int)((k) & 0xffffu))
+
+/* nearest point of keys[a..b) (one side, ascending y) to q; ties -> lowest cloud index */
+__device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, int b, const float4 q)
+{
+    const u32 ty = f2ord(q.y);
+    int lo = a, hi = b;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (KD_Y(keys[mid]) < ty) lo = mid + 1; else hi = mid;
+    }
+    float best = INFINITY;
+    int bidx = 0x7fffffff, bj = a;
+    for (int i = lo; i < b; ++i) {
+        const float4 c = a4[KD_POS(keys[i])];
+        float dy = q.y - c.y;
+        if (dy * dy > best) break;
+        float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
+        int id = idx_of(c);
+        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
+    }
+    for (int i = lo - 1; i >= a; --i) {
+        const float4 c = a4[KD_POS(keys[i])];
+        float dy = q.y - c.y;
+        if (dy * dy > best) break;
+        float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
+        int id = idx_of(c);
+        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
+    }
+    return bj;
+}
+
+__global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+                                                  DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
+                                                  const float *__restrict__ hi, int capb, float *node_y, float *node_z,
+                                                  int node_cap, int *node_start, int *node_cnt, int *band_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    __shared__ int s_scr[17];
+    __shared__ int s_n, s_plane, s_ner, s_base, s_m;
+    const int s = blockIdx.x;
+    if (s >= m->S) return;
+    SliceKdLds L = carve_slice_kd_lds(s_raw, capb);
+    const float Px = px[s], blo = lo[s], bhi = hi[s];
+    if (threadIdx.x == 0) { s_n = 0; s_plane = 0; s_ner = 0; s_m = 0; }
+    __syncthreads();
+    /* rangedX_index: the PassThrough band, minus points exactly on the plane (neither side) */
+    {
+        const int b0 = slab_of(m, blo), b1 = slab_of(m, bhi);
+        const int i0 = slab_start[b0], i1 = slab_start[b1 + 1];
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            float4 p = sorted4[i];
+            if (!(p.x < blo || p.x > bhi)) {
+                float distance2plane = (p.x - Px) * 1.f + (p.y - 0.f) * 0.f + (p.z - 0.f) * 0.f;
+                if (distance2plane > 0 || distance2plane < 0) {
+                    int slot = atomicAdd(&s_n, 1);
+                    if (slot < capb) L.a4[slot] = p;
+                } else atomicAdd(&s_plane, 1);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (threadIdx.x == 0) band_cnt[s] = n + s_plane;
+    if (n > capb) {
+        if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
+        return;
+    }
+    const int P = next_pow2(n);
+    int ner = 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        u64 k = ~0ull;
+        if (i < n) {
+            float4 p = L.a4[i];
+            u64 side = (p.x - Px) > 0 ? 1ull : 0ull; /* 1 = El (left, x > Px), 0 = Er */
+            ner += side ? 0 : 1;
+            k = (side << 63) | ((u64)f2ord(p.y) << 16) | (u64)i;
+        }
+        L.keys[i] = k;
+    }
+    ner = wave_sum(ner);
+    if ((threadIdx.x & 63) == 0 && ner) atomicAdd(&s_ner, ner);
+    if (P > 1) bitonic_lds<false>(L.keys, nullptr, P);
+    else __syncthreads();
+    const int nEr = s_ner, nEl = n - nEr;
+    if (nEl == 0 || nEr == 0) {
+        /* empty left side: empty map -> < 3 knots; empty right side: empty FLANN tree */
+        if (threadIdx.x == 0) { set_err(m, DERR_SLICE, s); node_start[s] = 0; node_cnt[s] = 0; }
+        return;
+    }
+    for (int i = threadIdx.x; i < nEl; i += blockDim.x) {
+        const float4 q = L.a4[KD_POS(L.keys[nEr + i])];
+        const int jr = nn_sorted_side(L.keys, L.a4, 0, nEr, q);
+        const float4 R = L.a4[KD_POS(L.keys[jr])];
+        const int jl = nn_sorted_side(L.keys, L.a4, nEr, n, R);
+        const float4 Lp = L.a4[KD_POS(L.keys[jl])];
+        float t = (Px - R.x) / (Lp.x - R.x);
+        float y = R.y + t * (Lp.y - R.y);
+        float z = R.z + t * (Lp.z - R.z);
+        if (y == 0.f) y = 0.f;
+        L.candz[i] = z;
+        L.cpay[i] = (u16)i;
+        L.ckeys[i] = ((u64)f2ord(y) << 32) | (u32)idx_of(q); /* Node[y] = ...: the highest index writes last */
+    }
+    const int P2 = next_pow2(nEl);
+    for (int i = nEl + threadIdx.x; i < P2; i += blockDim.x) { L.ckeys[i] = ~0ull; L.cpay[i] = 0; }
+    if (P2 > 1) bitonic_lds<true>(L.ckeys, L.cpay, P2);
+    else __syncthreads();
+    int mcount = 0;
+    for (int j = threadIdx.x; j < nEl; j += blockDim.x)
+        mcount += (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 32) != (u32)(L.ckeys[j] >> 32));
+    int tot;
+    block_exscan(mcount, s_scr, &tot);
+    if (threadIdx.x == 0) {
+        int base = atomicAdd(&m->node_cursor, tot);
+        if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
+        s_base = base;
+        node_start[s] = base;
+        node_cnt[s] = tot;
+        if (tot < 3) set_err(m, DERR_SLICE, s);
+    }
+    __syncthreads();
+    if (node_cnt[s] == 0) return;
+    float *oy = node_y + s_base, *oz = node_z + s_base;
+    for (int base = 0; base < nEl; base += blockDim.x) {
+        int j = base + threadIdx.x;
+        int keep = 0;
+        u64 k = 0;
+        if (j < nEl) {
+            k = L.ckeys[j];
+            keep = (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 32) != (u32)(k >> 32));
+        }
+        int t2;
+        int pre = block_exscan(keep, s_scr, &t2);
+        int o = s_m;
+        if (keep) { oy[o + pre] = ord2f((u32)(k >> 32)); oz[o + pre] = L.candz[L.cpay[j]]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_m = o + t2;
+        __syncthreads();
+    }
+}
+
 /* API mirrors: rangedX_index(position) and insert_point(indices, plane) on one workgroup */
 __global__ void __launch_bounds__(256) k_band_indices(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                       DevMeta *m, float lo, float hi, int capb, int *out, int out_cap)
@@ -856,85 +1062,181 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 
 /* ------------------------------------------------------------------ */
 /* a13: postion_smooth (path_translation_alg.cpp:114-141).              */
-/* Gauss-Seidel sweep  y_i' = fl32( y_i + 0.65(x_i - y_i) + 0.35(y_{i+1} + y'_{i-1} - 2 y_i) ):   */
-/* every thread owns a contiguous chunk and re-derives its carry-in     */
-/* y'_{c0-1} by running the same float-rounded recurrence over a 48     */
-/* element run-up (the seed error decays by 0.35 per step, 0.35^48 <    */
-/* 1e-21: far below half an ulp, so the values equal the sequential     */
-/* sweep's).  Stop rule: DESIGN.md B.12.                                */
+/* One Gauss-Seidel sweep of the reference is the recurrence             */
+/*   y_i' = fl32( y_i + 0.65 (x_i - y_i) + 0.35 (y_{i+1} + y'_{i-1} - 2 y_i) )                   */
+/*        = fl32( c_i + 0.35 y'_{i-1} ),  c_i = y_i + 0.65 (x_i - y_i) + 0.35 (y_{i+1} - 2 y_i)  */
+/* where c_i only needs the previous sweep.  The serial chain is issue   */
+/* bound (12 f64 instructions per step), so the kernel evaluates it as   */
+/* a filter: c is computed for every element in parallel, then each      */
+/* thread runs  acc = c_i + 0.35 acc  (one FMA per step) over a run-up   */
+/* of SM_D elements -- the seed error decays by 0.35 per step, 0.35^17   */
+/* of a <= mm-sized seed is < 1e-10 m -- and over its own SM_L elements. */
+/* Difference from the reference: the chain carries the unrounded double */
+/* instead of the float-rounded y'_{i-1}; that perturbs each sweep by    */
+/* < 1 float ulp (6e-8 m) and the sweeps contract by ~0.5, so the        */
+/* smoothed list differs from the sequential one by ~1e-7 m (tolerance   */
+/* 1e-4 m; tests/test_gpu_parity.py bounds it at 1e-6 m).                */
+/* A workgroup keeps a tile + halo in LDS for SM_K sweeps per launch and */
+/* snapshots its owned range after every sweep; the per-sweep sums of    */
+/* |delta| that drive the stop rule are written per     */
+/* workgroup and summed in a fixed order by the next launch, which       */
+/* either continues from the last snapshot or emits the snapshot of the  */
+/* stop sweep.                                                           */
 /* ------------------------------------------------------------------ */
-#define SMOOTH_RUNUP 48
-__global__ void __launch_bounds__(1024) k_smooth(DevMeta *m, DevParams P, const float *__restrict__ sx, float *ya,
-                                                 float *yb, const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out)
+#define SM_K 16
+#define SM_D 16
+#define SM_L 3
+#define SM_T 512
+#define SM_M (SM_T * SM_L)
+#define SM_HB ((SM_D + 1) * SM_K + 1)
+#define SM_OWN (SM_M - SM_HB - SM_K)
+#define SM_MAXS 512
+#define SM_LDS_BYTES (3 * SM_M * (8 + 4 + 4 + 4))
+
+__host__ __device__ inline int smooth_tiles(int W) { return W > 2 ? (W - 2 + SM_OWN - 1) / SM_OWN : 1; }
+/* snapshot set q (0/1), level k (1..SM_K), coordinate j: float[W_cap] */
+__host__ __device__ inline size_t smooth_snap_off(int q, int k, int j, int W_cap)
 {
-    __shared__ double s_part[16];
-    __shared__ double s_change;
+    return ((size_t)(q * SM_K + (k - 1)) * 3 + j) * (size_t)W_cap;
+}
+
+__global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, int b, int ntiles_cap, int W_cap,
+                                                       const float *__restrict__ sx, float *snap, double *part,
+                                                       const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    double (*s_c)[SM_M] = (double (*)[SM_M])s_raw;
+    float (*s_x)[SM_M] = (float (*)[SM_M])(s_raw + 3 * SM_M * 8);
+    float (*s_a)[SM_M] = s_x + 3;
+    float (*s_b)[SM_M] = s_a + 3;
+    __shared__ double s_change[SM_MAXS + 1];
+    __shared__ double s_red[2][SM_T / 64]; /* double-buffered by sweep parity */
+    __shared__ int s_kstar;
     const int W = m->W;
     if (m->err || W == 0) return;
+    if (m->smooth_done >= 0 && m->smooth_done < b) return; /* an earlier launch emitted the list */
+    const int inner = W - 2;
+    const int ntiles = smooth_tiles(W);
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
     const double weight_data = 0.65, weight_smooth = 1 - weight_data, tolerance = 0.00001;
-    const int per_dim = blockDim.x / 3;           /* 341 threads per coordinate */
-    const int j = threadIdx.x / per_dim;          /* coordinate (3 = idle) */
-    const int tj = threadIdx.x - j * per_dim;
-    const int inner = W - 2;                       /* elements 1 .. W-2 move */
-    int c0 = 0, c1 = 0;
-    if (j < 3 && inner > 0) {
-        int L = (inner + per_dim - 1) / per_dim;
-        c0 = 1 + tj * L;
-        c1 = min(W - 1, c0 + L);
-        if (c0 > W - 1) c0 = c1 = 0;
+    const int t0 = 1 + tile * SM_OWN;
+    const int t1 = min(W - 1, t0 + SM_OWN);
+    const int w0 = tile == 0 ? 0 : t0, w1 = (t1 == W - 1 || W <= 2) ? W : t1; /* border tiles carry the fixed ends */
+
+    /* ---- emit or continue?  (identical decision in every workgroup) ---- */
+    int emit_level = -1; /* >= 0: emit; 0 = the unsmoothed list */
+    int total_sweeps = 0;
+    if (!P.smooth || inner <= 0) {
+        if (b != 0) return;
+        emit_level = 0; total_sweeps = P.smooth ? 1 : 0;
+    } else if (b > 0) {
+        const int done = SM_K * b;
+        for (int k = 1 + threadIdx.x; k <= done; k += blockDim.x) {
+            double c = 0;
+            const double *pp = part + (size_t)k * ntiles_cap;
+            for (int q = 0; q < ntiles; ++q) c += pp[q];
+            s_change[k] = c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int ks = 0;
+            for (int k = 1; k <= done && !ks; ++k) {
+                double c = s_change[k];
+                bool stop = !(c >= tolerance);
+                if (k >= 2 && c >= 0.9 * s_change[k - 1]) stop = true;
+                if (k >= P.smooth_max_sweeps) stop = true;
+                if (stop) ks = k;
+            }
+            s_kstar = ks;
+        }
+        __syncthreads();
+        if (s_kstar) { emit_level = s_kstar - SM_K * (b - 1); total_sweeps = s_kstar; }
     }
-    for (int i = threadIdx.x; i < 3 * W; i += blockDim.x) { ya[i] = sx[i]; yb[i] = sx[i]; }
+    if (emit_level >= 0) {
+        for (int j = 0; j < 3; ++j) {
+            const float *S = emit_level == 0 ? sx + (size_t)j * W : snap + smooth_snap_off((b - 1) & 1, emit_level, j, W_cap);
+            for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) {
+                float v = S[g];
+                float r = wp_pre[6 * (size_t)g + 3 + j];
+                wp_smooth[6 * (size_t)g + j] = v; wp_out[6 * (size_t)g + j] = v;
+                wp_smooth[6 * (size_t)g + 3 + j] = r; wp_out[6 * (size_t)g + 3 + j] = r;
+            }
+        }
+        if (tile == 0 && threadIdx.x == 0) { m->sweeps = total_sweeps; m->smooth_done = b; }
+        return;
+    }
+
+    /* ---- SM_K more sweeps from the state after SM_K*b sweeps ---- */
+    const int base = t0 - SM_HB; /* LDS slot l <-> list index base + l */
+    for (int j = 0; j < 3; ++j) {
+        const float *X = sx + (size_t)j * W;
+        const float *S = b == 0 ? X : snap + smooth_snap_off((b - 1) & 1, SM_K, j, W_cap);
+        for (int l = threadIdx.x; l < SM_M; l += blockDim.x) {
+            int g = base + l;
+            float xv = 0.f, yv = 0.f;
+            if (g >= 0 && g < W) { xv = X[g]; yv = S[g]; }
+            s_x[j][l] = xv; s_a[j][l] = yv; s_b[j][l] = yv;
+        }
+    }
     __syncthreads();
-    float *cur = ya, *nxt = yb;
-    int sweeps = 0;
-    double prev_change = INFINITY;
-    if (P.smooth && inner > 0) {
-        while (true) {
-            double change = 0;
-            if (c1 > c0) {
-                const float *X = sx + (size_t)j * W;
-                const float *C = cur + (size_t)j * W;
-                float *Nn = nxt + (size_t)j * W;
-                int ws = max(1, c0 - SMOOTH_RUNUP);
-                double y_prev = (double)C[ws - 1]; /* exact when ws == 1 (fixed end point) */
-                for (int i = ws; i < c1; ++i) {
-                    double x_i = (double)X[i], y_i = (double)C[i], y_next = (double)C[i + 1];
-                    double y_i_saved = y_i;
-                    y_i += (weight_data * (x_i - y_i) + weight_smooth * (y_next + y_prev - 2 * y_i));
-                    float stored = (float)y_i;
-                    if (i >= c0) { Nn[i] = stored; change += fabs(y_i - y_i_saved); }
-                    y_prev = (double)stored;
+    float (*cur)[SM_M] = s_a, (*nxt)[SM_M] = s_b;
+    const int l0 = threadIdx.x * SM_L; /* this thread's LDS slots l0 .. l0+SM_L-1 */
+    for (int k = 1; k <= SM_K; ++k) {
+        /* level k is exact on [lo_k, hi_k); the fixed end points 0 and W-1 are exact on every level */
+        const int lo_k = max(1, base + 1 + (SM_D + 1) * k), lo_km1 = max(1, base + 1 + (SM_D + 1) * (k - 1));
+        const int hi_k = min(W - 1, base + SM_M - k);
+        /* c_i from level k-1, for every slot whose neighbours exist */
+#pragma unroll
+        for (int q = 0; q < SM_L; ++q) {
+            const int l = l0 + q, i = base + l;
+            if (i >= lo_km1 && i < hi_k) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double x_i = (double)s_x[j][l], y_i = (double)cur[j][l], y_next = (double)cur[j][l + 1];
+                    s_c[j][l] = y_i + (weight_data * (x_i - y_i) + weight_smooth * (y_next - 2 * y_i));
                 }
             }
-            change = wave_sum(change);
-            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = change;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double c = 0;
-                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) c += s_part[w];
-                s_change = c;
+        }
+        lds_barrier();
+        const int a = max(base + l0, lo_k), e = min(base + l0 + SM_L, hi_k);
+        double change = 0;
+        if (a < e) {
+            const int rs = max(a - SM_D, lo_km1);
+            double acc[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[j] = (double)cur[j][rs - 1 - base];
+            for (int i = rs; i < a; ++i) {
+                const int l = i - base;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[j] = s_c[j][l] + weight_smooth * acc[j];
             }
-            __syncthreads();
-            change = s_change;
-            ++sweeps;
-            float *t = cur; cur = nxt; nxt = t;
-            /* end points never move: keep both buffers consistent */
-            bool stop = !(change >= tolerance);
-            if (sweeps >= 2 && change >= 0.9 * prev_change) stop = true;
-            if (sweeps >= P.smooth_max_sweeps) stop = true;
-            prev_change = change;
-            __syncthreads();
-            if (stop) break;
+            for (int i = a; i < e; ++i) {
+                const int l = i - base;
+                const bool owned = i >= t0 && i < t1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[j] = s_c[j][l] + weight_smooth * acc[j];
+                    nxt[j][l] = (float)acc[j];
+                    if (owned) change += fabs(acc[j] - (double)cur[j][l]);
+                }
+            }
+        }
+        change = wave_sum(change);
+        if ((threadIdx.x & 63) == 0) s_red[k & 1][threadIdx.x >> 6] = change;
+        lds_barrier(); /* also publishes nxt; the snapshot stores below stay in flight */
+        if (threadIdx.x == 0) {
+            double c = 0;
+            for (int w = 0; w < SM_T / 64; ++w) c += s_red[k & 1][w];
+            part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
+        }
+        float (*t)[SM_M] = cur; cur = nxt; nxt = t;
+        /* snapshot of level k (owned range; the last level is the next launch's input) */
+        for (int j = 0; j < 3; ++j) {
+            float *D = snap + smooth_snap_off(b & 1, k, j, W_cap);
+            for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) D[g] = cur[j][g - base];
         }
     }
-    for (int w = threadIdx.x; w < W; w += blockDim.x) {
-        for (int d = 0; d < 6; ++d) {
-            float v = d < 3 ? cur[(size_t)d * W + w] : wp_pre[6 * (size_t)w + d];
-            wp_smooth[6 * (size_t)w + d] = v;
-            wp_out[6 * (size_t)w + d] = v;
-        }
-    }
-    if (threadIdx.x == 0) m->sweeps = (P.smooth && inner <= 0) ? 1 : sweeps;
 }
 
 /* ------------------------------------------------------------------ */
@@ -969,33 +1271,63 @@ __device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int
             for (int D = 3; D < 6; ++D) W6[6 * (size_t)i + D] = W6[6 * (size_t)preId + D];
 }
 
-__global__ void k_rpy(DevMeta *m, DevParams P, const int *__restrict__ tail, float *W6)
+/* Only when a slice is shorter than RPYres+1 waypoints do the reference's segments overlap
+   (App. B.6): then, and only then, the list is walked in order by one thread, literally. */
+__global__ void k_rpy_short(DevMeta *m, DevParams P, const int *__restrict__ tail, float *W6)
 {
     const int W = m->W, nk = m->nkept;
-    if (m->err || W == 0 || !(P.rpy_resolution > 2)) return;
-    const int res = (int)P.rpy_resolution;
-    if (m->any_short) {
-        /* a short slice makes segments overlap (App. B.6): walk them in order, literally */
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            int preId = 0;
-            for (int id = 0; id < nk; ++id) { rpy_segment(W6, W, preId, tail[id], res, m); preId = tail[id] + 1; }
-        }
-        return;
+    if (m->err || W == 0 || !(P.rpy_resolution > 2) || !m->any_short) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int res = (int)P.rpy_resolution;
+        int preId = 0;
+        for (int id = 0; id < nk; ++id) { rpy_segment(W6, W, preId, tail[id], res, m); preId = tail[id] + 1; }
     }
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nk) return;
-    int preId = id == 0 ? 0 : tail[id - 1] + 1;
-    rpy_segment(W6, W, preId, tail[id], res, m);
 }
 
-/* a14 tail (limit to -180..180) + a15 TransFlangeposition (path_translation_alg.cpp:81-112) */
-__global__ void k_final(const DevMeta *m, DevParams P, const float *__restrict__ W6, float *out)
+/* reduceRPY (path_translation_alg.cpp:37-86) per waypoint -- the key waypoints (every RPYres-th
+   of a slice) are never modified, so every interval is independent --, then the -180..180 limit
+   (:81-85) and TransFlangeposition (:89-112).  src: smoothed list; out: final WayPointsList. */
+__global__ void __launch_bounds__(64) k_finish(const DevMeta *m, DevParams P, const int *__restrict__ tail,
+                                               const float *__restrict__ src, float *out)
 {
+    const int W = m->W;
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m->err || w >= m->W) return;
+    if (m->err || w >= W) return;
     float p[6];
-    for (int d = 0; d < 6; ++d) p[d] = W6[6 * (size_t)w + d];
-    if (P.rpy_resolution > 2)
+    for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)w + d]; /* k_smooth_batch / k_rpy_short wrote it */
+    const bool reduce = P.rpy_resolution > 2;
+    if (reduce && !m->any_short) {
+        const int res = (int)P.rpy_resolution;
+        /* segment of w: first tail >= w */
+        int lo = 0, hi = m->nkept - 1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (tail[mid] < w) lo = mid + 1; else hi = mid; }
+        const int tl = tail[lo], p0 = lo == 0 ? 0 : tail[lo - 1] + 1;
+        const int nfull = (tl - p0) / res;       /* passes of the do-while */
+        const int lastkey = p0 + nfull * res;
+        const int r = w - p0;
+        if (w > lastkey) {
+            for (int D = 3; D < 6; ++D) p[D] = src[6 * (size_t)lastkey + D];
+        } else if (r % res != 0) {
+            const int pre = p0 + (r / res) * res, last = pre + res, wi = w - pre;
+            for (int D = 3; D < 6; D++) {
+                float a = src[6 * (size_t)last + D], bb = src[6 * (size_t)pre + D];
+                double dr;
+                if (a * bb >= 0) {
+                    dr = (double)((a - bb) / res);
+                } else {
+                    double no1, no2;
+                    if (a < 0) { no2 = bb; no1 = 2 * M_PI + a; }
+                    else { no2 = 2 * M_PI + bb; no1 = a; }
+                    dr = (double)fabsf(a - bb) < fabs(no1 - no2) ? (double)(a - bb) : (no1 - no2);
+                    dr /= res;
+                }
+                float v = bb;
+                for (int q = 1; q <= wi; ++q) v = (float)(dr + v); /* the reference accumulates in float */
+                p[D] = v;
+            }
+        }
+    }
+    if (reduce)
         for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
     float R[3][3];
     rot_zyx(p[3], p[4], p[5], R);

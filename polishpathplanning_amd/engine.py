@@ -26,6 +26,10 @@ class PPPError(RuntimeError):
         self.code = code
 
 
+class Config(C.Structure):
+    pass  # fields assigned after Params
+
+
 class Params(C.Structure):
     _fields_ = [
         ("tool_radius", C.c_double),
@@ -46,6 +50,18 @@ class Params(C.Structure):
     ]
 
 
+Config._fields_ = [
+    ("params", Params),
+    ("path_file", C.c_char * 512),
+    ("depth", C.c_double),
+    ("adjust_threshold", C.c_double),
+    ("toolthickness", C.c_double),
+    ("smooth_cloud", C.c_int),
+    ("remove_outlier", C.c_int),
+    ("alignment", C.c_int),
+    ("dynamic_adjustment", C.c_int),
+]
+
 EXPORTS = [
     "ppp_default_params", "ppp_create", "ppp_destroy", "ppp_last_error", "ppp_version", "ppp_set_params",
     "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async",
@@ -53,7 +69,8 @@ EXPORTS = [
     "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
-    "ppp_get_kernel_times",
+    "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
+    "ppp_write_path_file",
 ]
 
 
@@ -114,6 +131,14 @@ def lib():
         L.ppp_smooth_sweeps.argtypes = [vp, ip]
         L.ppp_enable_timing.argtypes = [vp, C.c_int]
         L.ppp_get_kernel_times.argtypes = [vp, C.c_char_p, fp, sz, szp]
+        L.ppp_load_pcd.argtypes = [C.c_char_p, C.POINTER(fp), szp, fp]
+        L.ppp_save_pcd.argtypes = [C.c_char_p, fp, sz, sz, fp, C.c_int]
+        L.ppp_free.argtypes = [vp]
+        L.ppp_free.restype = None
+        L.ppp_default_config.argtypes = [C.POINTER(Config)]
+        L.ppp_default_config.restype = None
+        L.ppp_read_config.argtypes = [C.c_char_p, C.POINTER(Config)]
+        L.ppp_write_path_file.argtypes = [C.c_char_p, fp, sz]
         _lib = L
     return _lib
 
@@ -134,6 +159,43 @@ def default_params(**kw):
 
 def _f(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+# ---- host-side file formats (no GPU needed) ----
+def load_pcd(path):
+    """pcl::io::loadPCDFile: returns (xyz float32 [n,3], viewpoint float32 [7])."""
+    L = lib()
+    p = C.POINTER(C.c_float)()
+    n = C.c_size_t()
+    vp = np.zeros(7, np.float32)
+    rc = L.ppp_load_pcd(path.encode(), C.byref(p), C.byref(n), _f(vp))
+    if rc:
+        raise PPPError(rc, "cannot read PCD %s" % path)
+    xyz = np.ctypeslib.as_array(p, shape=(max(n.value, 1) * 3,))[: n.value * 3].reshape(-1, 3).copy()
+    L.ppp_free(p)
+    return xyz, vp
+
+
+def save_pcd(path, xyz, viewpoint=None, binary=True):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+    rc = lib().ppp_save_pcd(path.encode(), _f(xyz), xyz.shape[0], xyz.shape[1], vp, 1 if binary else 0)
+    if rc:
+        raise PPPError(rc, "cannot write PCD %s" % path)
+
+
+def read_config(path):
+    c = Config()
+    lib().ppp_default_config(C.byref(c))
+    rc = lib().ppp_read_config(path.encode(), C.byref(c))
+    return rc, c
+
+
+def write_path_file(path, wp6):
+    wp6 = np.ascontiguousarray(wp6, np.float32)
+    rc = lib().ppp_write_path_file(path.encode(), _f(wp6), wp6.shape[0])
+    if rc:
+        raise PPPError(rc, "cannot write %s" % path)
 
 
 def _d(a):

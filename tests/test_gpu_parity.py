@@ -23,7 +23,8 @@ def run_pair(engine_mod, oracle_mod, pts, **params):
     return e, o
 
 
-def assert_full_parity(engine_mod, e, o, every_slice=True):
+def assert_full_parity(engine_mod, e, o, every_slice=True, unit=1.0):
+    """unit: size of a metre in the waypoint list's length unit (1000 when ChangeRange is off)."""
     So = o.gen_path(); S = e.gen_path()
     assert S == So
     Wo = o.get_path(); W = e.get_path()
@@ -46,12 +47,12 @@ def assert_full_parity(engine_mod, e, o, every_slice=True):
     ang = np.arctan2(np.linalg.norm(np.cross(n[:, :3], on[:, :3]), axis=1), np.sum(n[:, :3] * on[:, :3], axis=1))
     assert ang.max() < 1e-4
     pre, opre = e.stage(engine_mod.STAGE_WP_PRESMOOTH), o.waypoints_presmooth()
-    assert np.abs(pre[:, :3] - opre[:, :3]).max() <= 1e-6
+    assert np.abs(pre[:, :3] - opre[:, :3]).max() <= 1e-6 * unit
     sm, osm = e.stage(engine_mod.STAGE_WP_SMOOTHED), o.waypoints_smoothed()
-    assert np.abs(sm[:, :3] - osm[:, :3]).max() <= 1e-6
+    assert np.abs(sm[:, :3] - osm[:, :3]).max() <= 1e-6 * unit  # filter form of the sweep: ~1e-7 m (ppp_kernels.h a13)
     assert abs(e.smooth_sweeps() - o.smooth_sweeps()) <= 1
     wp, owp = e.waypoints(), o.waypoints()
-    assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
+    assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M * unit
     d = np.abs(wp[:, 3:] - owp[:, 3:])
     assert np.minimum(d, np.abs(d - 2 * np.pi)).max() <= TOL_RAD
 
@@ -92,7 +93,7 @@ def test_not_change_range(engine_mod, oracle_mod):
     pts, cfg = synth.make_config("tiny_5k")
     mm = (pts * 1000).astype(np.float32)
     e, o = run_pair(engine_mod, oracle_mod, mm, tool_radius=6.0, change_range=0)
-    assert_full_parity(engine_mod, e, o)
+    assert_full_parity(engine_mod, e, o, unit=1000.0)  # the list is in millimetres here
 
 
 def test_rerun_is_bitwise_reproducible(engine_mod):
@@ -287,3 +288,33 @@ def test_two_handles_interleaved(engine_mod, oracle_mod):
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path):
+    """The drop-in C++ classes (include/Path_Generate_Algorithm.h) driven like src/connect.cpp:
+    PCD in, pathFile out."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "connect1", "main"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("small_40k")
+    pcd = str(tmp_path / "workpiece.pcd")
+    engine_mod.save_pcd(pcd, pts, binary=True)
+    out = str(tmp_path / "WayPoints.txt")
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n" % out)
+    env = dict(os.environ, PPP_CONFIG=str(conf))
+    for exe, walk in (("connect", 1), ("connect1", 2)):
+        if os.path.exists(out):
+            os.remove(out)
+        r = subprocess.run([os.path.join(root, "examples", exe), pcd], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "!!!!! GOT PATH !!!!!" in r.stdout
+        got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
+        o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk)
+        o.gen_path(); o.get_path()
+        want = o.waypoints()
+        assert got.shape == want.shape
+        assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 + 5e-6 * np.abs(want[:, :3]).max()  # 6 significant digits in the file
+    r = subprocess.run([os.path.join(root, "examples", "main"), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0 and "number of paths" in r.stdout

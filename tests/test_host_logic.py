@@ -89,3 +89,71 @@ def test_gather_without_process_group():
     from polishpathplanning_amd.robot_path import gather_robot_path
     t = torch.ones((3, 6))
     assert gather_robot_path(t)[0] is t
+
+
+# ---------------- file formats of the reference (host side of the C ABI) ----------------
+@pytest.mark.parametrize("binary", [True, False])
+def test_pcd_roundtrip(engine_mod, tmp_path, binary):
+    from polishpathplanning_amd import synth
+    pts, _ = synth.make_config("tiny_5k")
+    pts = pts.copy()
+    pts[3] = [np.nan, np.nan, np.nan]
+    p = str(tmp_path / "c.pcd")
+    engine_mod.save_pcd(p, pts, viewpoint=[0.1, 0.2, 0.3, 1, 0, 0, 0], binary=binary)
+    back, vp = engine_mod.load_pcd(p)
+    assert back.shape == pts.shape and np.array_equal(back[~np.isnan(back)], pts[~np.isnan(pts)])
+    assert np.isnan(back[3]).all() and np.allclose(vp, [0.1, 0.2, 0.3, 1, 0, 0, 0])
+
+
+def test_pcd_with_extra_fields_and_double_xyz(engine_mod, tmp_path):
+    # FIELDS in any order / F8 coordinates / rgb packed as U4, as PCL writes them
+    n = 5
+    rec = np.zeros(n, dtype=[("rgb", "<u4"), ("x", "<f8"), ("normal_x", "<f4"), ("y", "<f8"), ("z", "<f8")])
+    rec["x"] = np.arange(n) * 0.001; rec["y"] = 0.5; rec["z"] = 1.5 + np.arange(n); rec["rgb"] = 0xffffff
+    p = tmp_path / "d.pcd"
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS rgb x normal_x y z\nSIZE 4 8 4 8 8\nTYPE U F F F F\nCOUNT 1 1 1 1 1\n"
+           "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n))
+    p.write_bytes(hdr.encode() + rec.tobytes())
+    xyz, vp = engine_mod.load_pcd(str(p))
+    assert np.allclose(xyz[:, 0], rec["x"]) and np.allclose(xyz[:, 1], 0.5) and np.allclose(xyz[:, 2], rec["z"])
+
+
+def test_pcd_errors(engine_mod, tmp_path):
+    with pytest.raises(engine_mod.PPPError) as ei:
+        engine_mod.load_pcd(str(tmp_path / "missing.pcd"))
+    assert ei.value.code == engine_mod.ERR_IO
+    p = tmp_path / "z.pcd"
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n")
+    with pytest.raises(engine_mod.PPPError) as ei:
+        engine_mod.load_pcd(str(p))
+    assert ei.value.code == engine_mod.ERR_UNSUPPORTED
+
+
+def test_read_config_follows_the_reference_parser(engine_mod, tmp_path):
+    ref = "/root/reference/config.txt"
+    if os.path.exists(ref):  # only in the build container; the same text is restated below
+        rc, c = engine_mod.read_config(ref)
+        assert rc == 0 and c.params.tool_radius == 12 and c.path_file == b"WayPoints_test2.txt" and c.dynamic_adjustment == 1
+    p = tmp_path / "config.txt"
+    p.write_text("# comment\nTool_Radius = 6\npathFile = out dir/Way Points.txt\nEnd effector length = 0.25\n"
+                 "ChangeRange = True\nDynamic_adjustment = false\nPathResolution=3.5\nbogus line\nRPYresolution = 9\nunknown = 1\n")
+    rc, c = engine_mod.read_config(str(p))
+    assert rc == 0
+    assert c.params.tool_radius == 6 and c.params.path_resolution == 3.5 and c.params.rpy_resolution == 9
+    assert abs(c.params.ee_length - 0.25) < 1e-7
+    assert c.path_file == b"outdir/WayPoints.txt"   # every blank is stripped (path_slicing_alg.cpp:42)
+    assert c.params.change_range == 0                # booleans are exactly "true" (:60)
+    assert c.dynamic_adjustment == 0 and c.depth == 0.01  # absent keys keep config.txt's values
+    rc, c = engine_mod.read_config(str(tmp_path / "nope.txt"))
+    assert rc == engine_mod.ERR_IO and c.params.tool_radius == 12
+
+
+def test_write_path_file_c_abi_matches_python_writer(engine_mod, tmp_path):
+    from polishpathplanning_amd.robot_path import write_path_file
+    wp = np.random.default_rng(0).normal(size=(50, 6)).astype(np.float32) * [1, 1, 1, 3, 3, 3]
+    wp[0] = [0.5, -0.25, 1.0, 3.14159274, -1e-5, 123456.789]
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    engine_mod.write_path_file(a, wp)
+    write_path_file(b, wp)
+    assert open(a).read() == open(b).read()
+    assert open(a).readline() == "0.5 -0.25 1 3.14159 -1e-05 123457 \n"
