@@ -176,6 +176,156 @@ __device__ inline void bitonic_lds(u64 *k, u16 *pl, int P)
     __syncthreads();
 }
 
+/* ---------------------------------------------------------------------- */
+/* Block sort of 256*E 64-bit keys held in registers (blocked layout: thread */
+/* t owns elements t*E .. t*E+E-1), ascending, for a 256-thread workgroup.   */
+/* Bitonic network; a compare-exchange runs in registers when the partner    */
+/* is in the same thread, through wave shuffles when it is in the same wave, */
+/* and through LDS only for the three cross-wave strides -- so the whole     */
+/* sort has 3 barriers-pairs instead of one per step.                        */
+/* ---------------------------------------------------------------------- */
+template <int E, int S>
+__device__ inline void sort_reg_stride(u64 (&k)[E], int size, int base_i)
+{
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if ((r & S) == 0) {
+            const bool up = ((base_i + r) & size) == 0;
+            u64 a = k[r], b = k[r | S];
+            bool sw = (a > b) == up;
+            k[r] = sw ? b : a;
+            k[r | S] = sw ? a : b;
+        }
+    }
+}
+/* all in-register strides below FROM (a power of two <= E/2), down to 1 */
+template <int E, int FROM>
+__device__ inline void sort_reg_tail(u64 (&k)[E], int size, int base_i)
+{
+    if constexpr (FROM >= 1) {
+        sort_reg_stride<E, FROM>(k, size, base_i);
+        sort_reg_tail<E, FROM / 2>(k, size, base_i);
+    }
+}
+template <int E, int SIZE>
+__device__ inline void sort_reg_phase(u64 (&k)[E], int base_i)
+{   /* merge sizes 2 .. E that live entirely in one thread */
+    if constexpr (SIZE <= E) {
+        sort_reg_tail<E, SIZE / 2>(k, SIZE, base_i);
+        sort_reg_phase<E, SIZE * 2>(k, base_i);
+    }
+}
+template <int E>
+__device__ inline void block_sort_regs(u64 (&k)[E], u64 *lds /* 256*E keys of scratch */)
+{
+    const int t = threadIdx.x;
+    const int base_i = t * E;
+    constexpr int P = 256 * E;
+    sort_reg_phase<E, 2>(k, base_i);
+    for (int size = 2 * E; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride >= E; stride >>= 1) {
+            if (stride >= 64 * E) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) lds[base_i + r] = k[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int i = base_i + r;
+                    u64 o = lds[i ^ stride];
+                    const bool keep_min = (((i & stride) == 0) == ((i & size) == 0));
+                    u64 a = k[r];
+                    k[r] = keep_min ? (a < o ? a : o) : (a > o ? a : o);
+                }
+            } else {
+                const int lx = stride / E;
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int i = base_i + r;
+                    u64 a = k[r];
+                    u64 o = __shfl_xor(a, lx, 64);
+                    const bool keep_min = (((i & stride) == 0) == ((i & size) == 0));
+                    k[r] = keep_min ? (a < o ? a : o) : (a > o ? a : o);
+                }
+            }
+        }
+        sort_reg_tail<E, E / 2>(k, size, base_i);
+    }
+}
+
+/* Sorts keys[0..n) (LDS, n <= 4096) ascending with a 256-thread workgroup; on return the
+   keys are back in LDS.  Picks the smallest register tile that covers n. */
+template <int E>
+__device__ inline void block_sort_lds_e(u64 *keys, int n)
+{
+    u64 k[E];
+    const int base_i = threadIdx.x * E;
+#pragma unroll
+    for (int r = 0; r < E; ++r) k[r] = (base_i + r) < n ? keys[base_i + r] : ~0ull;
+    block_sort_regs<E>(k, keys);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[base_i + r] = k[r]; /* slots >= n hold the ~0 padding */
+    __syncthreads();
+}
+/* keys must have room for 256 * E entries, E = max(1, next_pow2(n) / 256) */
+__device__ inline void block_sort_lds(u64 *keys, int n)
+{
+    if (n <= 256) block_sort_lds_e<1>(keys, n);
+    else if (n <= 512) block_sort_lds_e<2>(keys, n);
+    else if (n <= 1024) block_sort_lds_e<4>(keys, n);
+    else if (n <= 2048) block_sort_lds_e<8>(keys, n);
+    else block_sort_lds_e<16>(keys, n);
+}
+
+/* ---------------------------------------------------------------------- */
+/* Exact LDS bucket sort for a 256-thread workgroup: n <= 4096 keys.         */
+/*   gen(i)      -> the i-th key (recomputed in both passes, so no copy)     */
+/*   bucket(key) -> [0, NB), monotone non-decreasing in the sort order       */
+/*   less(a, b)  -> strict weak order (refines the bucket order)             */
+/* Histogram (LDS atomics) + scan + scatter, then every bucket (mean size    */
+/* <= 1) is finished by an insertion sort.  ~15x fewer instructions than a   */
+/* 64-bit bitonic network at these sizes (measured: 2100 VALU/wave).         */
+/* hist: NB + 1 ints of LDS; out: n keys of LDS.                             */
+/* ---------------------------------------------------------------------- */
+template <typename Gen, typename Bucket, typename Less>
+__device__ inline void block_bucket_sort(u64 *out, int n, int *hist, int NB, int *scratch17, Gen gen, Bucket bucket, Less less)
+{
+    for (int b = threadIdx.x; b <= NB; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[bucket(gen(i))], 1);
+    __syncthreads();
+    /* exclusive scan of hist[0..NB): every thread owns NB/blockDim consecutive buckets */
+    {
+        const int per = (NB + blockDim.x - 1) / blockDim.x;
+        const int b0 = threadIdx.x * per;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) if (b0 + k < NB) sum += hist[b0 + k];
+        int total;
+        int pre = block_exscan(sum, scratch17, &total);
+        for (int k = 0; k < per; ++k) {
+            if (b0 + k < NB) { int c = hist[b0 + k]; hist[b0 + k] = pre; pre += c; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        u64 k = gen(i);
+        out[atomicAdd(&hist[bucket(k)], 1)] = k;
+    }
+    __syncthreads();
+    /* hist[b] is now the END of bucket b */
+    for (int b = threadIdx.x; b < NB; b += blockDim.x) {
+        const int s = b ? hist[b - 1] : 0, e = hist[b];
+        for (int p = s + 1; p < e; ++p) {
+            u64 kp = out[p];
+            int q = p - 1;
+            while (q >= s && less(kp, out[q])) { out[q + 1] = out[q]; --q; }
+            out[q + 1] = kp;
+        }
+    }
+    __syncthreads();
+}
+
 __host__ __device__ inline int next_pow2(int v)
 {
     int p = 1;

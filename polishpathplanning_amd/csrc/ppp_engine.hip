@@ -233,7 +233,7 @@ int enqueue_index(ppp_handle h)
     int gs = std::max(1, (n + chunk - 1) / chunk);
     LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
            h->slab_cursor.p, h->unsorted4.p);
-    size_t sort_lds = (size_t)h->slab_cap * 10;
+    size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
     LAUNCH(h, "k_slab_sort", k_slab_sort, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
            h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap);
     h->index_built = true;

@@ -248,33 +248,41 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
     }
 }
 
-/* one workgroup per slab: LDS bitonic sort on (y, idx); exact x bounds of the slab */
+/* one workgroup per slab: exact LDS bucket sort on (y, cloud index) -- buckets are uniform in y
+   over the cloud's y range --, then the exact x bounds of the slab */
 __global__ void __launch_bounds__(256) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                    float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    u64 *key = (u64 *)s_raw;
-    u16 *pay = (u16 *)(key + cap);
+    u64 *key = (u64 *)s_raw;            /* cap entries: (ord(y) << 16) | position in the unsorted slab */
+    int *hist = (int *)(key + cap);     /* cap + 1 buckets */
     __shared__ float s_mn[4], s_mx[4];
+    __shared__ int s_scr[17];
     const int b = blockIdx.x;
     const int s0 = slab_start[b], c = slab_start[b + 1] - s0;
     float mn = INFINITY, mx = -INFINITY;
     if (c > cap) {
         if (threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
         for (int i = threadIdx.x; i < c; i += blockDim.x) sorted4[s0 + i] = unsorted4[s0 + i];
-    } else {
-        const int P = next_pow2(c);
-        for (int i = threadIdx.x; i < P; i += blockDim.x) {
-            if (i < c) {
-                float4 p = unsorted4[s0 + i];
-                key[i] = ((u64)f2ord(p.y) << 32) | (u32)idx_of(p);
-                pay[i] = (u16)i;
-            } else { key[i] = ~0ull; pay[i] = 0; }
-        }
-        if (P > 1) bitonic_lds<true>(key, pay, P);
-        else __syncthreads();
+    } else if (c > 0) {
+        const int NB = min(cap, next_pow2(c));
+        const float y0 = m->mn[1];
+        const float yr = m->mx[1] - y0;
+        const float scale = yr > 0.f ? (float)NB / yr : 0.f;
+        const float4 *src = unsorted4 + s0;
+        auto gen = [&](int i) { return ((u64)f2ord(src[i].y) << 16) | (u64)i; };
+        auto bucket = [&](u64 k) {
+            int q = (int)((ord2f((u32)(k >> 16)) - y0) * scale);
+            return q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+        };
+        auto less = [&](u64 a, u64 bb) {
+            u32 ya = (u32)(a >> 16), yb = (u32)(bb >> 16);
+            if (ya != yb) return ya < yb;
+            return idx_of(src[(int)(a & 0xffffu)]) < idx_of(src[(int)(bb & 0xffffu)]); /* equal y: cloud index */
+        };
+        block_bucket_sort(key, c, hist, NB, s_scr, gen, bucket, less);
         for (int i = threadIdx.x; i < c; i += blockDim.x) {
-            float4 p = unsorted4[s0 + pay[i]];
+            float4 p = src[(int)(key[i] & 0xffffu)];
             sorted4[s0 + i] = p;
             mn = fminf(mn, p.x); mx = fmaxf(mx, p.x);
         }
@@ -336,11 +344,9 @@ __device__ inline int band_gather_sorted(const SliceLds &L, int capb, const floa
     __syncthreads();
     n = *s_n;
     if (n > capb) return -1;
-    const int P = next_pow2(n);
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        L.keys[i] = i < n ? (((u64)(u32)idx_of(L.a4[i]) << 32) | (u32)i) : ~0ull;
-    if (P > 1) bitonic_lds<false>(L.keys, nullptr, P);
-    else __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) L.keys[i] = ((u64)(u32)idx_of(L.a4[i]) << 32) | (u32)i;
+    __syncthreads();
+    block_sort_lds(L.keys, n);
     return n;
 }
 
@@ -484,10 +490,7 @@ __device__ inline int insert_point_lds(const SliceLds &L, int n, float Px, int p
     }
     __syncthreads();
     /* --- std::map semantics: ascending key, last writer wins --- */
-    const int P = next_pow2(ncand);
-    for (int i = ncand + threadIdx.x; i < P; i += blockDim.x) L.keys[i] = ~0ull;
-    if (P > 1) bitonic_lds<false>(L.keys, nullptr, P);
-    else __syncthreads();
+    block_sort_lds(L.keys, ncand);
     return ncand;
 }
 
@@ -570,20 +573,27 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
 /* rule, which is carried as the query's cloud index in the sort key.   */
 /* ------------------------------------------------------------------ */
 struct SliceKdLds {
-    float4 *a4;
-    u64 *keys, *ckeys;
-    float *candz;
-    u16 *cpay;
+    float4 *a4;  /* band points                                              (dead after the NN phase) */
+    u64 *keys;   /* band sorted by (side, y): (side<<63)|(ord(y)<<16)|slot   (dead after the NN phase) */
+    float *cy, *cz; /* node candidate of the i-th left point: y, z */
+    int *cidx;      /* ... and the cloud index of that left point  */
+    /* aliases: */
+    int *hist_band; /* over cy..cidx while the band is sorted        */
+    u64 *ckeys;     /* over a4 once the candidates exist             */
+    int *hist_cand; /* behind ckeys                                   */
 };
-__host__ __device__ inline size_t slice_kd_lds_bytes(int capb) { return (size_t)capb * (16 + 8 + 8 + 4 + 2); }
+__host__ __device__ inline size_t slice_kd_lds_bytes(int capb) { return (size_t)capb * (16 + 8 + 12) + 64; }
 __device__ inline SliceKdLds carve_slice_kd_lds(char *raw, int capb)
 {
     SliceKdLds L;
     L.a4 = (float4 *)raw;
     L.keys = (u64 *)(L.a4 + capb);
-    L.ckeys = L.keys + capb;
-    L.candz = (float *)(L.ckeys + capb);
-    L.cpay = (u16 *)(L.candz + capb);
+    L.cy = (float *)(L.keys + capb);
+    L.cz = L.cy + capb;
+    L.cidx = (int *)(L.cz + capb);
+    L.hist_band = (int *)L.cy;            /* needs capb + 1 ints <= 3 capb */
+    L.ckeys = (u64 *)L.a4;                /* capb keys = half of a4        */
+    L.hist_cand = (int *)(L.ckeys + capb); /* capb + 1 ints, second half    */
     return L;
 }
 #define KD_Y(k) ((u32)((k) >> 16))
@@ -655,22 +665,29 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
         return;
     }
-    const int P = next_pow2(n);
-    int ner = 0;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        u64 k = ~0ull;
-        if (i < n) {
+    /* sort the band by (side, y): Er first, then El, ascending y inside each */
+    const float y0 = m->mn[1];
+    const float yr = m->mx[1] - y0;
+    {
+        const int NBh = next_pow2(max(n, 64)) >> 1; /* buckets per side (about one point each) */
+        const float scale = yr > 0.f ? (float)NBh / yr : 0.f;
+        auto gen = [&](int i) {
             float4 p = L.a4[i];
             u64 side = (p.x - Px) > 0 ? 1ull : 0ull; /* 1 = El (left, x > Px), 0 = Er */
-            ner += side ? 0 : 1;
-            k = (side << 63) | ((u64)f2ord(p.y) << 16) | (u64)i;
-        }
-        L.keys[i] = k;
+            return (side << 63) | ((u64)f2ord(p.y) << 16) | (u64)i;
+        };
+        auto bucket = [&](u64 k) {
+            int q = (int)((ord2f(KD_Y(k)) - y0) * scale);
+            q = q < 0 ? 0 : (q >= NBh ? NBh - 1 : q);
+            return q + ((k >> 63) ? NBh : 0);
+        };
+        auto less = [&](u64 a, u64 bb) { return a < bb; };
+        int ner = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ner += (L.a4[i].x - Px) > 0 ? 0 : 1;
+        ner = wave_sum(ner);
+        if ((threadIdx.x & 63) == 0 && ner) atomicAdd(&s_ner, ner);
+        block_bucket_sort(L.keys, n, L.hist_band, 2 * NBh, s_scr, gen, bucket, less);
     }
-    ner = wave_sum(ner);
-    if ((threadIdx.x & 63) == 0 && ner) atomicAdd(&s_ner, ner);
-    if (P > 1) bitonic_lds<false>(L.keys, nullptr, P);
-    else __syncthreads();
     const int nEr = s_ner, nEl = n - nEr;
     if (nEl == 0 || nEr == 0) {
         /* empty left side: empty map -> < 3 knots; empty right side: empty FLANN tree */
@@ -686,18 +703,27 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         float t = (Px - R.x) / (Lp.x - R.x);
         float y = R.y + t * (Lp.y - R.y);
         float z = R.z + t * (Lp.z - R.z);
-        if (y == 0.f) y = 0.f;
-        L.candz[i] = z;
-        L.cpay[i] = (u16)i;
-        L.ckeys[i] = ((u64)f2ord(y) << 32) | (u32)idx_of(q); /* Node[y] = ...: the highest index writes last */
+        if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
+        L.cy[i] = y; L.cz[i] = z; L.cidx[i] = idx_of(q);
     }
-    const int P2 = next_pow2(nEl);
-    for (int i = nEl + threadIdx.x; i < P2; i += blockDim.x) { L.ckeys[i] = ~0ull; L.cpay[i] = 0; }
-    if (P2 > 1) bitonic_lds<true>(L.ckeys, L.cpay, P2);
-    else __syncthreads();
+    __syncthreads(); /* the band (a4, keys) is dead from here: ckeys / hist_cand reuse it */
+    {   /* sort the node candidates by y */
+        const int NBc = next_pow2(max(nEl, 64));
+        const float scale = yr > 0.f ? (float)NBc / yr : 0.f;
+        auto gen = [&](int i) { return ((u64)f2ord(L.cy[i]) << 16) | (u64)i; };
+        auto bucket = [&](u64 k) {
+            int q = (int)((ord2f((u32)(k >> 16)) - y0) * scale);
+            return q < 0 ? 0 : (q >= NBc ? NBc - 1 : q);
+        };
+        auto less = [&](u64 a, u64 bb) { return a < bb; };
+        block_bucket_sort(L.ckeys, nEl, L.hist_cand, NBc, s_scr, gen, bucket, less);
+    }
+    /* std::map semantics: one node per distinct y.  Node[y] = ... is overwritten by every later
+       writer and El is walked in ascending cloud index, so the value kept is the one written by
+       the candidate with the highest cloud index inside the run of equal keys. */
     int mcount = 0;
     for (int j = threadIdx.x; j < nEl; j += blockDim.x)
-        mcount += (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 32) != (u32)(L.ckeys[j] >> 32));
+        mcount += (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 16) != (u32)(L.ckeys[j] >> 16));
     int tot;
     block_exscan(mcount, s_scr, &tot);
     if (threadIdx.x == 0) {
@@ -717,12 +743,21 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         u64 k = 0;
         if (j < nEl) {
             k = L.ckeys[j];
-            keep = (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 32) != (u32)(k >> 32));
+            keep = (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 16) != (u32)(k >> 16));
         }
         int t2;
         int pre = block_exscan(keep, s_scr, &t2);
         int o = s_m;
-        if (keep) { oy[o + pre] = ord2f((u32)(k >> 32)); oz[o + pre] = L.candz[L.cpay[j]]; }
+        if (keep) {
+            int best_i = (int)(k & 0xffffu);
+            int best_idx = L.cidx[best_i];
+            for (int q = j - 1; q >= 0 && (u32)(L.ckeys[q] >> 16) == (u32)(k >> 16); --q) {
+                int ci = (int)(L.ckeys[q] & 0xffffu);
+                if (L.cidx[ci] > best_idx) { best_idx = L.cidx[ci]; best_i = ci; }
+            }
+            oy[o + pre] = ord2f((u32)(k >> 16));
+            oz[o + pre] = L.cz[best_i];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_m = o + t2;
         __syncthreads();
