@@ -835,7 +835,7 @@ void ppo_default_params(ppo_params *p)
     memcpy(p->handeye, he, sizeof(he));
     p->normal_radius = 2.5f;
     p->reference_complexity = 0;
-    p->smooth_max_sweeps = 64;
+    p->smooth_max_sweeps = 32;
 }
 
 ppo_handle *ppo_create(const float *xyz, size_t n, size_t stride, const ppo_params *p)

@@ -73,7 +73,7 @@ struct ppp_handle_s {
     DevBuf<int> wp_nn;
     DevBuf<float> wp_pre, wp_smooth, wp_out, sx, snap;
     DevBuf<MinMaxPart> mm_part;
-    DevBuf<double> sm_part;
+    DevBuf<double> sm_part, sm_chist;
     int mm_grid = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
 
@@ -89,7 +89,7 @@ struct ppp_handle_s {
         meta.release(); px.release(); lo.release(); hi.release(); node_y.release(); node_z.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
-        sx.release(); snap.release(); mm_part.release(); sm_part.release(); scratch.release();
+        sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); scratch.release();
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -212,6 +212,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->snap.ensure(2 * (size_t)SM_K * 3 * (size_t)h->W_cap));
     h->sm_tiles = smooth_tiles(h->W_cap);
     HIPCHK(h, h->sm_part.ensure((size_t)(SM_MAXS + SM_K + 1) * h->sm_tiles));
+    HIPCHK(h, h->sm_chist.ensure(SM_MAXS + SM_K + 1));
     h->planned = true;
     h->index_built = false; h->gen_done = false; h->path_done = false;
     return PPP_OK;
@@ -336,7 +337,7 @@ void ppp_default_params(ppp_params *p)
     const float he[6] = {-0.764091f, 0.025886f, 0.663790f, -3.1270175f, -0.040124f, -1.6063578f};
     memcpy(p->handeye, he, sizeof(he));
     p->normal_radius = 2.5f;
-    p->smooth_max_sweeps = 64;
+    p->smooth_max_sweeps = 32;
     p->alignment = 0; p->dynamic_adjustment = 0;
 }
 
@@ -459,9 +460,8 @@ int ppp_get_path_async(ppp_handle h)
         int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
         for (int b = 0; b <= nb; ++b)
             LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
     }
-    LAUNCH(h, "k_rpy_short", k_rpy_short, 1, 64, 0, h->meta.p, D, h->tail.p, h->wp_out.p);
     LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
     h->path_done = true;
     return PPP_OK;

@@ -147,27 +147,29 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     if (threadIdx.x == 0) {
         int c = 0;
         for (int w = 0; w < 4; ++w) c += s_cnt[w];
+        DevMeta r; /* built in registers, stored once: no dependent global round trips */
         for (int d = 0; d < 3; ++d) {
             float a = INFINITY, b = -INFINITY;
             for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
             /* getMinMax3D starts from +-FLT_MAX */
-            m->mn[d] = c ? a : 3.402823466e+38f;
-            m->mx[d] = c ? b : -3.402823466e+38f;
-            m->mn_ord[d] = f2ord(m->mn[d]); m->mx_ord[d] = f2ord(m->mx[d]);
+            r.mn[d] = c ? a : 3.402823466e+38f;
+            r.mx[d] = c ? b : -3.402823466e+38f;
+            r.mn_ord[d] = f2ord(r.mn[d]); r.mx_ord[d] = f2ord(r.mx[d]);
         }
-        m->n_valid = c;
-        m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
-        m->node_cursor = 0; m->api_cnt = 0; m->api_flag = 0; m->smooth_done = -1;
-        int S = c ? ppp_slice_walk(P.walk, m->mn[0], m->mx[0], P.tool_radius, px, S_cap) : 0;
-        if (S > S_cap) { set_err(m, DERR_CAPACITY, -1); S = S_cap; }
-        m->S = S;
-        m->first_kept = P.drop_ends ? 1 : 0;
+        r.n_valid = c;
+        r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
+        r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1;
+        int S = c ? ppp_slice_walk(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap) : 0;
+        if (S > S_cap) { r.err = DERR_CAPACITY; S = S_cap; }
+        r.S = S;
+        r.first_kept = P.drop_ends ? 1 : 0;
         int nk = P.drop_ends ? S - 2 : S;
-        m->nkept = nk < 0 ? 0 : nk;
-        m->B = B;
-        m->slab_x0 = m->mn[0];
-        float range = m->mx[0] - m->mn[0];
-        m->slab_invw = (c && range > 0.f) ? (float)B / range : 0.f;
+        r.nkept = nk < 0 ? 0 : nk;
+        r.B = B;
+        r.slab_x0 = r.mn[0];
+        float range = r.mx[0] - r.mn[0];
+        r.slab_invw = (c && range > 0.f) ? (float)B / range : 0.f;
+        *m = r;
         s_S = S;
     }
     __syncthreads();
@@ -1118,10 +1120,10 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* either continues from the last snapshot or emits the snapshot of the  */
 /* stop sweep.                                                           */
 /* ------------------------------------------------------------------ */
-#define SM_K 16
+#define SM_K 8
 #define SM_D 16
-#define SM_L 3
-#define SM_T 512
+#define SM_L 1
+#define SM_T 256
 #define SM_M (SM_T * SM_L)
 #define SM_HB ((SM_D + 1) * SM_K + 1)
 #define SM_OWN (SM_M - SM_HB - SM_K)
@@ -1136,7 +1138,7 @@ __host__ __device__ inline size_t smooth_snap_off(int q, int k, int j, int W_cap
 }
 
 __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, int b, int ntiles_cap, int W_cap,
-                                                       const float *__restrict__ sx, float *snap, double *part,
+                                                       const float *__restrict__ sx, float *snap, double *part, double *chist,
                                                        const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -1166,14 +1168,21 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
         if (b != 0) return;
         emit_level = 0; total_sweeps = P.smooth ? 1 : 0;
     } else if (b > 0) {
-        const int done = SM_K * b;
-        for (int k = 1 + threadIdx.x; k <= done; k += blockDim.x) {
-            double c = 0;
+        /* change[k] of the sweeps before the last batch was summed by the previous launch
+           (chist); the last batch's SM_K sweeps are summed here, all threads in parallel,
+           always in the same order (deterministic). */
+        const int done = SM_K * b, first_new = SM_K * (b - 1) + 1;
+        for (int k = 1 + threadIdx.x; k < first_new; k += blockDim.x) s_change[k] = chist[k];
+        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int k = first_new + wid; k <= done; k += nw) { /* one wave per sweep */
             const double *pp = part + (size_t)k * ntiles_cap;
-            for (int q = 0; q < ntiles; ++q) c += pp[q];
-            s_change[k] = c;
+            double c = 0;
+            for (int q = lane; q < ntiles; q += 64) c += pp[q];
+            c = wave_sum(c);
+            if (lane == 0) s_change[k] = c;
         }
         __syncthreads();
+        if (tile == 0) for (int k = first_new + threadIdx.x; k <= done; k += blockDim.x) chist[k] = s_change[k];
         if (threadIdx.x == 0) {
             int ks = 0;
             for (int k = 1; k <= done && !ks; ++k) {
@@ -1306,19 +1315,6 @@ __device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int
             for (int D = 3; D < 6; ++D) W6[6 * (size_t)i + D] = W6[6 * (size_t)preId + D];
 }
 
-/* Only when a slice is shorter than RPYres+1 waypoints do the reference's segments overlap
-   (App. B.6): then, and only then, the list is walked in order by one thread, literally. */
-__global__ void k_rpy_short(DevMeta *m, DevParams P, const int *__restrict__ tail, float *W6)
-{
-    const int W = m->W, nk = m->nkept;
-    if (m->err || W == 0 || !(P.rpy_resolution > 2) || !m->any_short) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int res = (int)P.rpy_resolution;
-        int preId = 0;
-        for (int id = 0; id < nk; ++id) { rpy_segment(W6, W, preId, tail[id], res, m); preId = tail[id] + 1; }
-    }
-}
-
 /* reduceRPY (path_translation_alg.cpp:37-86) per waypoint -- the key waypoints (every RPYres-th
    of a slice) are never modified, so every interval is independent --, then the -180..180 limit
    (:81-85) and TransFlangeposition (:89-112).  src: smoothed list; out: final WayPointsList. */
@@ -1327,11 +1323,31 @@ __global__ void __launch_bounds__(64) k_finish(const DevMeta *m, DevParams P, co
 {
     const int W = m->W;
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m->err || w >= W) return;
-    float p[6];
-    for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)w + d]; /* k_smooth_batch / k_rpy_short wrote it */
+    if (m->err || W == 0) return;
     const bool reduce = P.rpy_resolution > 2;
-    if (reduce && !m->any_short) {
+    if (reduce && m->any_short) {
+        /* Only when a slice is shorter than RPYres+1 waypoints do the reference's segments overlap
+           (App. B.6): then, and only then, the whole list is finished in order by one thread. */
+        if (w != 0) return;
+        const int res = (int)P.rpy_resolution;
+        int preId = 0;
+        for (int id = 0; id < m->nkept; ++id) { rpy_segment(out, W, preId, tail[id], res, const_cast<DevMeta *>(m)); preId = tail[id] + 1; }
+        for (int q = 0; q < W; ++q) {
+            float p[6];
+            for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)q + d];
+            for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
+            float R[3][3];
+            rot_zyx(p[3], p[4], p[5], R);
+            const float ee[3] = {0.f, 0.f, -P.ee_length};
+            for (int i = 0; i < 3; ++i) out[6 * (size_t)q + i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
+            for (int D = 3; D < 6; ++D) out[6 * (size_t)q + D] = p[D];
+        }
+        return;
+    }
+    if (w >= W) return;
+    float p[6];
+    for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)w + d]; /* k_smooth_batch wrote it */
+    if (reduce) {
         const int res = (int)P.rpy_resolution;
         /* segment of w: first tail >= w */
         int lo = 0, hi = m->nkept - 1;
