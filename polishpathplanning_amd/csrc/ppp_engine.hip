@@ -365,6 +365,7 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_slice_kd, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     *out = h;
@@ -450,10 +451,9 @@ int ppp_get_path_async(ppp_handle h)
     LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
            h->wp_off.p, h->tail.p, h->W_cap);
     int nk = std::max(1, h->S_cap);
-    LAUNCH(h, "k_eval", k_eval, nk, 256, 0, h->meta.p, D, h->px.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p,
-           h->wp_cnt.p, h->wp_off.p, h->wp_xyz.p);
     int gw = std::max(1, (h->W_cap + 63) / 64);
-    LAUNCH(h, "k_pose", k_pose, gw, 64, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p,
+    LAUNCH(h, "k_pose", k_pose, nk, 256, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+           h->slab_xmax.p, h->px.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p, h->capb,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
     /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
     {

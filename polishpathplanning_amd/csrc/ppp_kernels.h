@@ -847,33 +847,6 @@ __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const f
     }
 }
 
-__global__ void __launch_bounds__(256) k_eval(const DevMeta *m, DevParams P, const float *__restrict__ px,
-                                              const float *__restrict__ node_y, const float *__restrict__ node_z,
-                                              const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                              const int *__restrict__ wp_cnt, const int *__restrict__ wp_off, float4 *wp_xyz)
-{
-    const int k = blockIdx.x;
-    if (m->err || k >= m->nkept || m->W == 0) return;
-    const int s = k + m->first_kept;
-    const int st = node_start[s], mm = node_cnt[s], cnt = wp_cnt[k], off = wp_off[k];
-    const float *ny = node_y + st, *nz = node_z + st;
-    const double Pxd = (double)px[s];
-    auto Yf = [&](int i) { return (double)ny[i]; };
-    auto Zf = [&](int i) { return (double)nz[i]; };
-    auto Xf = [&](int) { return Pxd; };
-    const double start = (double)ny[0] + P.trim;
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-        double dy = start;
-        for (int r = 0; r < t; ++r) dy += P.path_resolution; /* the reference accumulates */
-        int i = gsl_bsearch(mm, dy, Yf);
-        double x = steffen_eval_at(i, mm, dy, Yf, Xf);
-        double z = steffen_eval_at(i, mm, dy, Yf, Zf);
-        /* Vector4f(point) then invTransAlign (identity: Alignment=false) */
-        int slot = (k & 1) ? (cnt - 1 - t) : t; /* std::reverse on every second slice */
-        wp_xyz[off + slot] = make_float4((float)x, (float)dy, (float)z, 1.f);
-    }
-}
-
 __global__ void k_eval_api(DevMeta *m, const float *__restrict__ px, const float *__restrict__ node_y,
                            const float *__restrict__ node_z, const int *__restrict__ node_start,
                            const int *__restrict__ node_cnt, int s, const double *__restrict__ yq, int kq, double *out)
@@ -906,14 +879,18 @@ struct SlabView {
     const int *slab_start;
     const float *slab_xmin, *slab_xmax;
     const DevMeta *m;
+    /* optional LDS copy of sorted4[lds_lo, lds_hi) (the slabs around one slice) */
+    const float4 *lds;
+    int lds_lo, lds_hi;
+    __device__ inline float4 at(int i) const { return (i >= lds_lo && i < lds_hi) ? lds[i - lds_lo] : sorted4[i]; }
 };
 
 /* first position in [s0,s1) whose y >= qy */
-__device__ inline int lower_bound_y(const float4 *__restrict__ a, int s0, int s1, float qy)
+__device__ inline int lower_bound_y(const SlabView &V, int s0, int s1, float qy)
 {
     while (s0 < s1) {
         int mid = (s0 + s1) >> 1;
-        if (a[mid].y < qy) s0 = mid + 1; else s1 = mid;
+        if (V.at(mid).y < qy) s0 = mid + 1; else s1 = mid;
     }
     return s0;
 }
@@ -928,9 +905,9 @@ __device__ inline int nearest_in_slabs(const SlabView &V, float qx, float qy, fl
     auto scan_slab = [&](int b) {
         const int s0 = V.slab_start[b], s1 = V.slab_start[b + 1];
         if (s0 >= s1) return;
-        const int p = lower_bound_y(V.sorted4, s0, s1, qy);
+        const int p = lower_bound_y(V, s0, s1, qy);
         for (int i = p; i < s1; ++i) {
-            const float4 c = V.sorted4[i];
+            const float4 c = V.at(i);
             float dy = qy - c.y;
             if (dy * dy > best) break;
             float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
@@ -938,7 +915,7 @@ __device__ inline int nearest_in_slabs(const SlabView &V, float qx, float qy, fl
             if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
         }
         for (int i = p - 1; i >= s0; --i) {
-            const float4 c = V.sorted4[i];
+            const float4 c = V.at(i);
             float dy = qy - c.y;
             if (dy * dy > best) break;
             float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
@@ -976,9 +953,9 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
     auto scan_slab = [&](int b) {
         const int s0 = V.slab_start[b], s1 = V.slab_start[b + 1];
         if (s0 >= s1) return;
-        const int q0 = lower_bound_y(V.sorted4, s0, s1, p.y);
+        const int q0 = lower_bound_y(V, s0, s1, p.y);
         for (int i = q0; i < s1; ++i) {
-            const float4 c = V.sorted4[i];
+            const float4 c = V.at(i);
             float dy = p.y - c.y;
             if (dy * dy > r2) break;
             if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
@@ -990,7 +967,7 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
             }
         }
         for (int i = q0 - 1; i >= s0; --i) {
-            const float4 c = V.sorted4[i];
+            const float4 c = V.at(i);
             float dy = p.y - c.y;
             if (dy * dy > r2) break;
             if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
@@ -1037,35 +1014,85 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
     out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; out[3] = curv;
 }
 
-__global__ void __launch_bounds__(64) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
-                                             const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
-                                             const float *__restrict__ slab_xmax, const float4 *__restrict__ wp_xyz,
-                                             int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx)
+/* One workgroup per kept slice: a9 (sampling, path_translation_alg.cpp:156-169), then for every
+   waypoint the nearest cloud point, its PCL normal, the tool frame and the hand-eye transform
+   (:178-211).  The slabs within POSE_PAD mm of the plane and the slice's spline knots are staged
+   in LDS, so the binary searches and window scans are LDS reads instead of dependent HBM/L2
+   round trips; anything outside the staged window falls back to the global copy (exactness
+   never depends on the window). */
+#define POSE_STAGE_CAP 5120
+#define POSE_PAD 8.0f
+__host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 8; }
+
+__global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+                                              const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+                                              const float *__restrict__ slab_xmax, const float *__restrict__ px,
+                                              const float *__restrict__ node_y, const float *__restrict__ node_z,
+                                              const int *__restrict__ node_start, const int *__restrict__ node_cnt,
+                                              const int *__restrict__ wp_cnt, const int *__restrict__ wp_off, int capb,
+                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx)
 {
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    float4 *s_pts = (float4 *)s_raw;
+    float *s_ny = (float *)(s_pts + POSE_STAGE_CAP);
+    float *s_nz = s_ny + capb;
+    const int k = blockIdx.x;
     const int W = m->W;
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m->err || w >= W) return;
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m};
-    const float4 q = wp_xyz[w];
-    float wp[6];
-    float n4[4];
-    int id = -1;
-    if (q.x == q.x && q.y == q.y && q.z == q.z) {
-        float4 p;
-        id = nearest_in_slabs(V, q.x, q.y, q.z, &p);
-        if (id >= 0) normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
+    if (m->err || k >= m->nkept || W == 0) return;
+    const int s = k + m->first_kept;
+    const int st = node_start[s], mm = node_cnt[s], cnt = wp_cnt[k], off = wp_off[k];
+    if (cnt == 0) return;
+    const float Px = px[s];
+    /* slabs to stage: widest symmetric range around the plane's slab that fits */
+    int bL = slab_of(m, Px - POSE_PAD), bR = slab_of(m, Px + POSE_PAD);
+    while (slab_start[bR + 1] - slab_start[bL] > POSE_STAGE_CAP && bL < bR) {
+        const int bc = slab_of(m, Px);
+        if (bR - bc >= bc - bL) --bR; else ++bL;
     }
-    if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
-    float rpy[3];
-    pose_from_normal(n4, rpy);
-    if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
-    else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
-    wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
-    handeye_transform(P.handeye, wp);
-    wp_nn[w] = id;
-    wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
-    for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];
-    for (int d = 0; d < 3; ++d) sx[(size_t)d * W + w] = wp[d];
+    int lds_lo = slab_start[bL], lds_hi = slab_start[bR + 1];
+    if (lds_hi - lds_lo > POSE_STAGE_CAP) lds_hi = lds_lo; /* one over-full slab: no staging */
+    for (int i = lds_lo + threadIdx.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
+    const bool nodes_in_lds = mm <= capb;
+    if (nodes_in_lds)
+        for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; }
+    __syncthreads();
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
+    const float *ny = nodes_in_lds ? s_ny : node_y + st, *nz = nodes_in_lds ? s_nz : node_z + st;
+    const double Pxd = (double)Px;
+    auto Yf = [&](int i) { return (double)ny[i]; };
+    auto Zf = [&](int i) { return (double)nz[i]; };
+    auto Xf = [&](int) { return Pxd; };
+    const double start = (double)ny[0] + P.trim;
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        double dy = start;
+        for (int r = 0; r < t; ++r) dy += P.path_resolution; /* the reference accumulates */
+        const int iv = gsl_bsearch(mm, dy, Yf);
+        const double xd = steffen_eval_at(iv, mm, dy, Yf, Xf);
+        const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
+        /* Vector4f(point) then invTransAlign (identity: Alignment=false); std::reverse on every second slice */
+        const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
+        const float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
+        wp_xyz[w] = q;
+        float wp[6];
+        float n4[4];
+        int id = -1;
+        if (q.x == q.x && q.y == q.y && q.z == q.z) {
+            float4 p;
+            id = nearest_in_slabs(V, q.x, q.y, q.z, &p);
+            if (id >= 0) normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
+        }
+        if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
+        float rpy[3];
+        pose_from_normal(n4, rpy);
+        if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
+        else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
+        wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
+        handeye_transform(P.handeye, wp);
+        wp_nn[w] = id;
+        wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+        for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];
+        for (int d = 0; d < 3; ++d) sx[(size_t)d * W + w] = wp[d];
+    }
 }
 
 __global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
@@ -1075,7 +1102,7 @@ __global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict_
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k) return;
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m};
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     int id = idx[t];
     float n4[4] = {NAN, NAN, NAN, NAN};
     if (id >= 0 && id < npts && X[id] == X[id]) {
@@ -1091,7 +1118,7 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k) return;
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m};
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     float4 p;
     float qx = q[3 * t], qy = q[3 * t + 1], qz = q[3 * t + 2];
     out[t] = (qx == qx && qy == qy && qz == qz) ? nearest_in_slabs(V, qx, qy, qz, &p) : -1;
