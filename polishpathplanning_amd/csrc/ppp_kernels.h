@@ -123,6 +123,77 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
     }
 }
 
+/* Device form of ppp_slice_walk for one thread: identical values, but without a data dependent
+   branch per element (a float compare feeding a scalar branch costs ~60 cycles per iteration on
+   one lane).  Integer walks are closed forms; float walks keep the reference's sequential
+   float accumulation (each add rounds) in a predicated loop whose trip count comes from a
+   double estimate, with the literal loop as the tail.  front[] is LDS scratch. */
+__device__ inline int slice_walk_device(int walk, float min_x, float max_x, double toolRadius, float *px, int cap, float *front,
+                                        int front_cap)
+{
+    const int step = (int)(toolRadius * 2);
+    if (step <= 0 || !(min_x <= max_x)) return 0;
+    const float fstep = (float)step;
+    auto up_arm = [&](float loc, int k0) { /* while (loc < max_x) { px[k++] = loc; loc += step; } */
+        int k = k0;
+        double est = ((double)max_x - (double)loc) / (double)step;
+        int n_est = est > 0 ? (int)fmin(est + 2.0, 4.0e6) : 1;
+        for (int it = 0; it < n_est; ++it) {
+            const bool v = loc < max_x;
+            if (v && k < cap) px[k] = loc;
+            k += v ? 1 : 0;
+            loc += fstep;
+        }
+        while (loc < max_x && k < PPP_WALK_HARD_MAX) { if (k < cap) px[k] = loc; k++; loc += fstep; }
+        return k;
+    };
+    switch (walk) {
+    case 0: {
+        float loc = (min_x + max_x) / 2 - fstep;
+        int nfront = 0;
+        double est = ((double)loc - (double)min_x) / (double)step;
+        int n_est = est > 0 ? (int)fmin(est + 2.0, 4.0e6) : 1;
+        for (int it = 0; it < n_est; ++it) {
+            const bool v = loc > min_x;
+            if (v && nfront < front_cap) front[nfront] = loc;
+            nfront += v ? 1 : 0;
+            loc -= fstep;
+        }
+        while (loc > min_x && nfront < PPP_WALK_HARD_MAX) { if (nfront < front_cap) front[nfront] = loc; nfront++; loc -= fstep; }
+        if (nfront <= front_cap) {
+            for (int i = 0; i < nfront; ++i) if (nfront - 1 - i < cap) px[nfront - 1 - i] = front[i];
+        } else { /* LDS scratch too small: redo the arm writing straight to its final place */
+            loc = (min_x + max_x) / 2 - fstep;
+            for (int i = nfront - 1; i >= 0 && loc > min_x; --i) { if (i < cap) px[i] = loc; loc -= fstep; }
+        }
+        return up_arm((min_x + max_x) / 2, nfront);
+    }
+    case 1: {
+        const int imin = (int)min_x, imax = (int)max_x;
+        const int c = (imax + imin) / 2;
+        int nfront = 0, nback = 0;
+        if (imax > c - step && c - step > imin) nfront = (c - imin - 1) / step;
+        if (imax > c + step && c + step > imin) nback = (imax - c - 1) / step;
+        for (int i = 0; i < nfront; ++i) if (i < cap) px[i] = (float)(c - (nfront - i) * step);
+        if (nfront < cap) px[nfront] = (min_x + max_x) / 2;
+        for (int j = 0; j < nback; ++j) if (nfront + 1 + j < cap) px[nfront + 1 + j] = (float)(c + (j + 1) * step);
+        return nfront + 1 + nback;
+    }
+    case 2: {
+        int loc = (int)(min_x + toolRadius);
+        int k = 0;
+        if (k < cap) px[k] = (float)loc;
+        k++;
+        loc += step;
+        while (loc < max_x && k < PPP_WALK_HARD_MAX) { if (k < cap) px[k] = (float)loc; k++; loc += step; }
+        return k;
+    }
+    case 3: return up_arm((float)(min_x + toolRadius), 0);
+    case 4: { float x = min_x; x += (float)(step / 2); return up_arm(x, 0); }
+    }
+    return 0;
+}
+
 /* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
 __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
@@ -131,6 +202,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     __shared__ float s_mn[3][4], s_mx[3][4];
     __shared__ int s_cnt[4];
     __shared__ int s_S;
+    __shared__ float s_front[4096];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
@@ -159,7 +231,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         r.n_valid = c;
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
         r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1;
-        int S = c ? ppp_slice_walk(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap) : 0;
+        int S = c ? slice_walk_device(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap, s_front, 4096) : 0;
         if (S > S_cap) { r.err = DERR_CAPACITY; S = S_cap; }
         r.S = S;
         r.first_kept = P.drop_ends ? 1 : 0;

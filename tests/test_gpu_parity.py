@@ -318,3 +318,14 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path):
         assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 + 5e-6 * np.abs(want[:, :3]).max()  # 6 significant digits in the file
     r = subprocess.run([os.path.join(root, "examples", "main"), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
     assert r.returncode == 0 and "number of paths" in r.stdout
+
+
+@pytest.mark.parametrize("walk", [0, 1, 2, 3, 4])
+def test_slice_walks_on_device_match_the_reference_loops(engine_mod, oracle_mod, walk):
+    """a3: the device walk (closed forms / predicated float accumulation) against the literal loops."""
+    for R, x0, nx in [(6.0, 0.5, 300), (7.5, -93.7, 260), (12.0, 17.25, 400), (2.6, -200.3, 180), (15.0, 1000.2, 500)]:
+        pts = synth.make_plate(nx, 24, kind="flat", seed=int(R * 10) + walk, x0_mm=x0)
+        o = oracle_mod.Oracle(pts, tool_radius=R, walk=walk)
+        e = engine_mod.Engine(0, tool_radius=R, walk=walk)
+        e.set_cloud(pts)
+        assert np.array_equal(e.slice_positions(), o.slice_positions()), (R, x0, walk)
