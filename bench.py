@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2_1m_s256")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="workpieces per GPU per step, one engine handle (= one HIP stream) each (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=20)
     args = ap.parse_args()
@@ -54,9 +56,14 @@ def main():
 
     # ---- synthetic workpiece of this rank (untimed: generation + H2D) ----
     base_seed = sorted(synth.CONFIGS).index(args.config) + 1
-    pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank)
-    eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
-    eng.set_cloud(pts)
+    engines, clouds = [], []
+    for bi in range(args.batch):
+        pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank + 17 * bi)
+        e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+        e.set_cloud(pts)
+        engines.append(e)
+        clouds.append(pts)
+    eng, pts = engines[0], clouds[0]
     n_points = int(pts.shape[0])
 
     # first pass: learn S and W, size the gather buffer
@@ -64,12 +71,18 @@ def main():
     W = eng.get_path()
     if cfg.get("slices") and S != cfg["slices"]:
         raise SystemExit("config %s produced %d slices, expected %d" % (args.config, S, cfg["slices"]))
-    send = torch.zeros((max(W, 1) + 64, 6), dtype=torch.float32, device=dev)
+    w_all = [W]
+    for e in engines[1:]:
+        e.gen_path()
+        w_all.append(e.get_path())
+    send = torch.zeros((sum(w_all) + 64 * args.batch, 6), dtype=torch.float32, device=dev)
 
     def step():
-        eng.gen_path_async()
-        eng.get_path_async()
-        w = eng.copy_waypoints_to_device(send.data_ptr(), send.shape[0])  # waits for this handle's stream
+        for e in engines:  # every handle has its own stream: the workpieces overlap on the GPU
+            e.run_async()    # GenPath + getPath, one captured hipGraph launch per workpiece
+        w = 0
+        for e in engines:  # waits for that handle's stream, then D2D into the gather buffer
+            w += e.copy_waypoints_to_device(send.data_ptr() + 24 * w, send.shape[0] - w)
         blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev)
         return w, blocks
 
@@ -111,13 +124,14 @@ def main():
         eng.enable_timing(False)
         kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
         dom = max(kern_ms, key=kern_ms.get)
-        alg_bytes = 12.0 * n_points + 24.0 * w_local  # xyz read once + waypoints written once
+        w_one = float(w_all[0])
+        alg_bytes = 12.0 * n_points + 24.0 * w_one  # SURVEY.md 8(d), per workpiece: xyz read once + waypoints written once
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
                     "algorithmic_bytes": alg_bytes,
-                    "pipeline_gbs": alg_bytes / (elapsed / args.steps) / 1e9}
+                    "pipeline_gbs": alg_bytes * args.batch / (elapsed / args.steps) / 1e9}
 
         # ---- CPU baseline: the oracle in reference-complexity mode on the node's host cores ----
         cpu = None
@@ -147,7 +161,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "points_per_workpiece": n_points, "slices": S,
-                       "waypoints_per_workpiece": int(w_local), "workpieces": world,
+                       "waypoints_per_workpiece": int(w_all[0]), "workpieces": world * args.batch, "batch_per_gpu": args.batch,
                        "parallelism": "one workpiece per GPU, RCCL gather of robot_path to rank 0" if world > 1 else "single GPU",
                        "pairing": "kd", "walk": "center_int (connect)", "tool_radius_mm": cfg["tool_radius"]},
             "roofline": roofline,

@@ -99,6 +99,11 @@ int ppp_gen_path_async(ppp_handle h);
 /* getPath(): path_translation_alg.cpp:144-214 (sampling, normals, pose, HandEye, smoothing,
  * reduceRPY, TransFlangeposition); the list stays in HBM. */
 int ppp_get_path_async(ppp_handle h);
+/* GenPath() followed by getPath() as ONE enqueue: the kernel sequence is captured into a hipGraph
+ * the first time and replayed afterwards (one host call per workpiece instead of ~15 launches;
+ * this is what keeps a batch of small workpieces from being host-launch-bound).  Falls back to
+ * the two plain calls while kernel timing is enabled. */
+int ppp_run_async(ppp_handle h);
 /* waits for the stream, then reports deferred device-side errors */
 int ppp_sync(ppp_handle h);
 int ppp_failed_slice(ppp_handle h);

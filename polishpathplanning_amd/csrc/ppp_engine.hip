@@ -78,9 +78,19 @@ struct ppp_handle_s {
     DevBuf<char> scratch; /* API staging */
 
     DevMeta hmeta;
+    DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
+    bool meta_in_flight = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
     bool timing = false;
     std::vector<KTimer> timers;
 
+    void drop_graph()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_exec = nullptr; graph = nullptr;
+    }
     ~ppp_handle_s()
     {
         (void)hipSetDevice(device);
@@ -90,6 +100,8 @@ struct ppp_handle_s {
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); scratch.release();
+        drop_graph();
+        if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -215,6 +227,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->sm_chist.ensure(SM_MAXS + SM_K + 1));
     h->planned = true;
     h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->drop_graph(); /* buffer addresses and launch geometry are baked into the captured graph */
     return PPP_OK;
 }
 
@@ -243,8 +256,21 @@ int enqueue_index(ppp_handle h)
 
 int fetch_meta(ppp_handle h)
 {
+    if (h->meta_in_flight) { /* GenPath / getPath already enqueued the copy behind their last kernel */
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->hmeta = *h->hmeta_pinned;
+        h->meta_in_flight = false;
+        return PPP_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(&h->hmeta, h->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
+int enqueue_meta_copy(ppp_handle h)
+{
+    HIPCHK(h, hipMemcpyAsync(h->hmeta_pinned, h->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, h->stream));
+    h->meta_in_flight = true;
     return PPP_OK;
 }
 
@@ -356,6 +382,7 @@ int ppp_create(int device_id, ppp_handle *out)
     ppp_default_params(&h->P);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     if (h->meta.ensure(1) != hipSuccess) { delete h; return PPP_ERR_HIP; }
+    if (hipHostMalloc((void **)&h->hmeta_pinned, sizeof(DevMeta), hipHostMallocDefault) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) h->max_lds = lds;
     hipDeviceProp_t prop;
@@ -439,7 +466,7 @@ int ppp_gen_path_async(ppp_handle h)
     }
     h->gen_done = true;
     h->path_done = false;
-    return PPP_OK;
+    return enqueue_meta_copy(h);
 }
 
 int ppp_get_path_async(ppp_handle h)
@@ -464,6 +491,34 @@ int ppp_get_path_async(ppp_handle h)
     }
     LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
     h->path_done = true;
+    return enqueue_meta_copy(h);
+}
+
+int ppp_run_async(ppp_handle h)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    if (h->timing) {
+        int rc = ppp_gen_path_async(h);
+        return rc ? rc : ppp_get_path_async(h);
+    }
+    if (!h->graph_exec) {
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        int rc = ppp_gen_path_async(h);
+        if (rc == PPP_OK) rc = ppp_get_path_async(h);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(h->stream, &g);
+        if (rc != PPP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(h, PPP_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        h->graph = g;
+        e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { h->drop_graph(); return fail(h, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    }
+    HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+    h->index_built = true; h->gen_done = true; h->path_done = true;
+    h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
     return PPP_OK;
 }
 
@@ -585,6 +640,7 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
     HIPCHK(h, h->scratch.ensure(sizeof(int) * (size_t)capb));
     LAUNCH(h, "k_band_indices", k_band_indices, 1, 256, slice_lds_bytes(capb), h->sorted4.p, h->slab_start.p, h->meta.p, lo, hi,
            capb, (int *)h->scratch.p, capb);
+    h->meta_in_flight = false; /* the kernel above wrote meta: take a fresh copy */
     int rc = fetch_meta(h);
     if (rc) return rc;
     if (n) *n = (size_t)h->hmeta.api_cnt;
@@ -654,6 +710,7 @@ int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz)
     LAUNCH(h, "k_eval_api", k_eval_api, (unsigned)((k + 127) / 128), 128, 0, h->meta.p, h->px.p, h->node_y.p, h->node_z.p,
            h->node_start.p, h->node_cnt.p, s, dq, (int)k, dout);
     HIPCHK(h, hipMemcpyAsync(xyz, dout, k * 24, hipMemcpyDeviceToHost, h->stream));
+    h->meta_in_flight = false;
     rc = fetch_meta(h);
     if (rc) return rc;
     if (h->hmeta.api_flag == DERR_DOMAIN) return fail(h, PPP_ERR_DOMAIN, "y outside [miny, bigy] (GSL_EDOM)");
@@ -675,6 +732,7 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, 
     if (n) HIPCHK(h, hipMemcpyAsync(didx, indices, n * 4, hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "k_insert_api", k_insert_api, 1, 256, slice_lds_bytes(capb), h->X.p, h->Y.p, h->Z.p, (int)h->n, didx, (int)n, plane_x,
            h->P.pairing, capb, h->meta.p, dy, dz, capb);
+    h->meta_in_flight = false;
     int rc = fetch_meta(h);
     if (rc) return rc;
     if (h->hmeta.api_flag == DERR_SLICE) return fail(h, PPP_ERR_SLICE, "insert_point: empty right side (the reference crashes here)");

@@ -64,7 +64,7 @@ Config._fields_ = [
 
 EXPORTS = [
     "ppp_default_params", "ppp_create", "ppp_destroy", "ppp_last_error", "ppp_version", "ppp_set_params",
-    "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async",
+    "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async", "ppp_run_async",
     "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
     "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
@@ -110,6 +110,7 @@ def lib():
         L.ppp_num_points.argtypes = [vp, szp]
         L.ppp_gen_path_async.argtypes = [vp]
         L.ppp_get_path_async.argtypes = [vp]
+        L.ppp_run_async.argtypes = [vp]
         L.ppp_sync.argtypes = [vp]
         L.ppp_failed_slice.argtypes = [vp]
         L.ppp_num_slices.argtypes = [vp, ip]
@@ -262,6 +263,10 @@ class Engine:
 
     def get_path_async(self):
         self._chk(self.L.ppp_get_path_async(self.h))
+
+    def run_async(self):
+        """GenPath() + getPath() as one enqueue (captured hipGraph)."""
+        self._chk(self.L.ppp_run_async(self.h))
 
     def sync(self):
         self._chk(self.L.ppp_sync(self.h))

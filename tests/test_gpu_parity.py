@@ -329,3 +329,21 @@ def test_slice_walks_on_device_match_the_reference_loops(engine_mod, oracle_mod,
         e = engine_mod.Engine(0, tool_radius=R, walk=walk)
         e.set_cloud(pts)
         assert np.array_equal(e.slice_positions(), o.slice_positions()), (R, x0, walk)
+
+
+def test_run_async_graph_replay_matches_plain_calls(engine_mod):
+    pts, cfg = synth.make_config("small_40k")
+    a = engine_mod.Engine(0, tool_radius=6.0); a.set_cloud(pts); a.gen_path(); a.get_path()
+    want = a.waypoints().tobytes()
+    b = engine_mod.Engine(0, tool_radius=6.0); b.set_cloud(pts)
+    for _ in range(3):  # capture, then two replays
+        b.run_async(); b.sync()
+        assert b.waypoints().tobytes() == want
+    b.set_params(tool_radius=9.0)          # replans: the graph must be rebuilt
+    b.run_async(); b.sync()
+    c = engine_mod.Engine(0, tool_radius=9.0); c.set_cloud(pts); c.gen_path(); c.get_path()
+    assert b.waypoints().tobytes() == c.waypoints().tobytes()
+    pts2, _ = synth.make_config("tiny_5k")
+    b.set_cloud(pts2); b.run_async(); b.sync()  # new cloud: new plan, new graph
+    d = engine_mod.Engine(0, tool_radius=9.0); d.set_cloud(pts2); d.gen_path(); d.get_path()
+    assert b.waypoints().tobytes() == d.waypoints().tobytes()
