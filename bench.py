@@ -24,6 +24,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md "HBM3E peak BW"); 6290 GB/s measured copy
 
 
+def load_traffic(kernel, launches_per_pass, config):
+    """HBM bytes per pass of `kernel` from the newest committed PMC summary (profiles/*_traffic.json,
+    written by tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled
+    as MI355X_MICROARCH.md prescribes for gfx950).  None when no summary for this workload exists."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", "cfg2_1m_s256") == config and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["hbm_bytes_per_launch"] * launches_per_pass, os.path.basename(f))
+    return best if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,21 +130,28 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the engine's own stream ----
         eng.enable_timing(True)
-        acc = {}
+        acc, launches = {}, {}
         for _ in range(args.profile_passes):
             eng.gen_path_async()
             eng.get_path_async()
             eng.sync()
-            for k, v in eng.kernel_times().items():
+            kt, kl = eng.kernel_times(with_launches=True)
+            for k, v in kt.items():
                 acc.setdefault(k, []).append(v)
+            launches = kl
         eng.enable_timing(False)
-        kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+        kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}  # per pass, summed over that kernel's launches
         dom = max(kern_ms, key=kern_ms.get)
         w_one = float(w_all[0])
         alg_bytes = 12.0 * n_points + 24.0 * w_one  # SURVEY.md 8(d), per workpiece: xyz read once + waypoints written once
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), args.config)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "launches_per_pass": launches.get(dom, 1),
+                    "avg_launch_ms": kern_ms[dom] / max(1, launches.get(dom, 1)),
+                    "note": "one pass = one workpiece; kernel_ms are per pass (summed over a kernel's launches). "
+                            "12.6 MB of algorithmic traffic is 2 us at the HBM roof: this workload is launch/latency bound",
                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
                     "algorithmic_bytes": alg_bytes,
                     "pipeline_gbs": alg_bytes * args.batch / (elapsed / args.steps) / 1e9}

@@ -179,8 +179,9 @@ int ppp_write_path_file(const char *path, const float *wp6, size_t W);
 /* ---- measurement ---- */
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
 int ppp_enable_timing(ppp_handle h, int on);
-/* names: cap entries of 48 chars; ms: last recorded duration of each kernel */
-int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_t *n);
+/* names: cap entries of 48 chars; ms: time of each kernel since the last call, summed over its
+ * launches; launches (may be NULL): how many launches that sum covers */
+int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, int *launches, size_t cap, size_t *n);
 
 #ifdef __cplusplus
 }

@@ -835,7 +835,7 @@ int ppp_enable_timing(ppp_handle h, int on)
     return PPP_OK;
 }
 
-int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_t *n)
+int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, int *launches, size_t cap, size_t *n)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -850,6 +850,7 @@ int ppp_get_kernel_times(ppp_handle h, char *names, float *ms, size_t cap, size_
                 if (hipEventElapsedTime(&one, t.e0[q], t.e1[q]) == hipSuccess) v += one;
             }
             if (ms) ms[k] = v; /* sum over this kernel's launches since the last reset */
+            if (launches) launches[k] = t.used;
             if (names) { strncpy(names + 48 * k, t.name.c_str(), 47); names[48 * k + 47] = 0; }
         }
         ++k;

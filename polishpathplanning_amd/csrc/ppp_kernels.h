@@ -1227,7 +1227,7 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 #define SM_HB ((SM_D + 1) * SM_K + 1)
 #define SM_OWN (SM_M - SM_HB - SM_K)
 #define SM_MAXS 512
-#define SM_LDS_BYTES (3 * SM_M * (8 + 4 + 4 + 4))
+#define SM_LDS_BYTES (3 * SM_M * (8 + 4 + 4 + 4) + SM_K * SM_T * 8)
 
 __host__ __device__ inline int smooth_tiles(int W) { return W > 2 ? (W - 2 + SM_OWN - 1) / SM_OWN : 1; }
 /* snapshot set q (0/1), level k (1..SM_K), coordinate j: float[W_cap] */
@@ -1245,8 +1245,8 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
     float (*s_x)[SM_M] = (float (*)[SM_M])(s_raw + 3 * SM_M * 8);
     float (*s_a)[SM_M] = s_x + 3;
     float (*s_b)[SM_M] = s_a + 3;
+    double (*s_chg)[SM_T] = (double (*)[SM_T])(s_b + 3); /* per-thread |delta| sums of every sweep of the batch */
     __shared__ double s_change[SM_MAXS + 1];
-    __shared__ double s_red[2][SM_T / 64]; /* double-buffered by sweep parity */
     __shared__ int s_kstar;
     const int W = m->W;
     if (m->err || W == 0) return;
@@ -1365,19 +1365,24 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
                 }
             }
         }
-        change = wave_sum(change);
-        if ((threadIdx.x & 63) == 0) s_red[k & 1][threadIdx.x >> 6] = change;
-        lds_barrier(); /* also publishes nxt; the snapshot stores below stay in flight */
-        if (threadIdx.x == 0) {
-            double c = 0;
-            for (int w = 0; w < SM_T / 64; ++w) c += s_red[k & 1][w];
-            part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
-        }
+        s_chg[k - 1][threadIdx.x] = change; /* reduced once, after the last sweep (a block reduction per
+                                               sweep cost more than the sweep itself) */
+        lds_barrier(); /* publishes nxt; the snapshot stores below stay in flight */
         float (*t)[SM_M] = cur; cur = nxt; nxt = t;
         /* snapshot of level k (owned range; the last level is the next launch's input) */
         for (int j = 0; j < 3; ++j) {
             float *D = snap + smooth_snap_off(b & 1, k, j, W_cap);
             for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) D[g] = cur[j][g - base];
+        }
+    }
+    /* per-sweep sums of this tile, fixed summation order: one wave per sweep */
+    {
+        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int k = 1 + wid; k <= SM_K; k += nw) {
+            double c = 0;
+            for (int q = lane; q < SM_T; q += 64) c += s_chg[k - 1][q];
+            c = wave_sum(c);
+            if (lane == 0) part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
         }
     }
 }

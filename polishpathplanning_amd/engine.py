@@ -131,7 +131,7 @@ def lib():
         L.ppp_get_stage.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_smooth_sweeps.argtypes = [vp, ip]
         L.ppp_enable_timing.argtypes = [vp, C.c_int]
-        L.ppp_get_kernel_times.argtypes = [vp, C.c_char_p, fp, sz, szp]
+        L.ppp_get_kernel_times.argtypes = [vp, C.c_char_p, fp, ip, sz, szp]
         L.ppp_load_pcd.argtypes = [C.c_char_p, C.POINTER(fp), szp, fp]
         L.ppp_save_pcd.argtypes = [C.c_char_p, fp, sz, sz, fp, C.c_int]
         L.ppp_free.argtypes = [vp]
@@ -409,13 +409,17 @@ class Engine:
     def enable_timing(self, on=True):
         self._chk(self.L.ppp_enable_timing(self.h, 1 if on else 0))
 
-    def kernel_times(self):
+    def kernel_times(self, with_launches=False):
+        """{kernel: ms summed over its launches since the last call} (and {kernel: launches})."""
         cap = 64
         names = C.create_string_buffer(48 * cap)
         ms = np.zeros(cap, np.float32)
+        cnt = np.zeros(cap, np.int32)
         n = C.c_size_t()
-        self._chk(self.L.ppp_get_kernel_times(self.h, names, _f(ms), cap, C.byref(n)))
-        out = {}
+        self._chk(self.L.ppp_get_kernel_times(self.h, names, _f(ms), _i(cnt), cap, C.byref(n)))
+        out, launches = {}, {}
         for k in range(n.value):
-            out[names.raw[48 * k:48 * k + 48].split(b"\0", 1)[0].decode()] = float(ms[k])
-        return out
+            nm = names.raw[48 * k:48 * k + 48].split(b"\0", 1)[0].decode()
+            out[nm] = float(ms[k])
+            launches[nm] = int(cnt[k])
+        return (out, launches) if with_launches else out
