@@ -111,6 +111,24 @@ __device__ inline void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* In-kernel phase stamps, DIAGNOSTIC BUILD ONLY (make stamps -> libppp_hip_stamps.so): thread 0
+   of the middle workgroup accumulates s_memtime deltas per (kernel, slot).  In the product build
+   the macros expand to nothing, so no stamp executes and no output depends on one. */
+#ifdef PPP_STAMPS
+__device__ unsigned long long g_stamps[16][16];
+__device__ inline unsigned long long ppp_stamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP_BEGIN() const bool _st_on = (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0); unsigned long long _st_t = ppp_stamp()
+#define STAMP(kid, slot) do { unsigned long long _n = ppp_stamp(); if (_st_on) g_stamps[kid][slot] += _n - _st_t; _st_t = _n; } while (0)
+#else
+#define STAMP_BEGIN() do { } while (0)
+#define STAMP(kid, slot) do { } while (0)
+#endif
+
 /* ---- block-wide helpers (blockDim.x multiple of 64, <= 1024) ---- */
 template <typename T>
 __device__ inline T wave_sum(T v)

@@ -187,7 +187,7 @@ int make_plan(ppp_handle h)
         while (cap < 4096 && cap < 1.5 * mean) cap <<= 1;
         h->slab_cap = cap;
     }
-    h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 512));
+    h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
     HIPCHK(h, h->mm_part.ensure(h->mm_grid));
     /* exact slice count from the cached bounds (the device recomputes the same walk) */
     int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
@@ -243,7 +243,10 @@ int enqueue_index(ppp_handle h)
     int gh = std::max(1, std::min((n + 256 * 16 - 1) / (256 * 16), 1024));
     LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, h->meta.p, h->slab_cnt.p);
     LAUNCH(h, "k_slab_scan", k_slab_scan, 1, 1024, 0, h->slab_cnt.p, h->slab_start.p, h->slab_cursor.p, h->B);
+    /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
+       atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
     int chunk = 4096;
+    while (chunk < 32768 && (n + chunk - 1) / chunk > 768) chunk <<= 1;
     int gs = std::max(1, (n + chunk - 1) / chunk);
     LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
            h->slab_cursor.p, h->unsorted4.p);
@@ -330,7 +333,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     }
     /* cache the bounds for the plan (sizing only; the hot path recomputes them on device) */
     {
-        int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 512));
+        int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
         HIPCHK(h, h->mm_part.ensure(g));
         hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p);
         HIPCHK(h, hipGetLastError());
@@ -818,6 +821,16 @@ int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *
     HIPCHK(h, hipMemcpy(out, src, std::min(cap_bytes, W * elem), hipMemcpyDeviceToHost));
     return PPP_OK;
 }
+
+#ifdef PPP_STAMPS
+/* diagnostic build only: 16 x 16 accumulated s_memtime deltas, then reset */
+extern "C" int ppp_dbg_stamps(unsigned long long *out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 256) != hipSuccess) return PPP_ERR_HIP;
+    static const unsigned long long zero[256] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero)) == hipSuccess ? PPP_OK : PPP_ERR_HIP;
+}
+#endif
 
 int ppp_smooth_sweeps(ppp_handle h, int *sweeps)
 {

@@ -299,8 +299,10 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     const int B = m->B;
+    STAMP_BEGIN();
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
+    STAMP(2, 0); /* zero */
     const int i0 = blockIdx.x * chunk;
     const int i1 = min(n, i0 + chunk);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
@@ -308,11 +310,13 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
         if (x == x) atomicAdd(&s_hist[slab_of(m, x)], 1);
     }
     __syncthreads();
+    STAMP(2, 1); /* count */
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         int c = s_hist[b];
         if (c) s_hist[b] = atomicAdd(&slab_cursor[b], c);
     }
     __syncthreads();
+    STAMP(2, 2); /* reserve (global atomics) */
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         float x = X[i];
         if (x == x) {
@@ -320,6 +324,7 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
             unsorted4[pos] = make_float4(x, Y[i], Z[i], __int_as_float(i));
         }
     }
+    STAMP(2, 3); /* scatter */
 }
 
 /* one workgroup per slab: exact LDS bucket sort on (y, cloud index) -- buckets are uniform in y
@@ -714,6 +719,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
     const int s = blockIdx.x;
     if (s >= m->S) return;
     SliceKdLds L = carve_slice_kd_lds(s_raw, capb);
+    STAMP_BEGIN();
     const float Px = px[s], blo = lo[s], bhi = hi[s];
     if (threadIdx.x == 0) { s_n = 0; s_plane = 0; s_ner = 0; s_m = 0; }
     __syncthreads();
@@ -733,6 +739,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         }
     }
     __syncthreads();
+    STAMP(0, 0); /* band gather */
     const int n = s_n;
     if (threadIdx.x == 0) band_cnt[s] = n + s_plane;
     if (n > capb) {
@@ -762,6 +769,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         if ((threadIdx.x & 63) == 0 && ner) atomicAdd(&s_ner, ner);
         block_bucket_sort(L.keys, n, L.hist_band, 2 * NBh, s_scr, gen, bucket, less);
     }
+    STAMP(0, 1); /* band sort */
     const int nEr = s_ner, nEl = n - nEr;
     if (nEl == 0 || nEr == 0) {
         /* empty left side: empty map -> < 3 knots; empty right side: empty FLANN tree */
@@ -781,6 +789,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         L.cy[i] = y; L.cz[i] = z; L.cidx[i] = idx_of(q);
     }
     __syncthreads(); /* the band (a4, keys) is dead from here: ckeys / hist_cand reuse it */
+    STAMP(0, 2); /* nearest neighbours + lerp */
     {   /* sort the node candidates by y */
         const int NBc = next_pow2(max(nEl, 64));
         const float scale = yr > 0.f ? (float)NBc / yr : 0.f;
@@ -792,6 +801,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         auto less = [&](u64 a, u64 bb) { return a < bb; };
         block_bucket_sort(L.ckeys, nEl, L.hist_cand, NBc, s_scr, gen, bucket, less);
     }
+    STAMP(0, 3); /* candidate sort */
     /* std::map semantics: one node per distinct y.  Node[y] = ... is overwritten by every later
        writer and El is walked in ascending cloud index, so the value kept is the one written by
        the candidate with the highest cloud index inside the run of equal keys. */
@@ -836,6 +846,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         if (threadIdx.x == 0) s_m = o + t2;
         __syncthreads();
     }
+    STAMP(0, 4); /* map flattening + node write */
 }
 
 /* API mirrors: rangedX_index(position) and insert_point(indices, plane) on one workgroup */
@@ -1115,6 +1126,7 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
     const int st = node_start[s], mm = node_cnt[s], cnt = wp_cnt[k], off = wp_off[k];
     if (cnt == 0) return;
     const float Px = px[s];
+    STAMP_BEGIN();
     /* slabs to stage: widest symmetric range around the plane's slab that fits */
     int bL = slab_of(m, Px - POSE_PAD), bR = slab_of(m, Px + POSE_PAD);
     while (slab_start[bR + 1] - slab_start[bL] > POSE_STAGE_CAP && bL < bR) {
@@ -1128,6 +1140,7 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
     if (nodes_in_lds)
         for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; }
     __syncthreads();
+    STAMP(1, 0); /* staging */
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
     const float *ny = nodes_in_lds ? s_ny : node_y + st, *nz = nodes_in_lds ? s_nz : node_z + st;
     const double Pxd = (double)Px;
@@ -1145,13 +1158,16 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
         const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
         const float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
         wp_xyz[w] = q;
+        STAMP(1, 1); /* dy accumulation + spline */
         float wp[6];
         float n4[4];
         int id = -1;
         if (q.x == q.x && q.y == q.y && q.z == q.z) {
             float4 p;
             id = nearest_in_slabs(V, q.x, q.y, q.z, &p);
+            STAMP(1, 2); /* nearest */
             if (id >= 0) normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
+            STAMP(1, 3); /* normal */
         }
         if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
         float rpy[3];
@@ -1160,6 +1176,7 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
         else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
         wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
         handeye_transform(P.handeye, wp);
+        STAMP(1, 4); /* pose + hand-eye */
         wp_nn[w] = id;
         wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
         for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];

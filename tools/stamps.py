@@ -1,0 +1,23 @@
+"""Developer tool: per-phase s_memtime shares of the instrumented kernels (diagnostic build,
+`make -C polishpathplanning_amd/csrc stamps`).  Read the SHARES, not the absolute times: the
+stamps serialise what the product build overlaps."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polishpathplanning_amd import engine, synth
+engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libppp_hip_stamps.so")
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_1m_s256"
+pts, cfg = synth.make_config(name)
+e = engine.Engine(0, tool_radius=cfg["tool_radius"]); e.set_cloud(pts)
+out = (C.c_ulonglong * 256)()
+e.gen_path(); e.get_path(); engine.lib().ppp_dbg_stamps(out)  # warm-up + reset
+N = 10
+for _ in range(N):
+    e.gen_path_async(); e.get_path_async()
+e.sync(); engine.lib().ppp_dbg_stamps(out)
+labels = {0: ("k_slice_kd", ["gather", "band sort", "NN+lerp", "cand sort", "flatten"]),
+          1: ("k_pose", ["staging", "dy+spline", "nearest", "normal", "pose+handeye"]),
+          2: ("k_slab_scatter", ["zero", "count", "reserve", "scatter"])}
+for kid, (kn, ls) in labels.items():
+    vals = [out[16 * kid + i] / N for i in range(len(ls))]
+    tot = sum(vals) or 1
+    print("%-16s total %8.0f ticks (%.1f us): " % (kn, tot, tot / 2400.0) + "  ".join("%s %.0f%%" % (l, 100 * v / tot) for l, v in zip(ls, vals)))
