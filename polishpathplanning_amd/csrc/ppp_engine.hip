@@ -73,6 +73,9 @@ struct ppp_handle_s {
     DevBuf<int> wp_nn;
     DevBuf<float> wp_pre, wp_smooth, wp_out, sx, snap;
     DevBuf<MinMaxPart> mm_part;
+    DevBuf<int> big_slabs, big_slices; /* work lists of the LDS-overflow fallback kernels */
+    DevBuf<char> arena;                /* their global scratch, allocated on first need */
+    bool big_path = false;             /* launch the fallback kernels (set by the plan or after an overflow) */
     DevBuf<double> sm_part, sm_chist;
     int mm_grid = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
@@ -99,7 +102,7 @@ struct ppp_handle_s {
         meta.release(); px.release(); lo.release(); hi.release(); node_y.release(); node_z.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
-        sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); scratch.release();
+        sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
         drop_graph();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
@@ -179,7 +182,7 @@ int make_plan(ppp_handle h)
     const int n = (int)h->n;
     /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS */
     int B = (h->h_nvalid + 639) / 640;
-    B = std::max(1, std::min(B, 8192));
+    B = std::max(1, std::min(B, 16384));
     h->B = B;
     {
         double mean = (double)h->h_nvalid / B;
@@ -187,18 +190,23 @@ int make_plan(ppp_handle h)
         while (cap < 4096 && cap < 1.5 * mean) cap <<= 1;
         h->slab_cap = cap;
     }
+    HIPCHK(h, h->big_slabs.ensure(B));
     h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
     HIPCHK(h, h->mm_part.ensure(h->mm_grid));
     /* exact slice count from the cached bounds (the device recomputes the same walk) */
     int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
     if (S >= PPP_WALK_HARD_MAX) return fail(h, PPP_ERR_CAPACITY, "slice walk does not terminate");
     h->S_cap = std::max(1, S);
+    HIPCHK(h, h->big_slices.ensure(h->S_cap));
     /* band capacity: expected points in a 4 mm band, x2 margin, power of two in [1024, 4096] */
     double range = (double)h->h_mx[0] - (double)h->h_mn[0];
     double expect = range > 0 ? (double)h->h_nvalid * 4.0 / range : (double)h->h_nvalid;
     int capb = 1024;
     while (capb < 4096 && capb < 2.0 * expect) capb <<= 1;
     h->capb = capb;
+    /* slabs or bands that may not fit LDS: also run the arena passes (a later overflow turns them on too) */
+    if (2.0 * expect > 4096 || 1.5 * (double)h->h_nvalid / B > 4096) h->big_path = true;
+    if (h->big_path) HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max(n, 1) + (1u << 20)));
     /* waypoints: every kept slice samples at most (yrange - 2 trim)/res + 1 points */
     double yr = (double)h->h_mx[1] - (double)h->h_mn[1];
     double per = std::max(0.0, (yr - 2 * h->P.trim)) / h->P.path_resolution + 2.0;
@@ -251,8 +259,11 @@ int enqueue_index(ppp_handle h)
     LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
            h->slab_cursor.p, h->unsorted4.p);
     size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
-    LAUNCH(h, "k_slab_sort", k_slab_sort, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap);
+    LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
+    if (h->big_path)
+        LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, 256, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
     h->index_built = true;
     return PPP_OK;
 }
@@ -279,6 +290,8 @@ int enqueue_meta_copy(ppp_handle h)
 
 int map_dev_err(ppp_handle h)
 {
+    if (h->hmeta.err == DERR_CAPACITY && !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0))
+        return fail(h, PPP_ERR_CAPACITY, "a slab or band exceeds the LDS capacity: re-run (the arena passes are now enabled)");
     switch (h->hmeta.err) {
     case DERR_NONE: return PPP_OK;
     case DERR_SLICE: {
@@ -293,6 +306,25 @@ int map_dev_err(ppp_handle h)
     return fail(h, PPP_ERR_HIP, "unknown device error");
 }
 
+/* An overflow of the LDS-resident fast path is not an error of the input: turn the arena passes on
+   and run the same calls again, once. */
+int rerun_with_arena(ppp_handle h)
+{
+    const bool had_path = h->path_done;
+    h->big_path = true;
+    h->drop_graph();
+    HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max<size_t>(h->n, 1) + (1u << 20)));
+    int rc = ppp_gen_path_async(h);
+    if (rc == PPP_OK && had_path) rc = ppp_get_path_async(h);
+    if (rc) return rc;
+    return fetch_meta(h);
+}
+
+bool overflowed_fast_path(ppp_handle h)
+{
+    return h->hmeta.err == DERR_CAPACITY && !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0);
+}
+
 int ensure_ready(ppp_handle h, bool need_gen, bool need_path)
 {
     if (!h) return PPP_ERR_ARG;
@@ -302,6 +334,7 @@ int ensure_ready(ppp_handle h, bool need_gen, bool need_path)
     if (need_path && !h->path_done) return fail(h, PPP_ERR_ARG, "call ppp_get_path_async first");
     int rc = fetch_meta(h);
     if (rc) return rc;
+    if (overflowed_fast_path(h)) return rerun_with_arena(h);
     return PPP_OK;
 }
 
@@ -317,7 +350,7 @@ int ensure_index(ppp_handle h)
 
 int slice_lds_ok(ppp_handle h, int capb)
 {
-    return std::max(slice_lds_bytes(capb), slice_kd_lds_bytes(capb)) + 1024 <= (size_t)h->max_lds;
+    return std::max(slice_lds_bytes(capb), slice_kd_bytes(capb)) + 1024 <= (size_t)h->max_lds;
 }
 
 int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
@@ -393,7 +426,9 @@ int ppp_create(int device_id, ppp_handle *out)
         h->max_lds = std::max(h->max_lds, 160 * 1024); /* CDNA4: one workgroup may own the CU's whole LDS */
     /* kernels with > 64 KiB of dynamic LDS opt in explicitly */
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_slice_kd, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_slice_kd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_slab_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
     (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
@@ -459,9 +494,13 @@ int ppp_gen_path_async(ppp_handle h)
     int rc = enqueue_index(h);
     if (rc) return rc;
     if (h->P.pairing == PPP_PAIR_KD) {
-        LAUNCH(h, "k_slice_kd", k_slice_kd, h->S_cap, 256, slice_kd_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
+        LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, 256, slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
                h->px.p, h->lo.p, h->hi.p, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
-               h->band_cnt.p);
+               h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
+        if (h->big_path)
+            LAUNCH(h, "k_slice_kd_arena", k_slice_kd<true>, h->S_cap, 256, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+                   h->lo.p, h->hi.p, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+                   h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
     } else {
         LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
@@ -479,7 +518,7 @@ int ppp_get_path_async(ppp_handle h)
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
     DevParams D = dev_params(h);
     LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
-           h->wp_off.p, h->tail.p, h->W_cap);
+           h->wp_off.p, h->tail.p, h->W_cap, h->big_path ? 1 : 0);
     int nk = std::max(1, h->S_cap);
     int gw = std::max(1, (h->W_cap + 63) / 64);
     LAUNCH(h, "k_pose", k_pose, nk, 256, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
@@ -531,6 +570,10 @@ int ppp_sync(ppp_handle h)
     HIPCHK(h, hipSetDevice(h->device));
     int rc = fetch_meta(h);
     if (rc) return rc;
+    if (overflowed_fast_path(h)) {
+        rc = rerun_with_arena(h);
+        if (rc) return rc;
+    }
     return map_dev_err(h);
 }
 
@@ -646,11 +689,29 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
     h->meta_in_flight = false; /* the kernel above wrote meta: take a fresh copy */
     int rc = fetch_meta(h);
     if (rc) return rc;
+    const int *src = (const int *)h->scratch.p;
+    if (h->hmeta.api_flag) {
+        /* the band does not fit LDS: same answer from global scratch sized by the count just learned */
+        const size_t cnt = (size_t)h->hmeta.api_cnt;
+        const int NB = next_pow2((int)std::min<size_t>(cnt, 1u << 20));
+        const size_t bytes = cnt * 4 + 16 + cnt * 8 * 2 + ((size_t)NB + 1) * 4 + 64;
+        HIPCHK(h, h->scratch.ensure(bytes));
+        int *dout = (int *)h->scratch.p;
+        u64 *tmp = (u64 *)(h->scratch.p + ((cnt * 4 + 15) & ~(size_t)15));
+        u64 *srt = tmp + cnt;
+        int *hist = (int *)(srt + cnt);
+        LAUNCH(h, "k_band_indices_big", k_band_indices_big, 1, 256, 0, h->sorted4.p, h->slab_start.p, h->meta.p, lo, hi, (int)h->n, tmp,
+               srt, hist, NB, (int)cnt, dout);
+        h->meta_in_flight = false;
+        rc = fetch_meta(h);
+        if (rc) return rc;
+        if (h->hmeta.api_flag) return fail(h, PPP_ERR_CAPACITY, "rangedX_index: band changed size between passes");
+        src = dout;
+    }
     if (n) *n = (size_t)h->hmeta.api_cnt;
-    if (h->hmeta.api_flag) return fail(h, PPP_ERR_CAPACITY, "band larger than the LDS capacity (4096 points)");
     if (out && cap) {
         size_t k = std::min(cap, (size_t)h->hmeta.api_cnt);
-        if (k) HIPCHK(h, hipMemcpy(out, h->scratch.p, k * sizeof(int), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, hipMemcpy(out, src, k * sizeof(int), hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }

@@ -24,6 +24,8 @@ struct DevMeta {
     int sweeps, any_short, rpy_oob;
     int node_cursor;
     int smooth_done;
+    int big_slabs, big_slices;   /* work lists of the LDS-overflow fallback kernels */
+    unsigned long long arena_cursor; /* bump allocator of the global arena those kernels use */
     int B;
     float slab_x0, slab_invw;
     int api_cnt, api_flag;
@@ -68,6 +70,11 @@ __global__ void k_ingest(const char *raw, size_t stride, int n, int scale, float
     if (!(isfinite(x) && isfinite(y) && isfinite(z))) { x = y = z = __int_as_float(0x7fc00000); }
     X[i] = x; Y[i] = y; Z[i] = z;
 }
+
+/* sort keys: [63] side, [62:31] order-preserving bits of y, [30:0] position */
+#define YK_MAKE(y, pos) (((u64)f2ord(y) << 31) | (u64)(u32)(pos))
+#define YK_Y(k) ((u32)(((k) >> 31) & 0xffffffffu))
+#define YK_POS(k) ((int)((k) & 0x7fffffffu))
 
 struct MinMaxPart { float mn[3], mx[3]; int cnt, pad; };
 
@@ -231,6 +238,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         r.n_valid = c;
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
         r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1;
+        r.big_slabs = 0; r.big_slices = 0; r.arena_cursor = 0;
         int S = c ? slice_walk_device(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap, s_front, 4096) : 0;
         if (S > S_cap) { r.err = DERR_CAPACITY; S = S_cap; }
         r.S = S;
@@ -327,41 +335,64 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
     STAMP(2, 3); /* scatter */
 }
 
-/* one workgroup per slab: exact LDS bucket sort on (y, cloud index) -- buckets are uniform in y
-   over the cloud's y range --, then the exact x bounds of the slab */
+/* One workgroup per slab: exact bucket sort on (y, cloud index) -- buckets are uniform in y over
+   the cloud's y range --, then the exact x bounds of the slab.  ARENA = false: keys and histogram
+   in LDS, slabs larger than `cap` are appended to a work list; ARENA = true: second pass over that
+   list with the same code on a bump-allocated global arena (any slab size, slower). */
+template <bool ARENA>
 __global__ void __launch_bounds__(256) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
-                                                   float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap)
+                                                   float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
+                                                   int *big_list, char *arena, unsigned long long arena_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    u64 *key = (u64 *)s_raw;            /* cap entries: (ord(y) << 16) | position in the unsorted slab */
-    int *hist = (int *)(key + cap);     /* cap + 1 buckets */
     __shared__ float s_mn[4], s_mx[4];
     __shared__ int s_scr[17];
-    const int b = blockIdx.x;
+    __shared__ unsigned long long s_off;
+    int b = blockIdx.x;
+    if (ARENA) {
+        if (b >= m->big_slabs) return;
+        b = big_list[b];
+    }
     const int s0 = slab_start[b], c = slab_start[b + 1] - s0;
+    u64 *key;
+    int *hist;
+    int NB;
+    if (ARENA) {
+        NB = next_pow2(c);
+        const unsigned long long need = (unsigned long long)c * 8 + (unsigned long long)(NB + 1) * 4 + 16;
+        if (threadIdx.x == 0) s_off = atomicAdd(&m->arena_cursor, (need + 15) & ~15ull);
+        __syncthreads();
+        if (s_off + need > arena_cap) { if (threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1); return; }
+        key = (u64 *)(arena + s_off);
+        hist = (int *)(key + c);
+    } else {
+        if (c > cap) {
+            if (threadIdx.x == 0) big_list[atomicAdd(&m->big_slabs, 1)] = b;
+            return;
+        }
+        NB = min(cap, next_pow2(c));
+        key = (u64 *)s_raw;
+        hist = (int *)(key + cap);
+    }
     float mn = INFINITY, mx = -INFINITY;
-    if (c > cap) {
-        if (threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
-        for (int i = threadIdx.x; i < c; i += blockDim.x) sorted4[s0 + i] = unsorted4[s0 + i];
-    } else if (c > 0) {
-        const int NB = min(cap, next_pow2(c));
+    if (c > 0) {
         const float y0 = m->mn[1];
         const float yr = m->mx[1] - y0;
         const float scale = yr > 0.f ? (float)NB / yr : 0.f;
         const float4 *src = unsorted4 + s0;
-        auto gen = [&](int i) { return ((u64)f2ord(src[i].y) << 16) | (u64)i; };
+        auto gen = [&](int i) { return YK_MAKE(src[i].y, i); };
         auto bucket = [&](u64 k) {
-            int q = (int)((ord2f((u32)(k >> 16)) - y0) * scale);
+            int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
             return q < 0 ? 0 : (q >= NB ? NB - 1 : q);
         };
         auto less = [&](u64 a, u64 bb) {
-            u32 ya = (u32)(a >> 16), yb = (u32)(bb >> 16);
+            u32 ya = YK_Y(a), yb = YK_Y(bb);
             if (ya != yb) return ya < yb;
-            return idx_of(src[(int)(a & 0xffffu)]) < idx_of(src[(int)(bb & 0xffffu)]); /* equal y: cloud index */
+            return idx_of(src[YK_POS(a)]) < idx_of(src[YK_POS(bb)]); /* equal y: cloud index */
         };
         block_bucket_sort(key, c, hist, NB, s_scr, gen, bucket, less);
         for (int i = threadIdx.x; i < c; i += blockDim.x) {
-            float4 p = src[(int)(key[i] & 0xffffu)];
+            float4 p = src[YK_POS(key[i])];
             sorted4[s0 + i] = p;
             mn = fminf(mn, p.x); mx = fmaxf(mx, p.x);
         }
@@ -651,9 +682,9 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
 /* best distance).  El order only matters through the map's last-writer */
 /* rule, which is carried as the query's cloud index in the sort key.   */
 /* ------------------------------------------------------------------ */
-struct SliceKdLds {
+struct SliceKdMem {
     float4 *a4;  /* band points                                              (dead after the NN phase) */
-    u64 *keys;   /* band sorted by (side, y): (side<<63)|(ord(y)<<16)|slot   (dead after the NN phase) */
+    u64 *keys;   /* band sorted by (side, y): (side<<63) | YK_MAKE(y, slot)  (dead after the NN phase) */
     float *cy, *cz; /* node candidate of the i-th left point: y, z */
     int *cidx;      /* ... and the cloud index of that left point  */
     /* aliases: */
@@ -661,22 +692,21 @@ struct SliceKdLds {
     u64 *ckeys;     /* over a4 once the candidates exist             */
     int *hist_cand; /* behind ckeys                                   */
 };
-__host__ __device__ inline size_t slice_kd_lds_bytes(int capb) { return (size_t)capb * (16 + 8 + 12) + 64; }
-__device__ inline SliceKdLds carve_slice_kd_lds(char *raw, int capb)
+__host__ __device__ inline size_t slice_kd_bytes(size_t capb) { return capb * (16 + 8 + 12) + 64; }
+__device__ inline SliceKdMem carve_slice_kd(char *raw, size_t capb)
 {
-    SliceKdLds L;
+    SliceKdMem L;
     L.a4 = (float4 *)raw;
     L.keys = (u64 *)(L.a4 + capb);
     L.cy = (float *)(L.keys + capb);
     L.cz = L.cy + capb;
     L.cidx = (int *)(L.cz + capb);
-    L.hist_band = (int *)L.cy;            /* needs capb + 1 ints <= 3 capb */
-    L.ckeys = (u64 *)L.a4;                /* capb keys = half of a4        */
-    L.hist_cand = (int *)(L.ckeys + capb); /* capb + 1 ints, second half    */
+    L.hist_band = (int *)L.cy;            /* <= capb + 1 ints of the 3 capb available */
+    L.ckeys = (u64 *)L.a4;                /* capb keys = half of a4                    */
+    L.hist_cand = (int *)(L.ckeys + capb); /* <= capb + 1 ints, second half of a4 (+ pad) */
     return L;
 }
-#define KD_Y(k) ((u32)((k) >> 16))
-#define KD_POS(k) ((int)((k) & 0xffffu))
+#define KD_SIDE (1ull << 63)
 
 /* nearest point of keys[a..b) (one side, ascending y) to q; ties -> lowest cloud index */
 __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, int b, const float4 q)
@@ -685,12 +715,12 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
     int lo = a, hi = b;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
-        if (KD_Y(keys[mid]) < ty) lo = mid + 1; else hi = mid;
+        if (YK_Y(keys[mid]) < ty) lo = mid + 1; else hi = mid;
     }
     float best = INFINITY;
     int bidx = 0x7fffffff, bj = a;
     for (int i = lo; i < b; ++i) {
-        const float4 c = a4[KD_POS(keys[i])];
+        const float4 c = a4[YK_POS(keys[i])];
         float dy = q.y - c.y;
         if (dy * dy > best) break;
         float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
@@ -698,7 +728,7 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
         if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
     }
     for (int i = lo - 1; i >= a; --i) {
-        const float4 c = a4[KD_POS(keys[i])];
+        const float4 c = a4[YK_POS(keys[i])];
         float dy = q.y - c.y;
         if (dy * dy > best) break;
         float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
@@ -708,43 +738,64 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
     return bj;
 }
 
+/* ARENA = false: the band lives in LDS (capb points); a slice whose band does not fit is appended
+   to a work list.  ARENA = true: second pass over that list, same code on a global arena. */
+template <bool ARENA>
 __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                   DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
-                                                  const float *__restrict__ hi, int capb, float *node_y, float *node_z,
-                                                  int node_cap, int *node_start, int *node_cnt, int *band_cnt)
+                                                  const float *__restrict__ hi, int capb_lds, float *node_y, float *node_z,
+                                                  int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
+                                                  char *arena, unsigned long long arena_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
     __shared__ int s_n, s_plane, s_ner, s_base, s_m;
-    const int s = blockIdx.x;
-    if (s >= m->S) return;
-    SliceKdLds L = carve_slice_kd_lds(s_raw, capb);
+    __shared__ unsigned long long s_off;
+    int s = blockIdx.x;
+    if (ARENA) {
+        if (s >= m->big_slices) return;
+        s = big_list[s];
+    } else if (s >= m->S) return;
     STAMP_BEGIN();
     const float Px = px[s], blo = lo[s], bhi = hi[s];
+    const int b0 = slab_of(m, blo), b1 = slab_of(m, bhi);
+    const int i0 = slab_start[b0], i1 = slab_start[b1 + 1];
+    size_t capb = (size_t)capb_lds;
+    char *mem = s_raw;
+    if (ARENA) { /* size the arena segment from the band count of the first pass */
+        capb = (size_t)band_cnt[s];
+        const unsigned long long need = slice_kd_bytes(capb);
+        if (threadIdx.x == 0) s_off = atomicAdd(&m->arena_cursor, (need + 15) & ~15ull);
+        __syncthreads();
+        if (s_off + need > arena_cap) {
+            if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
+            return;
+        }
+        mem = arena + s_off;
+    }
+    SliceKdMem L = carve_slice_kd(mem, capb);
     if (threadIdx.x == 0) { s_n = 0; s_plane = 0; s_ner = 0; s_m = 0; }
     __syncthreads();
     /* rangedX_index: the PassThrough band, minus points exactly on the plane (neither side) */
-    {
-        const int b0 = slab_of(m, blo), b1 = slab_of(m, bhi);
-        const int i0 = slab_start[b0], i1 = slab_start[b1 + 1];
-        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-            float4 p = sorted4[i];
-            if (!(p.x < blo || p.x > bhi)) {
-                float distance2plane = (p.x - Px) * 1.f + (p.y - 0.f) * 0.f + (p.z - 0.f) * 0.f;
-                if (distance2plane > 0 || distance2plane < 0) {
-                    int slot = atomicAdd(&s_n, 1);
-                    if (slot < capb) L.a4[slot] = p;
-                } else atomicAdd(&s_plane, 1);
-            }
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        float4 p = sorted4[i];
+        if (!(p.x < blo || p.x > bhi)) {
+            float distance2plane = (p.x - Px) * 1.f + (p.y - 0.f) * 0.f + (p.z - 0.f) * 0.f;
+            if (distance2plane > 0 || distance2plane < 0) {
+                int slot = atomicAdd(&s_n, 1);
+                if ((size_t)slot < capb) L.a4[slot] = p;
+            } else atomicAdd(&s_plane, 1);
         }
     }
     __syncthreads();
     STAMP(0, 0); /* band gather */
     const int n = s_n;
-    if (threadIdx.x == 0) band_cnt[s] = n + s_plane;
-    if (n > capb) {
-        if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
-        return;
+    if (!ARENA) {
+        if (threadIdx.x == 0) band_cnt[s] = n + s_plane;
+        if ((size_t)n > capb) { /* does not fit LDS: leave it to the arena pass */
+            if (threadIdx.x == 0) { big_list[atomicAdd(&m->big_slices, 1)] = s; node_start[s] = 0; node_cnt[s] = 0; }
+            return;
+        }
     }
     /* sort the band by (side, y): Er first, then El, ascending y inside each */
     const float y0 = m->mn[1];
@@ -754,13 +805,12 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         const float scale = yr > 0.f ? (float)NBh / yr : 0.f;
         auto gen = [&](int i) {
             float4 p = L.a4[i];
-            u64 side = (p.x - Px) > 0 ? 1ull : 0ull; /* 1 = El (left, x > Px), 0 = Er */
-            return (side << 63) | ((u64)f2ord(p.y) << 16) | (u64)i;
+            return ((p.x - Px) > 0 ? KD_SIDE : 0ull) | YK_MAKE(p.y, i); /* side 1 = El (left, x > Px), 0 = Er */
         };
         auto bucket = [&](u64 k) {
-            int q = (int)((ord2f(KD_Y(k)) - y0) * scale);
+            int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
             q = q < 0 ? 0 : (q >= NBh ? NBh - 1 : q);
-            return q + ((k >> 63) ? NBh : 0);
+            return q + ((k & KD_SIDE) ? NBh : 0);
         };
         auto less = [&](u64 a, u64 bb) { return a < bb; };
         int ner = 0;
@@ -776,26 +826,32 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         if (threadIdx.x == 0) { set_err(m, DERR_SLICE, s); node_start[s] = 0; node_cnt[s] = 0; }
         return;
     }
-    for (int i = threadIdx.x; i < nEl; i += blockDim.x) {
-        const float4 q = L.a4[KD_POS(L.keys[nEr + i])];
-        const int jr = nn_sorted_side(L.keys, L.a4, 0, nEr, q);
-        const float4 R = L.a4[KD_POS(L.keys[jr])];
-        const int jl = nn_sorted_side(L.keys, L.a4, nEr, n, R);
-        const float4 Lp = L.a4[KD_POS(L.keys[jl])];
-        float t = (Px - R.x) / (Lp.x - R.x);
-        float y = R.y + t * (Lp.y - R.y);
-        float z = R.z + t * (Lp.z - R.z);
-        if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
-        L.cy[i] = y; L.cz[i] = z; L.cidx[i] = idx_of(q);
+    for (int i0q = 0; i0q < nEl; i0q += blockDim.x) {
+        const int i = i0q + threadIdx.x;
+        float y = 0.f, z = 0.f;
+        int qi = 0;
+        if (i < nEl) {
+            const float4 q = L.a4[YK_POS(L.keys[nEr + i])];
+            const int jr = nn_sorted_side(L.keys, L.a4, 0, nEr, q);
+            const float4 R = L.a4[YK_POS(L.keys[jr])];
+            const int jl = nn_sorted_side(L.keys, L.a4, nEr, n, R);
+            const float4 Lp = L.a4[YK_POS(L.keys[jl])];
+            float t = (Px - R.x) / (Lp.x - R.x);
+            y = R.y + t * (Lp.y - R.y);
+            z = R.z + t * (Lp.z - R.z);
+            if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
+            qi = idx_of(q);
+        }
+        if (i < nEl) { L.cy[i] = y; L.cz[i] = z; L.cidx[i] = qi; }
     }
     __syncthreads(); /* the band (a4, keys) is dead from here: ckeys / hist_cand reuse it */
     STAMP(0, 2); /* nearest neighbours + lerp */
     {   /* sort the node candidates by y */
         const int NBc = next_pow2(max(nEl, 64));
         const float scale = yr > 0.f ? (float)NBc / yr : 0.f;
-        auto gen = [&](int i) { return ((u64)f2ord(L.cy[i]) << 16) | (u64)i; };
+        auto gen = [&](int i) { return YK_MAKE(L.cy[i], i); };
         auto bucket = [&](u64 k) {
-            int q = (int)((ord2f((u32)(k >> 16)) - y0) * scale);
+            int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
             return q < 0 ? 0 : (q >= NBc ? NBc - 1 : q);
         };
         auto less = [&](u64 a, u64 bb) { return a < bb; };
@@ -807,7 +863,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
        the candidate with the highest cloud index inside the run of equal keys. */
     int mcount = 0;
     for (int j = threadIdx.x; j < nEl; j += blockDim.x)
-        mcount += (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 16) != (u32)(L.ckeys[j] >> 16));
+        mcount += (j == nEl - 1) || (YK_Y(L.ckeys[j + 1]) != YK_Y(L.ckeys[j]));
     int tot;
     block_exscan(mcount, s_scr, &tot);
     if (threadIdx.x == 0) {
@@ -827,19 +883,19 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
         u64 k = 0;
         if (j < nEl) {
             k = L.ckeys[j];
-            keep = (j == nEl - 1) || ((u32)(L.ckeys[j + 1] >> 16) != (u32)(k >> 16));
+            keep = (j == nEl - 1) || (YK_Y(L.ckeys[j + 1]) != YK_Y(k));
         }
         int t2;
         int pre = block_exscan(keep, s_scr, &t2);
         int o = s_m;
         if (keep) {
-            int best_i = (int)(k & 0xffffu);
+            int best_i = YK_POS(k);
             int best_idx = L.cidx[best_i];
-            for (int q = j - 1; q >= 0 && (u32)(L.ckeys[q] >> 16) == (u32)(k >> 16); --q) {
-                int ci = (int)(L.ckeys[q] & 0xffffu);
+            for (int q = j - 1; q >= 0 && YK_Y(L.ckeys[q]) == YK_Y(k); --q) {
+                int ci = YK_POS(L.ckeys[q]);
                 if (L.cidx[ci] > best_idx) { best_idx = L.cidx[ci]; best_i = ci; }
             }
-            oy[o + pre] = ord2f((u32)(k >> 16));
+            oy[o + pre] = ord2f(YK_Y(k));
             oz[o + pre] = L.cz[best_i];
         }
         __syncthreads();
@@ -859,6 +915,38 @@ __global__ void __launch_bounds__(256) k_band_indices(const float4 *__restrict__
     int n = band_gather_sorted(L, capb, sorted4, slab_start, m, lo, hi, &s_n);
     if (n < 0) { if (threadIdx.x == 0) { m->api_cnt = s_n; m->api_flag = DERR_CAPACITY; } return; }
     for (int j = threadIdx.x; j < n && j < out_cap; j += blockDim.x) out[j] = (int)(L.keys[j] >> 32);
+    if (threadIdx.x == 0) { m->api_cnt = n; m->api_flag = 0; }
+}
+
+/* rangedX_index for a band that does not fit LDS: same result from global scratch
+   (tmp, sorted: n keys each; hist: NB + 1 ints), one workgroup. */
+__global__ void __launch_bounds__(256) k_band_indices_big(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+                                                          DevMeta *m, float lo, float hi, int npts, u64 *tmp, u64 *sorted,
+                                                          int *hist, int NB, int cap, int *out)
+{
+    __shared__ int s_n;
+    __shared__ int s_scr[17];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (lo <= hi && m->n_valid > 0) {
+        const int b0 = slab_of(m, lo), b1 = slab_of(m, hi);
+        const int i0 = slab_start[b0], i1 = slab_start[b1 + 1];
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            float4 p = sorted4[i];
+            if (!(p.x < lo || p.x > hi)) {
+                int slot = atomicAdd(&s_n, 1);
+                if (slot < cap) tmp[slot] = (u64)(u32)idx_of(p);
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n > cap) { if (threadIdx.x == 0) { m->api_cnt = n; m->api_flag = DERR_CAPACITY; } return; }
+    auto gen = [&](int i) { return tmp[i]; };
+    auto bucket = [&](u64 k) { int q = (int)((k * (u64)NB) / (u64)max(npts, 1)); return q >= NB ? NB - 1 : q; };
+    auto less = [&](u64 a, u64 b) { return a < b; };
+    block_bucket_sort(sorted, n, hist, NB, s_scr, gen, bucket, less);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) out[j] = (int)sorted[j];
     if (threadIdx.x == 0) { m->api_cnt = n; m->api_flag = 0; }
 }
 
@@ -891,11 +979,15 @@ __global__ void __launch_bounds__(256) k_insert_api(const float *__restrict__ X,
 /* ------------------------------------------------------------------ */
 __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const float *__restrict__ node_y,
                                                 const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                                int *wp_cnt, int *wp_off, int *tail, int W_cap)
+                                                int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran)
 {
     __shared__ int scratch[17];
     __shared__ int s_run;
-    if (threadIdx.x == 0) s_run = 0;
+    if (threadIdx.x == 0) {
+        s_run = 0;
+        /* work was left for the arena passes but they were not launched: report, the host re-runs */
+        if (!arena_ran && (m->big_slabs > 0 || m->big_slices > 0)) atomicCAS(&m->err, 0, DERR_CAPACITY);
+    }
     __syncthreads();
     const int nk = m->err ? 0 : m->nkept;
     const int res_i = (int)P.rpy_resolution;

@@ -337,17 +337,23 @@ class Engine:
 
     def slice_indices(self, s):
         cap = 4096
-        out = np.empty(cap, np.int32)
-        n = C.c_size_t()
-        self._chk(self.L.ppp_get_slice_indices(self.h, int(s), _i(out), cap, C.byref(n)))
-        return out[:n.value].copy()
+        while True:
+            out = np.empty(cap, np.int32)
+            n = C.c_size_t()
+            self._chk(self.L.ppp_get_slice_indices(self.h, int(s), _i(out), cap, C.byref(n)))
+            if n.value <= cap:
+                return out[:n.value].copy()
+            cap = n.value
 
     def ranged_x_index(self, position):
         cap = 4096
-        out = np.empty(cap, np.int32)
-        n = C.c_size_t()
-        self._chk(self.L.ppp_ranged_x_index(self.h, int(position), _i(out), cap, C.byref(n)))
-        return out[:n.value].copy()
+        while True:
+            out = np.empty(cap, np.int32)
+            n = C.c_size_t()
+            self._chk(self.L.ppp_ranged_x_index(self.h, int(position), _i(out), cap, C.byref(n)))
+            if n.value <= cap:
+                return out[:n.value].copy()
+            cap = n.value
 
     def nodes(self, s):
         m = C.c_size_t()

@@ -347,3 +347,15 @@ def test_run_async_graph_replay_matches_plain_calls(engine_mod):
     b.set_cloud(pts2); b.run_async(); b.sync()  # new cloud: new plan, new graph
     d = engine_mod.Engine(0, tool_radius=9.0); d.set_cloud(pts2); d.gen_path(); d.get_path()
     assert b.waypoints().tobytes() == d.waypoints().tobytes()
+
+
+def test_dense_cloud_overflows_lds_and_takes_the_arena_path(engine_mod, oracle_mod):
+    """Maximum sizes: bands of > 4096 points do not fit the workgroup's LDS; the engine re-runs the
+    slices (and slabs) that overflow on a global arena, transparently, with identical results."""
+    pts = synth.make_plate(64, 2600, kind="wavy", amp=3.0, seed=31)   # 166k points, ~7000 per 4 mm band
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=8.0, path_resolution=40.0)
+    assert_full_parity(engine_mod, e, o, every_slice=False)
+    assert max(len(o.slice_indices(s)) for s in range(o.num_slices())) > 4096
+    a = e.waypoints().tobytes()
+    e.run_async(); e.sync()
+    assert e.waypoints().tobytes() == a
