@@ -55,7 +55,7 @@ def main():
     import torch
     import torch.distributed as dist
     from polishpathplanning_amd import engine, synth
-    from polishpathplanning_amd.robot_path import gather_robot_path
+    from polishpathplanning_amd.robot_path import exchange_counts, gather_robot_path
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,6 +92,8 @@ def main():
         e.gen_path()
         w_all.append(e.get_path())
     send = torch.zeros((sum(w_all) + 64 * args.batch, 6), dtype=torch.float32, device=dev)
+    # the batch is fixed, so is every rank's waypoint count: exchanged once, checked on every gather
+    counts = exchange_counts(sum(w_all), dist, dev) if world > 1 else None
 
     def step():
         for e in engines:  # every handle has its own stream: the workpieces overlap on the GPU
@@ -99,7 +101,7 @@ def main():
         w = 0
         for e in engines:  # waits for that handle's stream, then D2D into the gather buffer
             w += e.copy_waypoints_to_device(send.data_ptr() + 24 * w, send.shape[0] - w)
-        blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev)
+        blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev, counts)
         return w, blocks
 
     def fence():

@@ -1328,10 +1328,10 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* either continues from the last snapshot or emits the snapshot of the  */
 /* stop sweep.                                                           */
 /* ------------------------------------------------------------------ */
-#define SM_K 8
+#define SM_K 16
 #define SM_D 16
 #define SM_L 1
-#define SM_T 256
+#define SM_T 512
 #define SM_M (SM_T * SM_L)
 #define SM_HB ((SM_D + 1) * SM_K + 1)
 #define SM_OWN (SM_M - SM_HB - SM_K)

@@ -10,20 +10,30 @@ torch.distributed is plumbing here: backend "nccl" is RCCL on ROCm, "gloo" is us
 import numpy as np
 
 
-def gather_robot_path(local_wp, dist=None, device=None):
+def exchange_counts(w_local, dist, device):
+    """Waypoint count of every rank (one tiny all-gather).  A caller that replans the same batch
+    can keep the result and pass it to gather_robot_path(counts=...)."""
+    import torch
+    cnt = torch.tensor([int(w_local)], dtype=torch.int64, device=device)
+    counts = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, cnt)
+    return counts.cpu().tolist()
+
+
+def gather_robot_path(local_wp, dist=None, device=None, counts=None):
     """local_wp: torch tensor [W_local, 6] float32 on `device`.  Returns on rank 0 the list of
     per-rank waypoint tensors in rank order (None elsewhere).  Works for world_size 1 without
-    a process group."""
+    a process group.  counts: per-rank waypoint counts if already known (skips the count exchange)."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [local_wp]
     world = dist.get_world_size()
     rank = dist.get_rank()
     dev = local_wp.device if device is None else device
-    cnt = torch.tensor([local_wp.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, cnt)
-    counts = counts.cpu().tolist()
+    if counts is None:
+        counts = exchange_counts(local_wp.shape[0], dist, dev)
+    elif counts[rank] != local_wp.shape[0]:
+        raise ValueError("stale counts: rank %d has %d waypoints, not %d" % (rank, local_wp.shape[0], counts[rank]))
     wmax = max(max(counts), 1)
     send = torch.zeros((wmax, 6), dtype=torch.float32, device=dev)
     send[: local_wp.shape[0]] = local_wp

@@ -57,11 +57,15 @@ def _worker(rank, world, port, q):
     w = 5 + 3 * rank  # ragged blocks
     local = torch.arange(w * 6, dtype=torch.float32).reshape(w, 6) + 1000 * rank
     blocks = gather_robot_path(local, dist)
+    from polishpathplanning_amd.robot_path import exchange_counts
+    counts = exchange_counts(w, dist, local.device)
+    again = gather_robot_path(local, dist, counts=counts)       # cached counts: no count exchange
     if rank == 0:
         full = concat_robot_path(blocks)
+        assert torch.equal(full, concat_robot_path(again))
         q.put(([b.shape[0] for b in blocks], full.numpy()))
     else:
-        assert blocks is None
+        assert blocks is None and again is None
     dist.barrier()
     dist.destroy_process_group()
 
