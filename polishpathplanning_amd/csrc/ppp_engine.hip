@@ -182,12 +182,12 @@ int make_plan(ppp_handle h)
     const int n = (int)h->n;
     /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS */
     int B = (h->h_nvalid + 639) / 640;
-    B = std::max(1, std::min(B, 16384));
+    B = std::max(1, std::min(B, 8192));
     h->B = B;
     {
         double mean = (double)h->h_nvalid / B;
-        int cap = 1024;
-        while (cap < 4096 && cap < 1.5 * mean) cap <<= 1;
+        int cap = 2048; /* 24 KiB of LDS per workgroup: still 6 workgroups per CU */
+        while (cap < 4096 && cap < 2.0 * mean) cap <<= 1;
         h->slab_cap = cap;
     }
     HIPCHK(h, h->big_slabs.ensure(B));
@@ -220,6 +220,7 @@ int make_plan(ppp_handle h)
 
     HIPCHK(h, h->unsorted4.ensure(n)); HIPCHK(h, h->sorted4.ensure(n));
     HIPCHK(h, h->slab_cnt.ensure(B)); HIPCHK(h, h->slab_start.ensure(B + 1)); HIPCHK(h, h->slab_cursor.ensure(B));
+    HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream)); /* every run leaves it cleared again */
     HIPCHK(h, h->slab_xmin.ensure(B)); HIPCHK(h, h->slab_xmax.ensure(B));
     HIPCHK(h, h->px.ensure(h->S_cap)); HIPCHK(h, h->lo.ensure(h->S_cap)); HIPCHK(h, h->hi.ensure(h->S_cap));
     HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
@@ -244,13 +245,16 @@ int enqueue_index(ppp_handle h)
 {
     const int n = (int)h->n;
     DevParams D = dev_params(h);
-    LAUNCH(h, "k_minmax", k_minmax, h->mm_grid, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p);
-    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
-           h->slab_cnt.p);
     size_t hist_lds = sizeof(int) * (size_t)h->B;
-    int gh = std::max(1, std::min((n + 256 * 16 - 1) / (256 * 16), 1024));
-    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, h->meta.p, h->slab_cnt.p);
-    LAUNCH(h, "k_slab_scan", k_slab_scan, 1, 1024, 0, h->slab_cnt.p, h->slab_start.p, h->slab_cursor.p, h->B);
+    /* slab grid from the bounds cached when the cloud was set (identical to what k_minmax finds) */
+    const float slab_x0 = h->h_mn[0];
+    const float xr = h->h_mx[0] - h->h_mn[0];
+    const float slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f;
+    LAUNCH(h, "k_minmax", k_minmax<false>, h->mm_grid, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, 0.f, 0.f, 0, (int *)nullptr);
+    int gh = std::max(1, std::min((n / 4 + 256 * 8 - 1) / (256 * 8), 512));
+    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, slab_x0, slab_invw, h->B, h->slab_cnt.p);
+    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
+           h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
     int chunk = 4096;
@@ -368,7 +372,8 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     {
         int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
         HIPCHK(h, h->mm_part.ensure(g));
-        hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p);
+        hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
+                           (int *)nullptr);
         HIPCHK(h, hipGetLastError());
         std::vector<MinMaxPart> parts(g);
         HIPCHK(h, hipMemcpyAsync(parts.data(), h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));

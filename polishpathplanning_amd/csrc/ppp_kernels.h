@@ -80,9 +80,26 @@ struct MinMaxPart { float mn[3], mx[3]; int cnt, pad; };
 
 /* a2: pcl::getMinMax3D (path_slicing_alg.cpp:303, path_dynamic_alg.cpp:345).  One partial per
    workgroup, no atomics (same-address atomics serialise at ~11 ns each on this part). */
-__global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
-                                                const float *__restrict__ Z, int n, MinMaxPart *part)
+/* HIST: the same pass also builds the x-slab histogram (LDS-privatised, flushed with one global
+   atomic per non-empty slab and workgroup).  The slab grid (x0, invw, B) comes from the bounds the
+   host cached when the cloud was set; k_setup stores the same grid in DevMeta for every later
+   kernel, so the index is consistent whatever this launch's own min/max turn out to be. */
+__device__ inline int slab_of_grid(float x, float x0, float invw, int B)
 {
+    int b = (int)((x - x0) * invw);
+    b = b < 0 ? 0 : b;
+    return b >= B ? B - 1 : b;
+}
+template <bool HIST>
+__global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
+                                                const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
+                                                int B, int *slab_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_hist[];
+    if (HIST) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
+        __syncthreads();
+    }
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
     const int n4 = n >> 2;
@@ -96,6 +113,7 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
                 mn[1] = fminf(mn[1], ys[k]); mx[1] = fmaxf(mx[1], ys[k]);
                 mn[2] = fminf(mn[2], zs[k]); mx[2] = fmaxf(mx[2], zs[k]);
                 cnt++;
+                if (HIST) atomicAdd(&s_hist[slab_of_grid(xs[k], x0, invw, B)], 1);
             }
         }
     }
@@ -108,6 +126,14 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
             cnt++;
+            if (HIST) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            int c = s_hist[b];
+            if (c) atomicAdd(&slab_cnt[b], c);
         }
     }
     __shared__ float s_mn[3][4], s_mx[3][4];
@@ -204,8 +230,10 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
 /* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
 __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
-                                               float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt)
+                                               float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
+                                               float slab_invw, int *slab_start, int *slab_cursor)
 {
+    __shared__ int s_scan[17];
     __shared__ float s_mn[3][4], s_mx[3][4];
     __shared__ int s_cnt[4];
     __shared__ int s_S;
@@ -221,7 +249,25 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
     cnt = wave_sum(cnt);
     if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
-    for (int b = threadIdx.x; b < B; b += blockDim.x) slab_cnt[b] = 0;
+    /* exclusive scan of the slab histogram (k_minmax<true> filled it) -> CSR offsets + scatter
+       cursors; the histogram is cleared for the next run */
+    {
+        const int per = (B + blockDim.x - 1) / blockDim.x;
+        const int b0 = threadIdx.x * per;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) if (b0 + k < B) sum += slab_cnt[b0 + k];
+        int total;
+        int pre = block_exscan(sum, s_scan, &total);
+        for (int k = 0; k < per; ++k) {
+            if (b0 + k < B) {
+                int c = slab_cnt[b0 + k];
+                slab_start[b0 + k] = pre; slab_cursor[b0 + k] = pre;
+                pre += c;
+                slab_cnt[b0 + k] = 0;
+            }
+        }
+        if (threadIdx.x == 0) slab_start[B] = total;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int c = 0;
@@ -246,9 +292,8 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         int nk = P.drop_ends ? S - 2 : S;
         r.nkept = nk < 0 ? 0 : nk;
         r.B = B;
-        r.slab_x0 = r.mn[0];
-        float range = r.mx[0] - r.mn[0];
-        r.slab_invw = (c && range > 0.f) ? (float)B / range : 0.f;
+        r.slab_x0 = slab_x0;     /* the grid k_minmax<true> binned with */
+        r.slab_invw = slab_invw;
         *m = r;
         s_S = S;
     }
@@ -265,40 +310,31 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
 /* Slice binning, generalised: every point goes to one x-slab (the      */
 /* replacement for kdtree.setInputCloud + the S PassThrough scans).     */
 /* ------------------------------------------------------------------ */
-__global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, int n, const DevMeta *m, int *slab_cnt)
+/* x-slab histogram: LDS-privatised, few workgroups (every workgroup flushes one global atomic per
+   non-empty slab, so the grid stays small while each thread streams many points). */
+__global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, int n, float x0, float invw, int B, int *slab_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
-    const int B = m->B;
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float x = X[i];
-        if (x == x) atomicAdd(&s_hist[slab_of(m, x)], 1);
+    const int n4 = n >> 2;
+    const float4 *X4 = (const float4 *)X;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+        float4 x = X4[i];
+        if (x.x == x.x) atomicAdd(&s_hist[slab_of_grid(x.x, x0, invw, B)], 1);
+        if (x.y == x.y) atomicAdd(&s_hist[slab_of_grid(x.y, x0, invw, B)], 1);
+        if (x.z == x.z) atomicAdd(&s_hist[slab_of_grid(x.z, x0, invw, B)], 1);
+        if (x.w == x.w) atomicAdd(&s_hist[slab_of_grid(x.w, x0, invw, B)], 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float x = X[(n4 << 2) + threadIdx.x];
+        if (x == x) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         int c = s_hist[b];
         if (c) atomicAdd(&slab_cnt[b], c);
     }
-}
-
-__global__ void __launch_bounds__(1024) k_slab_scan(const int *slab_cnt, int *slab_start, int *slab_cursor, int B)
-{
-    __shared__ int scratch[17];
-    const int per = (B + blockDim.x - 1) / blockDim.x;
-    const int b0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k) if (b0 + k < B) sum += slab_cnt[b0 + k];
-    int total;
-    int pre = block_exscan(sum, scratch, &total);
-    for (int k = 0; k < per; ++k) {
-        if (b0 + k < B) {
-            slab_start[b0 + k] = pre;
-            slab_cursor[b0 + k] = pre;
-            pre += slab_cnt[b0 + k];
-        }
-    }
-    if (threadIdx.x == 0) slab_start[B] = total;
 }
 
 __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
