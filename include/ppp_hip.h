@@ -143,6 +143,10 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x,
 /* estimate_normal() (path_slicing_alg.cpp:141-150) evaluated at the given cloud indices:
  * out4 = nx ny nz curvature */
 int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4);
+/* estimate_normal() over the WHOLE cloud (path_slicing_alg.cpp:141-150, Path_Generation.cpp:323-333):
+ * out4 = n x 4 floats (nx ny nz curvature) in cloud index order; NaN where PCL gives NaN
+ * (< 3 neighbours, dropped points).  SURVEY.md 8f rank 2. */
+int ppp_estimate_normals(ppp_handle h, float *out4);
 /* kdtree.nearestKSearch(q, 1) on the whole cloud for k query points */
 int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx);
 

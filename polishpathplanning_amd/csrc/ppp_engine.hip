@@ -840,6 +840,28 @@ int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4)
     return PPP_OK;
 }
 
+int ppp_estimate_normals(ppp_handle h, float *out4)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    if (!h->n) return PPP_OK;
+    if (!out4) return fail(h, PPP_ERR_ARG, "bad arguments");
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    const size_t n = h->n;
+    HIPCHK(h, h->scratch.ensure(n * 16));
+    /* dropped (non-finite) points never enter the index: they keep the NaN fill */
+    HIPCHK(h, hipMemsetAsync(h->scratch.p, 0xff, n * 16, h->stream));
+    DevParams D = dev_params(h);
+    const int nsorted = h->hmeta.n_valid;
+    if (nsorted > 0)
+        LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((nsorted + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
+               h->slab_xmin.p, h->slab_xmax.p, nsorted, (float4 *)h->scratch.p);
+    HIPCHK(h, hipMemcpyAsync(out4, h->scratch.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
 int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx)
 {
     int rc = ensure_index(h);

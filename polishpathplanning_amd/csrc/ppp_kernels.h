@@ -1329,6 +1329,21 @@ __global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict_
     for (int d = 0; d < 4; ++d) out4[4 * (size_t)t + d] = n4[d];
 }
 
+/* whole-cloud normal field: one thread per point, walked in slab order so that neighbouring
+   threads search the same slabs (L1/L2 friendly); result scattered to cloud index order */
+__global__ void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+                                                     const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+                                                     const float *__restrict__ slab_xmax, int nsorted, float4 *out4)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsorted) return;
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
+    const float4 p = sorted4[i];
+    float n4[4];
+    normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
+    out4[idx_of(p)] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+}
+
 __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                               const float *__restrict__ slab_xmin, const float *__restrict__ slab_xmax,
                               const float *__restrict__ q, int k, int *out)

@@ -68,7 +68,7 @@ EXPORTS = [
     "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
     "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
-    "ppp_normals_at", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
+    "ppp_normals_at", "ppp_estimate_normals", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file",
 ]
@@ -127,6 +127,7 @@ def lib():
         L.ppp_ranged_x_index.argtypes = [vp, C.c_int, ip, sz, szp]
         L.ppp_insert_point.argtypes = [vp, ip, sz, C.c_float, dp, dp, dp, sz, szp]
         L.ppp_normals_at.argtypes = [vp, ip, sz, fp]
+        L.ppp_estimate_normals.argtypes = [vp, fp]
         L.ppp_nearest.argtypes = [vp, fp, sz, ip]
         L.ppp_get_stage.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_smooth_sweeps.argtypes = [vp, ip]
@@ -386,6 +387,12 @@ class Engine:
         idx = np.ascontiguousarray(idx, np.int32)
         out = np.empty((len(idx), 4), np.float32)
         self._chk(self.L.ppp_normals_at(self.h, _i(idx), len(idx), _f(out)))
+        return out
+
+    def estimate_normals(self):
+        """estimate_normal() over the whole cloud: [n, 4] = nx ny nz curvature."""
+        out = np.empty((self.n, 4), np.float32)
+        self._chk(self.L.ppp_estimate_normals(self.h, _f(out)))
         return out
 
     def nearest(self, q):

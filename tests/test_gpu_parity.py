@@ -359,3 +359,16 @@ def test_dense_cloud_overflows_lds_and_takes_the_arena_path(engine_mod, oracle_m
     a = e.waypoints().tobytes()
     e.run_async(); e.sync()
     assert e.waypoints().tobytes() == a
+
+
+def test_whole_cloud_normal_field(engine_mod, oracle_mod):
+    """estimate_normal() as a public method: every point's PCL normal."""
+    pts, cfg = synth.make_config("small_40k")
+    pts = pts.copy(); pts[123] = np.nan
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    n = e.estimate_normals(); on = o.estimate_normals()
+    on[123] = np.nan  # the oracle leaves a dropped point's slot at zero; PCL gives NaN for it
+    nan = np.isnan(on[:, 0])
+    assert np.array_equal(np.isnan(n[:, 0]), nan) and nan.sum() >= 1
+    ang = np.arctan2(np.linalg.norm(np.cross(n[~nan, :3], on[~nan, :3]), axis=1), np.sum(n[~nan, :3] * on[~nan, :3], axis=1))
+    assert ang.max() < 1e-4 and np.abs(n[~nan, 3] - on[~nan, 3]).max() < 1e-5
