@@ -372,3 +372,59 @@ def test_whole_cloud_normal_field(engine_mod, oracle_mod):
     assert np.array_equal(np.isnan(n[:, 0]), nan) and nan.sum() >= 1
     ang = np.arctan2(np.linalg.norm(np.cross(n[~nan, :3], on[~nan, :3]), axis=1), np.sum(n[~nan, :3] * on[~nan, :3], axis=1))
     assert ang.max() < 1e-4 and np.abs(n[~nan, 3] - on[~nan, 3]).max() < 1e-5
+
+
+def test_duplicate_points_resolve_ties_like_the_reference(engine_mod, oracle_mod):
+    """Collisions: exact coordinate duplicates give exact distance ties (lowest index wins a
+    nearest-neighbour tie, highest index writes the map key last)."""
+    pts, cfg = synth.make_config("tiny_5k")
+    rng = np.random.default_rng(2)
+    dup = rng.integers(0, len(pts), 600)
+    both = np.concatenate([pts, pts[dup]])[rng.permutation(len(pts) + 600)]
+    for pairing in (0, 1):
+        e, o = run_pair(engine_mod, oracle_mod, both, tool_radius=6.0, pairing=pairing)
+        assert_full_parity(engine_mod, e, o)
+
+
+def test_points_exactly_on_a_plane_are_on_neither_side(engine_mod, oracle_mod):
+    """x == plane_x: in the PassThrough band, but neither El nor Er (path_slicing_alg.cpp:180-181)."""
+    pts = synth.make_plate(90, 40, kind="wavy", amp=4.0, seed=6)
+    o0 = oracle_mod.Oracle(pts, tool_radius=6.0, walk=2)   # integer planes
+    px = o0.slice_positions()
+    mm = pts * np.float32(1000)
+    for p in px[1:-1:2]:                                    # snap the nearest column onto every other plane
+        col = np.abs(mm[:, 0] - p) < 0.75
+        pts[col, 0] = np.float32(p) / np.float32(1000)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0, walk=2)
+    assert_full_parity(engine_mod, e, o)
+    on_plane = sum(int((o.points()[o.slice_indices(s), 0] == o.slice_positions()[s]).sum()) for s in range(o.num_slices()))
+    assert on_plane > 50
+
+
+@pytest.mark.parametrize("name", ["cfg4_2m_s256", "cfg5_10m_s1024"])
+def test_large_baseline_configs(engine_mod, oracle_mod, name):
+    """BASELINE.json configs 4 and 5 at full size (per-GPU share of config 4; all of config 5 on one
+    GPU): counts, knots and sampled waypoints equal the oracle's, final list within 1e-4 m, plus the
+    size-independent properties of the path."""
+    pts, cfg = synth.make_config(name)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=cfg["tool_radius"])
+    S = e.gen_path(); W = e.get_path()
+    assert S == cfg["slices"] == o.gen_path() and W == o.get_path()
+    assert np.array_equal(e.stage(engine_mod.STAGE_WP_XYZ), o.waypoints_xyz())
+    assert np.array_equal(e.stage(engine_mod.STAGE_WP_NN), o.waypoint_nn())
+    wp, owp = e.waypoints(), o.waypoints()
+    assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
+    tail = e.tail_index()
+    assert np.array_equal(tail, o.tail_index()) and tail[-1] == W - 1 and np.all(np.diff(tail) > 0)
+    xyz = e.stage(engine_mod.STAGE_WP_XYZ)
+    px = e.slice_positions()
+    start = 0
+    for k, t in enumerate(tail):
+        seg = xyz[start:t + 1]
+        assert np.all(seg[:, 0] == px[k + 1])                       # the x spline is the plane
+        d = np.diff(seg[:, 1])
+        assert np.all(d > 0) if k % 2 == 0 else np.all(d < 0)       # boustrophedon
+        start = t + 1
+    for s in range(0, S, max(1, S // 16)):
+        y, x, z = e.nodes(s)
+        assert np.all(np.diff(y) > 0) and len(y) >= 3               # map order, strictly increasing knots
