@@ -34,6 +34,11 @@ class Params(C.Structure):
         ("normal_radius", C.c_float),
         ("reference_complexity", C.c_int),
         ("smooth_max_sweeps", C.c_int),
+        ("dynamic_adjustment", C.c_int),
+        ("depth", C.c_double),
+        ("adjust_threshold", C.c_double),
+        ("toolthickness", C.c_double),
+        ("curvature_k", C.c_int),
     ]
 
 
@@ -84,6 +89,9 @@ def lib():
         L.ppo_rpy_oob.argtypes = [vp]
         L.ppo_estimate_normals.argtypes = [vp, fp]
         L.ppo_normal_at.argtypes = [vp, C.c_int, fp]
+        L.ppo_knn.argtypes = [vp, fp, C.c_int, ip]
+        L.ppo_principal_curvature.argtypes = [vp, fp, fp]
+        L.ppo_area2cloud.argtypes = [vp, dp, C.c_int, fp]
         L.ppo_nearest.argtypes = [vp, fp, fp]
         L.ppo_radius_search.argtypes = [vp, fp, C.c_float, ip, C.c_int]
         L.ppo_steffen.argtypes = [C.c_int, dp, dp, dp, C.c_int, dp]
@@ -255,6 +263,24 @@ class Oracle:
     def normal_at(self, idx):
         out = np.empty(4, np.float32)
         self.L.ppo_normal_at(self.h, int(idx), _f(out))
+        return out
+
+    def knn(self, q, k):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.empty(k, np.int32)
+        n = self.L.ppo_knn(self.h, _f(q), k, _i(out))
+        return out[:n]
+
+    def principal_curvature(self, q):
+        q = np.ascontiguousarray(q, np.float32)
+        out = np.empty(5, np.float32)
+        self.L.ppo_principal_curvature(self.h, _f(q), _f(out))
+        return out
+
+    def area2cloud(self, p, key):
+        p = np.ascontiguousarray(p, np.float64)
+        out = np.empty(3, np.float32)
+        self.L.ppo_area2cloud(self.h, _d(p), int(key), _f(out))
         return out
 
     def nearest(self, q):

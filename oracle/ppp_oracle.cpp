@@ -89,6 +89,14 @@ public:
         if (d2out) *d2out = best;
         return bi;
     }
+    /* k nearest, ascending (distance, id) */
+    void knn(const float *q, int k, std::vector<std::pair<float, int>> &out) const
+    {
+        out.clear();
+        if (nodes_.empty() || k <= 0) return;
+        knn_rec(0, q, k, out);
+        std::sort_heap(out.begin(), out.end());
+    }
     void radius(const float *q, float r, std::vector<std::pair<float, int>> &out) const
     {
         out.clear();
@@ -146,6 +154,23 @@ private:
         int near = diff < 0 ? n.left : n.right, far = diff < 0 ? n.right : n.left;
         nn_rec(near, q, best, bi);
         if (diff * diff <= best) nn_rec(far, q, best, bi);
+    }
+    void knn_rec(int ni, const float *q, int k, std::vector<std::pair<float, int>> &heap) const
+    {
+        const Node &n = nodes_[ni];
+        if (n.dim < 0) {
+            for (int i = n.lo; i < n.hi; ++i) {
+                int id = order_[i];
+                std::pair<float, int> e(dist2(q, p(id)), id);
+                if ((int)heap.size() < k) { heap.push_back(e); std::push_heap(heap.begin(), heap.end()); }
+                else if (e < heap.front()) { std::pop_heap(heap.begin(), heap.end()); heap.back() = e; std::push_heap(heap.begin(), heap.end()); }
+            }
+            return;
+        }
+        float diff = q[n.dim] - n.split;
+        int near = diff < 0 ? n.left : n.right, far = diff < 0 ? n.right : n.left;
+        knn_rec(near, q, k, heap);
+        if ((int)heap.size() < k || diff * diff <= heap.front().first) knn_rec(far, q, k, heap);
     }
     void rad_rec(int ni, const float *q, float r2, std::vector<std::pair<float, int>> &out) const
     {
@@ -740,6 +765,218 @@ struct ppo_handle {
         return (int)Node.size();
     }
 
+
+    /* ---------------- dynamic adjustment (path_dynamic_alg.cpp:77-306) ---------------- */
+    const float *normal_of(int idx) { return P.reference_complexity ? &normals[4 * (size_t)idx] : normal_lazy(idx); }
+
+    /* pcl::PrincipalCurvaturesEstimation::computePointPrincipalCurvatures (PCL 1.12
+       features/impl/principal_curvatures.hpp) */
+    void principal_curvatures(int p_idx, const std::vector<std::pair<float, int>> &nb, float pc[5])
+    {
+        const float *np = normal_of(p_idx);
+        const float n_idx[3] = {np[0], np[1], np[2]};
+        float M[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M[i][j] = (i == j ? 1.f : 0.f) - n_idx[i] * n_idx[j];
+        std::vector<std::array<float, 3>> proj(nb.size());
+        float cen[3] = {0, 0, 0};
+        for (size_t k = 0; k < nb.size(); ++k) {
+            const float *nn = normal_of(nb[k].second);
+            for (int i = 0; i < 3; ++i) proj[k][i] = M[i][0] * nn[0] + M[i][1] * nn[1] + M[i][2] * nn[2];
+            for (int i = 0; i < 3; ++i) cen[i] += proj[k][i];
+        }
+        for (int i = 0; i < 3; ++i) cen[i] /= (float)nb.size();
+        float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t k = 0; k < nb.size(); ++k) {
+            float d[3] = {proj[k][0] - cen[0], proj[k][1] - cen[1], proj[k][2] - cen[2]};
+            double dxy = d[0] * d[1], dxz = d[0] * d[2], dyz = d[1] * d[2];
+            cov[0] += d[0] * d[0]; cov[1] += (float)dxy; cov[2] += (float)dxz;
+            cov[3] += (float)dxy; cov[4] += d[1] * d[1]; cov[5] += (float)dyz;
+            cov[6] += (float)dxz; cov[7] += (float)dyz; cov[8] += d[2] * d[2];
+        }
+        /* pcl::eigen33(mat, evals): scaled roots */
+        float scale = 0.f;
+        for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(cov[i]));
+        if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+        float m[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = cov[3 * i + j] / scale;
+        float ev[3];
+        compute_roots(m, ev);
+        for (int i = 0; i < 3; ++i) ev[i] *= scale;
+        /* pcl::computeCorrespondingEigenVector(mat, evals[2], vec) */
+        float sm[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sm[i][j] = cov[3 * i + j] / scale;
+        const float shift = ev[2] / scale;
+        sm[0][0] -= shift; sm[1][1] -= shift; sm[2][2] -= shift;
+        float cp[3][3];
+        cross3(sm[0], sm[1], cp[0]); cross3(sm[0], sm[2], cp[1]); cross3(sm[1], sm[2], cp[2]);
+        float len[3];
+        for (int i = 0; i < 3; ++i) len[i] = std::sqrt(cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1] + cp[i][2] * cp[i][2]);
+        int bi = 0;
+        if (len[1] > len[bi]) bi = 1;
+        if (len[2] > len[bi]) bi = 2;
+        for (int d = 0; d < 3; ++d) pc[d] = cp[bi][d] / len[bi];
+        float inv = 1.0f / (float)nb.size();
+        pc[3] = ev[2] * inv;
+        pc[4] = ev[1] * inv;
+    }
+
+    /* compute_transform (path_dynamic_alg.cpp:77-107): T = [n x c | c | n | p] */
+    void compute_transform(const float sp[3], float T[3][4], float pcv[2])
+    {
+        ensure_tree();
+        std::vector<std::pair<float, int>> nb;
+        tree.knn(sp, P.curvature_k, nb);
+        float pc[5];
+        principal_curvatures(nb[0].second, nb, pc);
+        pcv[0] = pc[3]; pcv[1] = pc[4];
+        const float *nn = normal_of(nb[0].second);
+        const float nv[3] = {nn[0], nn[1], nn[2]}, cv[3] = {pc[0], pc[1], pc[2]};
+        float cr[3];
+        cross3(nv, cv, cr);
+        for (int i = 0; i < 3; ++i) { T[i][0] = cr[i]; T[i][1] = cv[i]; T[i][2] = nv[i]; T[i][3] = sp[i]; }
+    }
+
+    /* Area2Cloud (path_dynamic_alg.cpp:110-180); key: 0 = left (min x), 1 = right (max x) */
+    void area2cloud(const double point[3], int key, float bound[3])
+    {
+        const float sp[3] = {(float)point[0], (float)point[1], (float)point[2]};
+        float T[3][4], pc[2];
+        compute_transform(sp, T, pc);
+        const double toolRadius = P.tool_radius, depth = P.depth, toolthickness = P.toolthickness;
+        double longAxis, shortAxis;
+        if ((pc[0] >= 0) && (pc[1] >= 0)) {
+            longAxis = std::sqrt(std::pow(1 / pc[1], 2) - std::pow(std::abs(1 / pc[1]) - depth, 2));
+            if (longAxis > toolRadius) longAxis = toolRadius;
+            shortAxis = std::sqrt(std::pow(1 / pc[0], 2) - std::pow(std::abs(1 / pc[0]) - depth, 2));
+            if (shortAxis > toolRadius) shortAxis = toolRadius;
+        } else {
+            longAxis = std::abs(1 / pc[1]) - std::sqrt(std::pow(1 / pc[1], 2) - std::pow(toolRadius, 2));
+            if (longAxis > toolthickness) longAxis = toolthickness;
+            shortAxis = std::abs(1 / pc[0]) - std::sqrt(std::pow(1 / pc[0], 2) - std::pow(toolRadius, 2));
+            if (shortAxis > toolthickness) shortAxis = toolthickness;
+        }
+        bool have = false;
+        float best[3] = {NAN, NAN, NAN};
+        for (float angle(0.0); angle <= 360.0; angle += 0.5) {
+            const float rad = angle * 0.017453293f; /* pcl::deg2rad(float) */
+            const float ex = (float)(longAxis * std::cos(rad));
+            const float ey = (float)(shortAxis * std::sin(rad));
+            /* pcl::transformPointCloud, SSE form: c0*x + (c1*y + (c2*z + c3)), z = 0 */
+            float t[3];
+            for (int i = 0; i < 3; ++i) t[i] = T[i][0] * ex + (T[i][1] * ey + (T[i][2] * 0.f + T[i][3]));
+            /* std::max_element / std::min_element on x: first extremum, NaN never wins */
+            if (!have) { best[0] = t[0]; best[1] = t[1]; best[2] = t[2]; have = true; }
+            else if (key == 1 ? (best[0] < t[0]) : (t[0] < best[0])) { best[0] = t[0]; best[1] = t[1]; best[2] = t[2]; }
+        }
+        bound[0] = best[0]; bound[1] = best[1]; bound[2] = best[2];
+    }
+
+    /* compute_boundary (path_dynamic_alg.cpp:183-235); returns 0/1 */
+    int compute_boundary(const Spline &path, Spline &boundary, int key)
+    {
+        double miny = path.small_y, maxy = path.big_y;
+        std::map<double, std::array<double, 2>> boundary_node;
+        double point[3] = {0, 0, 0};
+        float bp[3];
+        double dy = miny + 2;
+        while (dy < maxy - 2) {
+            path.point(dy, point);
+            dy += P.tool_radius / 4;
+            area2cloud(point, key, bp);
+            if (std::isnan(bp[0])) continue;
+            boundary_node[bp[1]] = {bp[0], bp[2]};
+        }
+        area2cloud(point, key, bp); /* "last point": the stale node again (App. B.9) */
+        if (!std::isnan(bp[1])) boundary_node[bp[1]] = {bp[0], bp[2]}; /* a NaN key would corrupt the std::map */
+        int node_number = (int)boundary_node.size();
+        if (node_number <= 2) return 0;
+        Spline b;
+        b.y.resize(node_number + 2); b.x.resize(node_number + 2); b.z.resize(node_number + 2);
+        int index = 0;
+        for (auto &kv : boundary_node) { index++; b.x[index] = kv.second[0]; b.y[index] = kv.first; b.z[index] = kv.second[1]; }
+        b.x[0] = b.x[1]; b.y[0] = b.y[1] - 20; b.z[0] = b.z[1];
+        b.x[index + 1] = b.x[index]; b.y[index + 1] = b.y[index] + 20; b.z[index + 1] = b.z[index];
+        b.fit();
+        boundary = b;
+        return 1;
+    }
+
+    /* bisection (path_dynamic_alg.cpp:237-265) */
+    void bisection(double node[3], const Spline &boundary, int itr, int key)
+    {
+        if (itr > 5) return;
+        float ab[3];
+        area2cloud(node, key == 0 ? 1 : 0, ab);
+        if (ab[1] < boundary.small_y || ab[1] > boundary.big_y) return;
+        if (!boundary.yx.in_domain((double)ab[1])) return; /* NaN y: GSL would abort; treated as overflow */
+        double bpnt[3];
+        boundary.point((double)ab[1], bpnt);
+        double norm0 = (double)ab[0] - bpnt[0];
+        if (std::fabs(norm0) < P.adjust_threshold) return;   /* norm.norm() of (n, 0, 0) */
+        node[0] = node[0] - norm0;
+        if (std::isnan(node[0])) return;
+        bisection(node, boundary, itr + 1, key);
+    }
+
+    /* dynamic_adjust_path (path_dynamic_alg.cpp:267-306); returns < 0 where the reference aborts */
+    int dynamic_adjust_path(Spline &origin, const Spline &boundary, int key)
+    {
+        std::map<double, std::array<double, 2>> new_path;
+        double miny = origin.small_y, maxy = origin.big_y, dy = 0;
+        int NumOfNode = (int)((maxy - miny) / 5);
+        ensure_tree();
+        for (int i = 0; i <= NumOfNode; i++) {
+            dy = ((maxy - miny) / NumOfNode * i) + miny;
+            if (!origin.yx.in_domain(dy)) return -1; /* gsl_spline_eval: GSL_EDOM -> abort */
+            double node[3];
+            origin.point(dy, node);
+            bisection(node, boundary, 0, key);
+            const float q[3] = {(float)node[0], (float)node[1], (float)node[2]};
+            int id = tree.nearest(q); /* nearestKSearch(point, 3): only pointIdx[0] is used */
+            if (id < 0) return -1;
+            const Pt &c = cloud[id];
+            new_path[(double)c.y] = {(double)c.x, (double)c.z};
+        }
+        if (new_path.size() < 3) return -1; /* gsl_spline_alloc */
+        origin.y.clear(); origin.x.clear(); origin.z.clear();
+        for (auto &kv : new_path) { origin.y.push_back(kv.first); origin.x.push_back(kv.second[0]); origin.z.push_back(kv.second[1]); }
+        origin.fit();
+        return 0;
+    }
+
+    /* the slice-to-slice chains of GenPath with Adjust = true */
+    int adjust_all()
+    {
+        int S = (int)path_set.size();
+        auto chain = [&](int from, int to, int dir, int key) -> int {
+            Spline boundary;
+            bool have_boundary = false;
+            for (int s = from; s != to; s += dir) {
+                const Spline &pre = path_set[s - dir];
+                if (compute_boundary(pre, boundary, key)) have_boundary = true;
+                if (!have_boundary) return -(1 + s); /* the reference would use an unconstructed Spline */
+                if (dynamic_adjust_path(path_set[s], boundary, key) < 0) return -(1 + s);
+            }
+            return 0;
+        };
+        if (P.walk == PPO_WALK_CENTER_INT) { /* thread_worker left / right of the centre path */
+            int c = 0;
+            { /* index of the centre slice = number of front slices */
+                float mn[3], mx[3];
+                minmax(mn, mx);
+                int imin = (int)mn[0], imax = (int)mx[0], step = int(P.tool_radius * 2);
+                int cc = (imax + imin) / 2, loc = cc - step;
+                while (imax > loc && loc > imin) { c++; loc -= step; }
+            }
+            int rc = chain(c - 1, -1, -1, 0);
+            if (rc) return rc;
+            return chain(c + 1, S, +1, 1);
+        }
+        if (P.walk == PPO_WALK_SDIR_INT) return chain(1, S, +1, 1);
+        return 0; /* SectPath::GenPath has no adjustment */
+    }
+
     int gen_path()
     {
         path_set.clear();
@@ -764,6 +1001,10 @@ struct ppo_handle {
             Spline &sp = path_set[s];
             for (auto &kv : Node) { sp.y.push_back(kv.first); sp.x.push_back(kv.second[0]); sp.z.push_back(kv.second[1]); }
             sp.fit();
+        }
+        if (P.dynamic_adjustment) {
+            int rc = adjust_all();
+            if (rc) return rc;
         }
         return S;
     }
@@ -836,6 +1077,8 @@ void ppo_default_params(ppo_params *p)
     p->normal_radius = 2.5f;
     p->reference_complexity = 0;
     p->smooth_max_sweeps = 32;
+    p->dynamic_adjustment = 0; /* config.txt says true; the benchmarks of this round run without */
+    p->depth = 0.01; p->adjust_threshold = 1; p->toolthickness = 10; p->curvature_k = 50;
 }
 
 ppo_handle *ppo_create(const float *xyz, size_t n, size_t stride, const ppo_params *p)
@@ -932,6 +1175,22 @@ void ppo_estimate_normals(ppo_handle *h, float *n4)
     memcpy(n4, h->normals.data(), h->normals.size() * sizeof(float));
 }
 void ppo_normal_at(ppo_handle *h, int idx, float n4[4]) { h->point_normal(idx, n4); }
+int ppo_knn(ppo_handle *h, const float q[3], int k, int *out)
+{
+    h->ensure_tree();
+    std::vector<std::pair<float, int>> nb;
+    h->tree.knn(q, k, nb);
+    for (size_t i = 0; i < nb.size(); ++i) out[i] = nb[i].second;
+    return (int)nb.size();
+}
+void ppo_principal_curvature(ppo_handle *h, const float q[3], float out[5])
+{
+    h->ensure_tree();
+    std::vector<std::pair<float, int>> nb;
+    h->tree.knn(q, h->P.curvature_k, nb);
+    h->principal_curvatures(nb[0].second, nb, out);
+}
+void ppo_area2cloud(ppo_handle *h, const double p[3], int key, float out[3]) { h->area2cloud(p, key, out); }
 int ppo_nearest(ppo_handle *h, const float q[3], float *d2) { h->ensure_tree(); return h->tree.nearest(q, d2); }
 int ppo_radius_search(ppo_handle *h, const float q[3], float r, int *out, int cap)
 {

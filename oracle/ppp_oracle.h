@@ -50,6 +50,12 @@ typedef struct ppo_params {
     int    reference_complexity; /* 1: per-slice O(N) PassThrough scans and whole-cloud
                                     normal estimation exactly where the reference runs them */
     int    smooth_max_sweeps;    /* cap for the smoothing loop (see ppp_oracle.cpp)   */
+    /* dynamic adjustment (path_dynamic_alg.cpp:77-306), SURVEY.md 8f rank 1 */
+    int    dynamic_adjustment;   /* Dynamic_adjustment (config.txt:13)                */
+    double depth;                /* depth             (config.txt:5)                  */
+    double adjust_threshold;     /* Adjust_Threshold  (config.txt:3)                  */
+    double toolthickness;        /* toolthickness     (config.txt:4)                  */
+    int    curvature_k;          /* 50 (path_dynamic_alg.cpp:87); 10 in Path_Generation.cpp:372 */
 } ppo_params;
 
 typedef struct ppo_handle ppo_handle;
@@ -98,6 +104,14 @@ int  ppo_rpy_oob(const ppo_handle *h);                            /* B.6 hazard 
 /* whole-cloud normal estimation (a10), nx ny nz curvature per point */
 void ppo_estimate_normals(ppo_handle *h, float *n4);
 void ppo_normal_at(ppo_handle *h, int idx, float n4[4]);
+/* dynamic adjustment building blocks (for the cross-check tests) */
+/* kdtree.nearestKSearch(q, k): ascending distance; returns the count */
+int ppo_knn(ppo_handle *h, const float q[3], int k, int *out);
+/* pcl::PrincipalCurvaturesEstimation::computePointPrincipalCurvatures on the k nearest points of q:
+   out = pcx pcy pcz pc1 pc2 */
+void ppo_principal_curvature(ppo_handle *h, const float q[3], float out[5]);
+/* Area2Cloud(point, flag, key) (path_dynamic_alg.cpp:110-180): key 0 = left (min x), 1 = right (max x) */
+void ppo_area2cloud(ppo_handle *h, const double p[3], int key, float out[3]);
 /* full-cloud kd-tree queries (used by the cross-check tests) */
 int ppo_nearest(ppo_handle *h, const float q[3], float *d2);
 int ppo_radius_search(ppo_handle *h, const float q[3], float r, int *out, int cap);

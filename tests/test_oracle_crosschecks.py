@@ -426,3 +426,81 @@ def test_reference_complexity_mode_is_identical(oracle_mod):
     b = oracle_mod.Oracle(pts, tool_radius=6.0, reference_complexity=1)
     assert a.gen_path() == b.gen_path() and a.get_path() == b.get_path()
     assert a.waypoints().tobytes() == b.waypoints().tobytes()
+
+
+# ---------------- dynamic adjustment building blocks -----------------
+@pytest.fixture(scope="module")
+def curved(oracle_mod):
+    pts = synth.make_plate(120, 70, kind="blade", amp=25.0, seed=15)
+    return pts, oracle_mod.Oracle(pts, tool_radius=6.0)
+
+
+def test_knn_matches_brute_force(curved):
+    pts, o = curved
+    cloud = o.points()
+    rng = np.random.default_rng(3)
+    for qi in cloud[rng.integers(0, len(cloud), 60)] + rng.normal(0, 1.0, (60, 3)).astype(np.float32):
+        got = o.knn(qi, 50)
+        d = qi[None, :] - cloud
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = np.lexsort((np.arange(len(d2)), d2))[:50]
+        assert np.array_equal(got, want)
+
+
+def test_principal_curvature_matches_numpy(curved):
+    """computePointPrincipalCurvatures restated in float64 numpy (PCL 1.12 principal_curvatures.hpp)."""
+    pts, o = curved
+    cloud = o.points()
+    normals = o.estimate_normals().astype(np.float64)[:, :3]
+    rng = np.random.default_rng(4)
+    for qi in cloud[rng.integers(0, len(cloud), 40)]:
+        nb = o.knn(qi, 50)
+        if np.isnan(normals[nb]).any():
+            continue
+        n = normals[nb[0]]
+        M = np.eye(3) - np.outer(n, n)
+        proj = normals[nb] @ M.T
+        dm = proj - proj.mean(0)
+        C = dm.T @ dm
+        w, v = np.linalg.eigh(C)
+        pc = o.principal_curvature(qi)
+        assert abs(pc[3] - w[2] / 50) <= 2e-3 * max(w[2] / 50, 1e-9) + 1e-9
+        assert abs(pc[4] - w[1] / 50) <= 5e-2 * max(w[2] / 50, 1e-9) + 1e-9   # float closed-form roots
+        assert abs(abs(np.dot(pc[:3], v[:, 2])) - 1) < 1e-3
+
+
+def test_area2cloud_is_the_extreme_point_of_the_contact_ellipse(curved):
+    pts, o = curved
+    cloud = o.points()
+    rng = np.random.default_rng(5)
+    for qi in cloud[rng.integers(0, len(cloud), 30)].astype(np.float64):
+        r = o.area2cloud(qi, 1); l = o.area2cloud(qi, 0)
+        if np.isnan(r).any():
+            continue
+        # both lie on an ellipse of semi-axes <= toolRadius centred on the node, on opposite sides in x
+        assert np.linalg.norm(r - qi) <= 6.0 + 1e-3 and np.linalg.norm(l - qi) <= 6.0 + 1e-3
+        assert r[0] >= qi[0] >= l[0]
+        assert np.allclose((r + l) / 2, qi, atol=2e-3)   # the sampled ellipse is centrally symmetric
+
+
+def test_dynamic_adjustment_moves_knots_onto_cloud_points(oracle_mod):
+    pts, cfg = synth.make_config("small_40k")
+    for walk in (1, 2):
+        o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk, dynamic_adjustment=1)
+        S = o.gen_path()
+        assert S > 10
+        cloud = o.points().astype(np.float64)
+        px = o.slice_positions()
+        first = (len(px) - 1) // 2 if walk == 1 else 0     # the centre / first path is never adjusted
+        for s in range(S):
+            y, x, z = o.nodes(s)
+            if s == first:
+                assert np.all(x == np.float64(px[s]))
+                continue
+            # every knot of an adjusted path is a cloud point (3-NN snap, path_dynamic_alg.cpp:291-294)
+            knots = np.stack([x, y, z], 1)
+            d = np.abs(knots[:, None, :] - cloud[None, ::1, :]).sum(2).min(1) if len(knots) * len(cloud) < 3e7 else None
+            if d is not None:
+                assert d.max() == 0.0
+            assert np.abs(x - px[s]).max() < 6.0
+        assert o.get_path() > 0
