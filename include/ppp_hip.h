@@ -68,7 +68,12 @@ typedef struct ppp_params {
     float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
     int    smooth_max_sweeps; /* cap of the smoothing loop                   */
     int    alignment;         /* Alignment / Smooth / RemoveOutlier: must be 0 (next rows)    */
-    int    dynamic_adjustment;/* Dynamic_adjustment: must be 0          */
+    int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306;
+                                 available for the kd pairing with the connect / connect1 walks */
+    double depth;             /* depth            (config.txt:5)                              */
+    double adjust_threshold;  /* Adjust_Threshold (config.txt:3)                              */
+    double toolthickness;     /* toolthickness    (config.txt:4)                              */
+    int    curvature_k;       /* neighbours of compute_transform: 50 (path_dynamic_alg.cpp:87) */
 } ppp_params;
 
 void ppp_default_params(ppp_params *p);
@@ -147,6 +152,10 @@ int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4);
  * out4 = n x 4 floats (nx ny nz curvature) in cloud index order; NaN where PCL gives NaN
  * (< 3 neighbours, dropped points).  SURVEY.md 8f rank 2. */
 int ppp_estimate_normals(ppp_handle h, float *out4);
+/* Area2Cloud(point, flag, key) of the dynamic adjustment (path_dynamic_alg.cpp:110-180) for k points
+ * (xyz doubles, mm): key 0 = left boundary point (min x of the contact ellipse), 1 = right (max x);
+ * out3 = k x 3 floats (NaN where the reference gets NaN) */
+int ppp_area2cloud(ppp_handle h, const double *pts_xyz, size_t k, int key, float *out3);
 /* kdtree.nearestKSearch(q, 1) on the whole cloud for k query points */
 int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx);
 

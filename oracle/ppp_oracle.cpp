@@ -928,7 +928,10 @@ struct ppo_handle {
         ensure_tree();
         for (int i = 0; i <= NumOfNode; i++) {
             dy = ((maxy - miny) / NumOfNode * i) + miny;
-            if (!origin.yx.in_domain(dy)) return -1; /* gsl_spline_eval: GSL_EDOM -> abort */
+            /* B.13: for i == NumOfNode the rounded product can land an ulp beyond the last knot, where
+               gsl_spline_eval raises GSL_EDOM and the reference aborts; evaluate at the last knot */
+            if (dy > maxy) dy = maxy;
+            if (!origin.yx.in_domain(dy)) return -1; /* NumOfNode == 0: 0/0 */
             double node[3];
             origin.point(dy, node);
             bisection(node, boundary, 0, key);

@@ -8,6 +8,7 @@
  * There is no CPU fallback: without a HIP device every entry point fails loudly.
  */
 #include "ppp_kernels.h"
+#include "ppp_dynamic.h"
 #include "../../include/ppp_hip.h"
 
 #include <algorithm>
@@ -66,7 +67,14 @@ struct ppp_handle_s {
     DevBuf<float> slab_xmin, slab_xmax;
     DevBuf<DevMeta> meta;
     DevBuf<float> px, lo, hi;
-    DevBuf<float> node_y, node_z;
+    DevBuf<float> node_x, node_y, node_z;
+    /* dynamic adjustment (allocated when Dynamic_adjustment is on or ppp_area2cloud is used) */
+    DevBuf<float4> normals4, dyn_bnd_pts, dyn_adj_pts;
+    DevBuf<float> ell_cs;
+    DevBuf<double> dyn_bnd_knots;
+    DevBuf<int> dyn_bnd_n;
+    int dyn_maxNB = 1, dyn_maxNA = 1;
+    bool normals_valid = false;
     DevBuf<int> node_start, node_cnt, band_cnt;
     DevBuf<int> wp_cnt, wp_off, tail;
     DevBuf<float4> wp_xyz, wp_normal;
@@ -99,7 +107,8 @@ struct ppp_handle_s {
         (void)hipSetDevice(device);
         X.release(); Y.release(); Z.release(); unsorted4.release(); sorted4.release();
         slab_cnt.release(); slab_start.release(); slab_cursor.release(); slab_xmin.release(); slab_xmax.release();
-        meta.release(); px.release(); lo.release(); hi.release(); node_y.release(); node_z.release();
+        meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
+        normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
@@ -171,7 +180,57 @@ int validate_params(ppp_handle h, const ppp_params *p)
     if (!(p->normal_radius > 0)) return fail(h, PPP_ERR_ARG, "normal_radius");
     if (p->smooth_max_sweeps < 1 || p->smooth_max_sweeps > SM_MAXS) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps must be in [1, 512]");
     if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
-    if (p->dynamic_adjustment) return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment is outside the hot path (SURVEY.md 8f rank 1)");
+    if (p->dynamic_adjustment) {
+        if (p->pairing != PPP_PAIR_KD || (p->walk != PPP_WALK_CENTER_INT && p->walk != PPP_WALK_SDIR_INT))
+            return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment is implemented for the connect / connect1 planners (kd pairing, centre-out or single-direction walk)");
+        if (p->curvature_k < 3 || p->curvature_k > 64) return fail(h, PPP_ERR_ARG, "curvature_k must be in [3, 64]");
+        if (!(p->depth > 0) || !(p->adjust_threshold >= 0) || !(p->toolthickness > 0)) return fail(h, PPP_ERR_ARG, "depth / Adjust_Threshold / toolthickness");
+    }
+    return PPP_OK;
+}
+
+DynParams dyn_params(const ppp_handle h)
+{
+    DynParams D;
+    D.tool_radius = h->P.tool_radius; D.depth = h->P.depth; D.toolthickness = h->P.toolthickness;
+    D.adjust_threshold = h->P.adjust_threshold; D.k = h->P.curvature_k;
+    /* first radius of the k-NN gather: k points of a sheet of the cloud's mean areal density, +25 % */
+    double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
+    double rho = (area > 0 && h->h_nvalid > 0) ? (double)h->h_nvalid / area : 1.0;
+    D.r0 = (float)std::max(0.5, 1.25 * std::sqrt((double)D.k / (3.14159265358979 * rho)));
+    return D;
+}
+
+int ensure_dynamic_buffers(ppp_handle h)
+{
+    HIPCHK(h, h->normals4.ensure(std::max<size_t>(h->n, 1)));
+    HIPCHK(h, h->dyn_bnd_pts.ensure(2 * (size_t)h->dyn_maxNB)); HIPCHK(h, h->dyn_adj_pts.ensure(2 * (size_t)h->dyn_maxNA));
+    HIPCHK(h, h->dyn_bnd_knots.ensure(2 * 3 * ((size_t)h->dyn_maxNB + 2))); HIPCHK(h, h->dyn_bnd_n.ensure(2));
+    if (!h->ell_cs.p) {
+        /* cos / sin of the 721 ellipse angles, computed as the reference does (float angle, pcl::deg2rad,
+           std::cos(float)) with the host libm so the device uses the very same values */
+        std::vector<float> cs(2 * DYN_ELL);
+        int a = 0;
+        for (float angle(0.0); angle <= 360.0 && a < DYN_ELL; angle += 0.5, ++a) {
+            const float rad = angle * 0.017453293f;
+            cs[2 * a] = std::cos(rad); cs[2 * a + 1] = std::sin(rad);
+        }
+        HIPCHK(h, h->ell_cs.ensure(2 * DYN_ELL));
+        HIPCHK(h, hipMemcpyAsync(h->ell_cs.p, cs.data(), sizeof(float) * 2 * DYN_ELL, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return PPP_OK;
+}
+
+/* whole-cloud normals into normals4 (cloud index order); needs the slab index */
+int enqueue_normals(ppp_handle h)
+{
+    const size_t n = h->n;
+    DevParams D = dev_params(h);
+    HIPCHK(h, hipMemsetAsync(h->normals4.p, 0xff, std::max<size_t>(n, 1) * 16, h->stream)); /* dropped points: NaN */
+    if (n)
+        LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((n + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
+               h->slab_xmin.p, h->slab_xmax.p, -1, h->normals4.p);
     return PPP_OK;
 }
 
@@ -223,7 +282,15 @@ int make_plan(ppp_handle h)
     HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream)); /* every run leaves it cleared again */
     HIPCHK(h, h->slab_xmin.ensure(B)); HIPCHK(h, h->slab_xmax.ensure(B));
     HIPCHK(h, h->px.ensure(h->S_cap)); HIPCHK(h, h->lo.ensure(h->S_cap)); HIPCHK(h, h->hi.ensure(h->S_cap));
-    HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
+    if (h->P.dynamic_adjustment) {
+        /* compute_boundary samples every Tool_Radius/4 between miny+2 and maxy-2; dynamic_adjust_path every ~5 mm */
+        h->dyn_maxNB = (int)std::min(4.0e6, std::max(0.0, yr - 4) / (h->P.tool_radius / 4) + 4);
+        h->dyn_maxNA = (int)std::min(4.0e6, yr / 5 + 4);
+        h->node_cap = (int)std::min(2.0e9, (double)h->node_cap + (double)h->S_cap * h->dyn_maxNA);
+        int rc = ensure_dynamic_buffers(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, h->node_x.ensure(h->node_cap)); HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
     HIPCHK(h, h->node_start.ensure(h->S_cap)); HIPCHK(h, h->node_cnt.ensure(h->S_cap)); HIPCHK(h, h->band_cnt.ensure(h->S_cap));
     HIPCHK(h, h->wp_cnt.ensure(h->S_cap)); HIPCHK(h, h->wp_off.ensure(h->S_cap + 1)); HIPCHK(h, h->tail.ensure(h->S_cap));
     HIPCHK(h, h->wp_xyz.ensure(h->W_cap)); HIPCHK(h, h->wp_normal.ensure(h->W_cap)); HIPCHK(h, h->wp_nn.ensure(h->W_cap));
@@ -269,6 +336,43 @@ int enqueue_index(ppp_handle h)
         LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, 256, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
                h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
     h->index_built = true;
+    return PPP_OK;
+}
+
+/* centre slice of the centre-out walk = number of slices left of it (path_dynamic_alg.cpp:310-313) */
+int host_centre_index(const ppp_handle h)
+{
+    const int step = (int)(h->P.tool_radius * 2);
+    const int imin = (int)h->h_mn[0], imax = (int)h->h_mx[0];
+    const int c = (imax + imin) / 2;
+    return (step > 0 && imax > c - step && c - step > imin) ? (c - imin - 1) / step : 0;
+}
+
+/* GenPath with Adjust = true: whole-cloud normals, then the slice-to-slice chains */
+int enqueue_dynamic(ppp_handle h)
+{
+    int rc = enqueue_normals(h);
+    if (rc) return rc;
+    const DynParams D = dyn_params(h);
+    DynBuffers Bf{h->dyn_bnd_pts.p, h->dyn_bnd_knots.p, h->dyn_bnd_n.p, h->dyn_adj_pts.p, h->dyn_maxNB, h->dyn_maxNA};
+    HIPCHK(h, hipMemsetAsync(h->dyn_bnd_n.p, 0, 2 * sizeof(int), h->stream));
+    const int S = h->S_cap, walk = h->P.walk;
+    const int centre = walk == PPP_WALK_CENTER_INT ? host_centre_index(h) : 0;
+    const int nchains = walk == PPP_WALK_CENTER_INT ? 2 : 1;
+    const int steps = walk == PPP_WALK_CENTER_INT ? std::max(centre, S - 1 - centre) : S - 1;
+    const size_t fit_lds = (size_t)4096 * 8 * 2 + (size_t)(4096 + 2) * 4 + 64;
+    const dim3 gb((Bf.maxNB + DYN_WAVES - 1) / DYN_WAVES, nchains), ga((Bf.maxNA + DYN_WAVES - 1) / DYN_WAVES, nchains);
+    for (int t = 0; t < steps; ++t) {
+        LAUNCH(h, "k_dyn_boundary_pts", k_dyn_boundary_pts, gb, 64 * DYN_WAVES, 0, h->meta.p, D, walk, t, centre, h->sorted4.p,
+               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->node_x.p, h->node_y.p, h->node_z.p,
+               h->node_start.p, h->node_cnt.p, Bf);
+        LAUNCH(h, "k_dyn_boundary_fit", k_dyn_boundary_fit, nchains, 256, fit_lds, h->meta.p, walk, t, centre, Bf);
+        LAUNCH(h, "k_dyn_adjust_pts", k_dyn_adjust_pts, ga, 64 * DYN_WAVES, 0, h->meta.p, D, walk, t, centre, h->sorted4.p,
+               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->node_x.p, h->node_y.p, h->node_z.p,
+               h->node_start.p, h->node_cnt.p, Bf);
+        LAUNCH(h, "k_dyn_adjust_fit", k_dyn_adjust_fit, nchains, 256, fit_lds, h->meta.p, walk, t, centre, Bf, h->node_x.p, h->node_y.p,
+               h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p);
+    }
     return PPP_OK;
 }
 
@@ -405,7 +509,8 @@ void ppp_default_params(ppp_params *p)
     memcpy(p->handeye, he, sizeof(he));
     p->normal_radius = 2.5f;
     p->smooth_max_sweeps = 32;
-    p->alignment = 0; p->dynamic_adjustment = 0;
+    p->alignment = 0; p->dynamic_adjustment = 0; /* config.txt says true: the planner classes pass it through */
+    p->depth = 0.01; p->adjust_threshold = 1; p->toolthickness = 10; p->curvature_k = 50;
 }
 
 const char *ppp_version(void) { return PPP_VERSION_STR; }
@@ -436,6 +541,8 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
     (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     *out = h;
@@ -500,16 +607,20 @@ int ppp_gen_path_async(ppp_handle h)
     if (rc) return rc;
     if (h->P.pairing == PPP_PAIR_KD) {
         LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, 256, slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
-               h->px.p, h->lo.p, h->hi.p, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+               h->px.p, h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
         if (h->big_path)
             LAUNCH(h, "k_slice_kd_arena", k_slice_kd<true>, h->S_cap, 256, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
-                   h->lo.p, h->hi.p, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
+                   h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                    h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
     } else {
         LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
-               h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
-               h->band_cnt.p);
+               h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p,
+               h->node_cnt.p, h->band_cnt.p);
+    }
+    if (h->P.dynamic_adjustment) {
+        int rc2 = enqueue_dynamic(h);
+        if (rc2) return rc2;
     }
     h->gen_done = true;
     h->path_done = false;
@@ -527,7 +638,8 @@ int ppp_get_path_async(ppp_handle h)
     int nk = std::max(1, h->S_cap);
     int gw = std::max(1, (h->W_cap + 63) / 64);
     LAUNCH(h, "k_pose", k_pose, nk, 256, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
-           h->slab_xmax.p, h->px.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p, h->capb,
+           h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
+           h->capb,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
     /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
     {
@@ -582,7 +694,7 @@ int ppp_sync(ppp_handle h)
     return map_dev_err(h);
 }
 
-int ppp_failed_slice(ppp_handle h) { return (h && h->hmeta.err == DERR_SLICE) ? h->hmeta.err_slice : -1; }
+int ppp_failed_slice(ppp_handle h) { return (h && h->hmeta.err != DERR_NONE && h->hmeta.err_slice != 0x7fffffff) ? h->hmeta.err_slice : -1; }
 
 int ppp_num_slices(ppp_handle h, int *S)
 {
@@ -753,13 +865,15 @@ int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t c
     HIPCHK(h, hipMemcpy(&pxs, h->px.p + s, 4, hipMemcpyDeviceToHost));
     if (m) *m = (size_t)cnt;
     size_t k = std::min(cap, (size_t)cnt);
+    (void)pxs;
     if (k && (y || z || x)) {
-        std::vector<float> fy(k), fz(k);
+        std::vector<float> fx(k), fy(k), fz(k);
+        HIPCHK(h, hipMemcpy(fx.data(), h->node_x.p + st, k * 4, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy(fy.data(), h->node_y.p + st, k * 4, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy(fz.data(), h->node_z.p + st, k * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; ++i) {
             if (y) y[i] = (double)fy[i];
-            if (x) x[i] = (double)pxs;
+            if (x) x[i] = (double)fx[i];
             if (z) z[i] = (double)fz[i];
         }
     }
@@ -776,7 +890,7 @@ int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz)
     double *dq = (double *)h->scratch.p, *dout = dq + k;
     HIPCHK(h, hipMemcpyAsync(dq, y, k * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(&h->meta.p->api_flag, 0, 4, h->stream));
-    LAUNCH(h, "k_eval_api", k_eval_api, (unsigned)((k + 127) / 128), 128, 0, h->meta.p, h->px.p, h->node_y.p, h->node_z.p,
+    LAUNCH(h, "k_eval_api", k_eval_api, (unsigned)((k + 127) / 128), 128, 0, h->meta.p, h->node_x.p, h->node_y.p, h->node_z.p,
            h->node_start.p, h->node_cnt.p, s, dq, (int)k, dout);
     HIPCHK(h, hipMemcpyAsync(xyz, dout, k * 24, hipMemcpyDeviceToHost, h->stream));
     h->meta_in_flight = false;
@@ -858,6 +972,28 @@ int ppp_estimate_normals(ppp_handle h, float *out4)
         LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((nsorted + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
                h->slab_xmin.p, h->slab_xmax.p, nsorted, (float4 *)h->scratch.p);
     HIPCHK(h, hipMemcpyAsync(out4, h->scratch.p, n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return PPP_OK;
+}
+
+int ppp_area2cloud(ppp_handle h, const double *pts_xyz, size_t k, int key, float *out3)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    if (!k) return PPP_OK;
+    if (!pts_xyz || !out3 || (key != 0 && key != 1)) return fail(h, PPP_ERR_ARG, "bad arguments");
+    if (h->P.curvature_k < 3 || h->P.curvature_k > 64) return fail(h, PPP_ERR_ARG, "curvature_k must be in [3, 64]");
+    rc = ensure_dynamic_buffers(h);
+    if (rc) return rc;
+    rc = enqueue_normals(h);
+    if (rc) return rc;
+    HIPCHK(h, h->scratch.ensure(k * 36 + 64));
+    double *dq = (double *)h->scratch.p;
+    float *dout = (float *)(dq + 3 * k);
+    HIPCHK(h, hipMemcpyAsync(dq, pts_xyz, k * 24, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "k_area2cloud_api", k_area2cloud_api, (unsigned)((k + DYN_WAVES - 1) / DYN_WAVES), 64 * DYN_WAVES, 0, h->meta.p, dyn_params(h),
+           h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, dq, (int)k, key, dout);
+    HIPCHK(h, hipMemcpyAsync(out3, dout, k * 12, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PPP_OK;
 }

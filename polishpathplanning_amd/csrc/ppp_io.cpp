@@ -184,6 +184,8 @@ int ppp_read_config(const char *path, ppp_config *c)
             return PPP_ERR_ARG; /* std::stod would have thrown out of the reference's constructor */
         }
     }
+    /* the adjustment parameters travel inside ppp_params */
+    c->params.depth = c->depth; c->params.adjust_threshold = c->adjust_threshold; c->params.toolthickness = c->toolthickness;
     return PPP_OK;
 }
 

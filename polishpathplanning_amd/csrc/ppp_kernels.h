@@ -670,7 +670,7 @@ __device__ inline int flatten_nodes(const SliceLds &L, int ncand, float *out_y, 
 
 __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
-                                               const float *__restrict__ hi, int pairing, int capb, float *node_y,
+                                               const float *__restrict__ hi, int pairing, int capb, float *node_x, float *node_y,
                                                float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -708,6 +708,7 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
     __syncthreads();
     if (node_cnt[s] == 0 && tot != 0) return;
     flatten_nodes(L, ncand, node_y + s_base, node_z + s_base, tot, s_scr);
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
 }
 
 /* ------------------------------------------------------------------ */
@@ -779,8 +780,8 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
 template <bool ARENA>
 __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                   DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
-                                                  const float *__restrict__ hi, int capb_lds, float *node_y, float *node_z,
-                                                  int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
+                                                  const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
+                                                  float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
                                                   char *arena, unsigned long long arena_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -913,6 +914,7 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
     __syncthreads();
     if (node_cnt[s] == 0) return;
     float *oy = node_y + s_base, *oz = node_z + s_base;
+    for (int i = threadIdx.x; i < node_cnt[s]; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
     for (int base = 0; base < nEl; base += blockDim.x) {
         int j = base + threadIdx.x;
         int keep = 0;
@@ -1058,18 +1060,17 @@ __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const f
     }
 }
 
-__global__ void k_eval_api(DevMeta *m, const float *__restrict__ px, const float *__restrict__ node_y,
+__global__ void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const float *__restrict__ node_y,
                            const float *__restrict__ node_z, const int *__restrict__ node_start,
                            const int *__restrict__ node_cnt, int s, const double *__restrict__ yq, int kq, double *out)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= kq) return;
     const int st = node_start[s], mm = node_cnt[s];
-    const float *ny = node_y + st, *nz = node_z + st;
-    const double Pxd = (double)px[s];
+    const float *nx = node_x + st, *ny = node_y + st, *nz = node_z + st;
     auto Yf = [&](int i) { return (double)ny[i]; };
     auto Zf = [&](int i) { return (double)nz[i]; };
-    auto Xf = [&](int) { return Pxd; };
+    auto Xf = [&](int i) { return (double)nx[i]; };
     double y = yq[t];
     if (mm < 3 || y < (double)ny[0] || y > (double)ny[mm - 1] || !(y == y)) {
         out[3 * t] = out[3 * t + 1] = out[3 * t + 2] = NAN;
@@ -1233,12 +1234,13 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
    never depends on the window). */
 #define POSE_STAGE_CAP 5120
 #define POSE_PAD 8.0f
-__host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 8; }
+__host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 12; }
 
 __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
                                               const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                               const float *__restrict__ slab_xmax, const float *__restrict__ px,
-                                              const float *__restrict__ node_y, const float *__restrict__ node_z,
+                                              const float *__restrict__ node_x, const float *__restrict__ node_y,
+                                              const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                               const int *__restrict__ wp_cnt, const int *__restrict__ wp_off, int capb,
                                               float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx)
@@ -1247,6 +1249,7 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
     float4 *s_pts = (float4 *)s_raw;
     float *s_ny = (float *)(s_pts + POSE_STAGE_CAP);
     float *s_nz = s_ny + capb;
+    float *s_nx = s_nz + capb;
     const int k = blockIdx.x;
     const int W = m->W;
     if (m->err || k >= m->nkept || W == 0) return;
@@ -1266,15 +1269,15 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
     for (int i = lds_lo + threadIdx.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
     const bool nodes_in_lds = mm <= capb;
     if (nodes_in_lds)
-        for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; }
+        for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; s_nx[i] = node_x[st + i]; }
     __syncthreads();
     STAMP(1, 0); /* staging */
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
     const float *ny = nodes_in_lds ? s_ny : node_y + st, *nz = nodes_in_lds ? s_nz : node_z + st;
-    const double Pxd = (double)Px;
+    const float *nx = nodes_in_lds ? s_nx : node_x + st; /* the plane x, or cloud x after the dynamic adjustment */
     auto Yf = [&](int i) { return (double)ny[i]; };
     auto Zf = [&](int i) { return (double)nz[i]; };
-    auto Xf = [&](int) { return Pxd; };
+    auto Xf = [&](int i) { return (double)nx[i]; };
     const double start = (double)ny[0] + P.trim;
     for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
         double dy = start;
@@ -1336,7 +1339,7 @@ __global__ void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, co
                                                      const float *__restrict__ slab_xmax, int nsorted, float4 *out4)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nsorted) return;
+    if (i >= (nsorted < 0 ? m->n_valid : nsorted)) return;
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     const float4 p = sorted4[i];
     float n4[4];

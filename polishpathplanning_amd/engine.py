@@ -47,6 +47,10 @@ class Params(C.Structure):
         ("smooth_max_sweeps", C.c_int),
         ("alignment", C.c_int),
         ("dynamic_adjustment", C.c_int),
+        ("depth", C.c_double),
+        ("adjust_threshold", C.c_double),
+        ("toolthickness", C.c_double),
+        ("curvature_k", C.c_int),
     ]
 
 
@@ -68,7 +72,7 @@ EXPORTS = [
     "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
     "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
-    "ppp_normals_at", "ppp_estimate_normals", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
+    "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file",
 ]
@@ -128,6 +132,7 @@ def lib():
         L.ppp_insert_point.argtypes = [vp, ip, sz, C.c_float, dp, dp, dp, sz, szp]
         L.ppp_normals_at.argtypes = [vp, ip, sz, fp]
         L.ppp_estimate_normals.argtypes = [vp, fp]
+        L.ppp_area2cloud.argtypes = [vp, dp, sz, C.c_int, fp]
         L.ppp_nearest.argtypes = [vp, fp, sz, ip]
         L.ppp_get_stage.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_smooth_sweeps.argtypes = [vp, ip]
@@ -393,6 +398,13 @@ class Engine:
         """estimate_normal() over the whole cloud: [n, 4] = nx ny nz curvature."""
         out = np.empty((self.n, 4), np.float32)
         self._chk(self.L.ppp_estimate_normals(self.h, _f(out)))
+        return out
+
+    def area2cloud(self, pts, key):
+        """Area2Cloud of the dynamic adjustment for points [k, 3] (float64, mm)."""
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty((len(pts), 3), np.float32)
+        self._chk(self.L.ppp_area2cloud(self.h, _d(pts), len(pts), int(key), _f(out)))
         return out
 
     def nearest(self, q):

@@ -245,10 +245,10 @@ def test_short_slices_take_the_sequential_rpy_path(engine_mod, oracle_mod):
 def test_unsupported_options_fail_loudly(engine_mod):
     e = engine_mod.Engine(0)
     with pytest.raises(engine_mod.PPPError) as ei:
-        e.set_params(dynamic_adjustment=1)
+        e.set_params(dynamic_adjustment=1, pairing=1)   # only the kd planners (connect / connect1) have it
     assert ei.value.code == engine_mod.ERR_UNSUPPORTED
     with pytest.raises(engine_mod.PPPError):
-        e.set_params(alignment=1, dynamic_adjustment=0)
+        e.set_params(alignment=1, dynamic_adjustment=0, pairing=0)
     with pytest.raises(engine_mod.PPPError):
         e.set_params(alignment=0, path_resolution=0.0)
 
@@ -428,3 +428,49 @@ def test_large_baseline_configs(engine_mod, oracle_mod, name):
     for s in range(0, S, max(1, S // 16)):
         y, x, z = e.nodes(s)
         assert np.all(np.diff(y) > 0) and len(y) >= 3               # map order, strictly increasing knots
+
+
+# ---------------- dynamic adjustment ----------------
+def test_area2cloud_api(engine_mod, oracle_mod):
+    pts = synth.make_plate(160, 90, kind="blade", amp=25.0, seed=15)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    cloud = o.points().astype(np.float64)
+    rng = np.random.default_rng(8)
+    q = cloud[rng.integers(0, len(cloud), 300)] + rng.normal(0, 0.4, (300, 3))
+    for key in (0, 1):
+        got = e.area2cloud(q, key)
+        want = np.stack([o.area2cloud(p, key) for p in q])
+        nan = np.isnan(want[:, 0])
+        assert np.array_equal(np.isnan(got[:, 0]), nan)
+        d = np.abs(got[~nan] - want[~nan])
+        # x (the extremum itself) agrees to float noise; y (and z through the surface slope) is the
+        # 0.5-degree sample that happens to be extreme, so a tiny rotation of the principal direction
+        # moves it by up to two samples (R sin 1 deg = 0.1 mm)
+        assert d[:, 0].max() < 2e-3 and d[:, 1].max() < 0.12 and d[:, 2].max() < 0.06
+        assert np.median(d) == 0.0   # and almost always nothing moves at all
+
+
+@pytest.mark.parametrize("walk", [1, 2])
+def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
+    """GenPath with Dynamic_adjustment = true (config.txt:13) for connect (walk 1) and connect1 (walk 2):
+    every adjusted knot is a cloud point, so the knot lists must be identical."""
+    pts, cfg = synth.make_config("small_40k")
+    kw = dict(tool_radius=6.0, walk=walk, dynamic_adjustment=1)
+    o = oracle_mod.Oracle(pts, **kw)
+    e = engine_mod.Engine(0, **kw)
+    e.set_cloud(pts)
+    So = o.gen_path(); S = e.gen_path()
+    assert S == So > 10
+    bad = 0
+    for s in range(S):
+        gy, gx, gz = e.nodes(s); oy, ox, oz = o.nodes(s)
+        if len(gy) != len(oy) or not (np.array_equal(gy, oy) and np.array_equal(gx, ox) and np.array_equal(gz, oz)):
+            bad += 1
+    assert bad == 0
+    Wo = o.get_path(); W = e.get_path()
+    assert W == Wo
+    wp, owp = e.waypoints(), o.waypoints()
+    assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
+    # and it differs from the equal-spacing path
+    e2 = engine_mod.Engine(0, tool_radius=6.0, walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
+    assert np.abs(e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0] - e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]).max() > 0.05
