@@ -2,9 +2,10 @@
  * Path_Generate.h -- drop-in for the reference header of the same name (class path_generater,
  * :33-75), the planner ./main links (src/main.cpp, src/Path_Generation.cpp): brute-force pairing
  * (insert_point, Path_Generation.cpp:107-206) and the float walks of slicing_method (:282-321)
- * and Contact_Path_Generation (:689-755).  The dynamic adjustment half of
- * Contact_Path_Generation (compute_boundary / dynamic_adjust_path) is a "next" row
- * (SURVEY.md 8f rank 1): the contact paths are produced without it and a note is printed.
+ * and Contact_Path_Generation (:689-755) including its dynamic adjustment (compute_transform,
+ * Area2Cloud, compute_boundary, bisection, dynamic_adjust_path, :362-634; k = 10 neighbours,
+ * depth 0.005, Adjust_Threshold 1, toolthickness 10 as in the reference header :71).
+ * compute_coverage / drawpath only colour the viewer's cloud and are not reproduced.
  */
 #ifndef PATH_GENERATION
 #define PATH_GENERATION
@@ -40,21 +41,23 @@ public:
         return planner.insert_point(indices, PlanePoint[0]);
     }
     /* Path_Generation.cpp:282-321: insert_point on every slice of the min+step/2 walk */
-    void slicing_method() { run(PPP_WALK_V1_SLICING, "use time: "); }
-    /* Path_Generation.cpp:689-755 without the dynamic adjustment */
+    void slicing_method() { run(PPP_WALK_V1_SLICING, 0, "use time: "); }
+    /* Path_Generation.cpp:689-755: contact paths, each adjusted against its predecessor's boundary */
     void Contact_Path_Generation()
     {
         printf("Start Path Planning!\n");
-        run(PPP_WALK_V1_CONTACT, "Toal Using Time: ");
-        fprintf(stderr, "ppp: dynamic adjustment of the contact paths is not accelerated yet (SURVEY.md 8f rank 1)\n");
+        run(PPP_WALK_V1_CONTACT, 1, "Toal Using Time: ");
     }
     std::vector<Spline> &paths() { return Path_set; }
 
 private:
-    void run(int walk, const char *label)
+    void run(int walk, int adjust, const char *label)
     {
         auto t0 = std::chrono::high_resolution_clock::now();
-        planner.config().params.walk = walk;
+        ppp_params &p = planner.config().params;
+        p.walk = walk;
+        p.dynamic_adjustment = adjust;
+        p.curvature_k = 10; p.depth = depth; p.adjust_threshold = Adjust_Threshold; p.toolthickness = toolthickness;
         if (!planner.apply_params() || !planner.gen_path()) return;
         Path_set.clear();
         int S = planner.num_slices();
@@ -68,7 +71,7 @@ private:
     void note(const char *what) { fprintf(stderr, "ppp: %s() is outside the accelerated path (no-op)\n", what); }
 
     ppp::Planner planner;
-    double toolRadius = 15;
+    double toolRadius = 15, depth = 0.005, Adjust_Threshold = 1, toolthickness = 10; /* Path_Generate.h:71 */
     std::vector<Spline> Path_set;
     std::string file_name;
 };

@@ -4,8 +4,9 @@
  * src/connect1.cpp.  Same public methods and constructor arguments; the arithmetic runs on the
  * MI355X through include/ppp_hip.h.  Differences a caller can observe:
  *   - show() prints a notice instead of opening a PCL viewer (visualisation is out of scope);
- *   - Dynamic_adjustment / Alignment / Smooth / RemoveOutlier = true are reported and ignored
- *     (SURVEY.md 8f "next" rows), the equal-spacing path is produced;
+ *   - Dynamic_adjustment = true runs the curvature-driven re-spacing (path_dynamic_alg.cpp:77-306)
+ *     on the GPU; Alignment / Smooth / RemoveOutlier = true are reported and ignored
+ *     (SURVEY.md 8f rank 3);
  *   - conditions on which the reference aborts (GSL / FLANN) are reported on stderr instead.
  * Build connect1's single-direction walk with -DPPP_SDIR (it links dynamic_alg_sdir.cpp in the
  * reference, CMakeLists.txt:38-47).
@@ -126,8 +127,9 @@ private:
         SectPath::read_config(filename);
         ppp_config &c = planner.config();
         depth = c.depth; Adjust_Threshold = c.adjust_threshold; toolthickness = c.toolthickness; Adjust = c.dynamic_adjustment;
-        if (Adjust)
-            fprintf(stderr, "ppp: Dynamic_adjustment=true is not accelerated yet (SURVEY.md 8f rank 1): producing the equal-spacing path\n");
+        /* path_dynamic_alg.cpp:337-372: with Adjust the slices left/right of the centre are re-fitted
+           against the boundary of their inner neighbour (compute_boundary / dynamic_adjust_path) */
+        c.params.dynamic_adjustment = Adjust ? 1 : 0;
     }
     double depth = 0.01, Adjust_Threshold = 1, toolthickness = 10;
     bool Adjust = false;

@@ -919,14 +919,15 @@ struct ppo_handle {
         bisection(node, boundary, itr + 1, key);
     }
 
-    /* dynamic_adjust_path (path_dynamic_alg.cpp:267-306); returns < 0 where the reference aborts */
-    int dynamic_adjust_path(Spline &origin, const Spline &boundary, int key)
+    /* dynamic_adjust_path (path_dynamic_alg.cpp:267-306; v1: Path_Generation.cpp:585-634, whose loop
+       leaves both end samples out); returns < 0 where the reference aborts */
+    int dynamic_adjust_path(Spline &origin, const Spline &boundary, int key, bool v1 = false)
     {
         std::map<double, std::array<double, 2>> new_path;
         double miny = origin.small_y, maxy = origin.big_y, dy = 0;
         int NumOfNode = (int)((maxy - miny) / 5);
         ensure_tree();
-        for (int i = 0; i <= NumOfNode; i++) {
+        for (int i = v1 ? 1 : 0; v1 ? i < NumOfNode : i <= NumOfNode; i++) {
             dy = ((maxy - miny) / NumOfNode * i) + miny;
             /* B.13: for i == NumOfNode the rounded product can land an ulp beyond the last knot, where
                gsl_spline_eval raises GSL_EDOM and the reference aborts; evaluate at the last knot */
@@ -977,7 +978,18 @@ struct ppo_handle {
             return chain(c + 1, S, +1, 1);
         }
         if (P.walk == PPO_WALK_SDIR_INT) return chain(1, S, +1, 1);
-        return 0; /* SectPath::GenPath has no adjustment */
+        if (P.walk == PPO_WALK_V1_CONTACT) {
+            /* Contact_Path_Generation (Path_Generation.cpp:711-725): every path but the first is adjusted
+               against the boundary (Area2Cloud key 0 = max x) of its already adjusted predecessor; a
+               predecessor without a boundary ("generate boundary fail", :589-592) leaves the path as is */
+            for (int s = 1; s < S; ++s) {
+                Spline boundary;
+                if (!compute_boundary(path_set[s - 1], boundary, 1)) continue;
+                if (dynamic_adjust_path(path_set[s], boundary, 1, true) < 0) return -(1 + s);
+            }
+            return 0;
+        }
+        return 0; /* SectPath::GenPath and slicing_method have no adjustment */
     }
 
     int gen_path()

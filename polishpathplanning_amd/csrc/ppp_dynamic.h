@@ -343,7 +343,10 @@ __global__ void __launch_bounds__(256) k_dyn_boundary_fit(DevMeta *m, int walk, 
     for (int q = threadIdx.x; q < n; q += blockDim.x) mcount += (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
     int node_number;
     block_exscan(mcount, s_scr, &node_number);
-    if (node_number <= 2) return; /* compute_boundary returns 0: the previous boundary stays */
+    if (node_number <= 2) { /* compute_boundary returns 0: the previous boundary stays; v1 has none then (Path_Generation.cpp:589-592) */
+        if (walk == 3 && threadIdx.x == 0) Bf.bnd_n[chain] = 0;
+        return;
+    }
     double *ky = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *kx = ky + (Bf.maxNB + 2), *kz = kx + (Bf.maxNB + 2);
     for (int base = 0; base < n; base += blockDim.x) {
         const int q = base + threadIdx.x;
@@ -386,10 +389,15 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     if (mm < 3) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
     const double miny = (double)node_y[st], maxy = (double)node_y[st + mm - 1];
     const int NumOfNode = (int)((maxy - miny) / 5);
-    if (i > NumOfNode) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
+    const bool v1 = walk == 3; /* Path_Generation.cpp:607: for (i = 1; i < NumOfNode; i++) */
+    const int ii = v1 ? i + 1 : i;
+    if (v1 ? ii >= NumOfNode : ii > NumOfNode) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
     const int nb = Bf.bnd_n[chain];
-    if (nb < 3) { if (lane == 0) set_err(m, DERR_SLICE, c.s); return; } /* no boundary yet: the reference reads an unconstructed Spline */
-    double dy = ((maxy - miny) / NumOfNode * i) + miny;
+    if (nb < 3) { /* no boundary: v1 leaves the path alone; v2 would read an unconstructed Spline */
+        if (lane == 0) { if (v1) *dst = make_float4(0, 0, 0, 0); else set_err(m, DERR_SLICE, c.s); }
+        return;
+    }
+    double dy = ((maxy - miny) / NumOfNode * ii) + miny;
     if (dy > maxy) dy = maxy; /* B.13: the reference aborts in GSL when the last sample lands an ulp past the last knot */
     if (!(dy >= miny && dy <= maxy)) { if (lane == 0) set_err(m, DERR_DOMAIN, c.s); return; } /* gsl_spline_eval: GSL_EDOM */
     double node[3];
@@ -434,6 +442,7 @@ __global__ void __launch_bounds__(256) k_dyn_adjust_fit(DevMeta *m, int walk, in
     const int chain = blockIdx.x;
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
+    if (walk == 3 && Bf.bnd_n[chain] < 3) return; /* "generate boundary fail": the path stays as fitted */
     const int cap = 4096;
     u64 *keys = (u64 *)s_raw;
     int *hist = (int *)(keys + cap);

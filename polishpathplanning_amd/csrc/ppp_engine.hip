@@ -181,8 +181,8 @@ int validate_params(ppp_handle h, const ppp_params *p)
     if (p->smooth_max_sweeps < 1 || p->smooth_max_sweeps > SM_MAXS) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps must be in [1, 512]");
     if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
     if (p->dynamic_adjustment) {
-        if (p->pairing != PPP_PAIR_KD || (p->walk != PPP_WALK_CENTER_INT && p->walk != PPP_WALK_SDIR_INT))
-            return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment is implemented for the connect / connect1 planners (kd pairing, centre-out or single-direction walk)");
+        if (p->walk != PPP_WALK_CENTER_INT && p->walk != PPP_WALK_SDIR_INT && p->walk != PPP_WALK_V1_CONTACT)
+            return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment exists for the connect / connect1 / main planners only (walks center_int, sdir_int, v1_contact); SectPath and slicing_method have none");
         if (p->curvature_k < 3 || p->curvature_k > 64) return fail(h, PPP_ERR_ARG, "curvature_k must be in [3, 64]");
         if (!(p->depth > 0) || !(p->adjust_threshold >= 0) || !(p->toolthickness > 0)) return fail(h, PPP_ERR_ARG, "depth / Adjust_Threshold / toolthickness");
     }

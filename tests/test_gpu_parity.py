@@ -245,10 +245,10 @@ def test_short_slices_take_the_sequential_rpy_path(engine_mod, oracle_mod):
 def test_unsupported_options_fail_loudly(engine_mod):
     e = engine_mod.Engine(0)
     with pytest.raises(engine_mod.PPPError) as ei:
-        e.set_params(dynamic_adjustment=1, pairing=1)   # only the kd planners (connect / connect1) have it
+        e.set_params(dynamic_adjustment=1, walk=0)   # SectPath::GenPath has no adjustment (path_slicing_alg.cpp:290-342)
     assert ei.value.code == engine_mod.ERR_UNSUPPORTED
     with pytest.raises(engine_mod.PPPError):
-        e.set_params(alignment=1, dynamic_adjustment=0, pairing=0)
+        e.set_params(alignment=1, dynamic_adjustment=0, walk=1)
     with pytest.raises(engine_mod.PPPError):
         e.set_params(alignment=0, path_resolution=0.0)
 
@@ -290,9 +290,10 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path):
+@pytest.mark.parametrize("dynamic", [0, 1])
+def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic):
     """The drop-in C++ classes (include/Path_Generate_Algorithm.h) driven like src/connect.cpp:
-    PCD in, pathFile out."""
+    PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13)."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "connect1", "main"], stdout=subprocess.DEVNULL)
@@ -302,7 +303,8 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path):
     out = str(tmp_path / "WayPoints.txt")
     conf = tmp_path / "config.txt"
     conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
-                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n" % out)
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = %s\n"
+                    "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n" % (out, "true" if dynamic else "false"))
     env = dict(os.environ, PPP_CONFIG=str(conf))
     for exe, walk in (("connect", 1), ("connect1", 2)):
         if os.path.exists(out):
@@ -311,7 +313,7 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path):
         assert r.returncode == 0, r.stderr
         assert "!!!!! GOT PATH !!!!!" in r.stdout
         got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
-        o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk)
+        o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk, dynamic_adjustment=dynamic)
         o.gen_path(); o.get_path()
         want = o.waypoints()
         assert got.shape == want.shape
@@ -450,12 +452,15 @@ def test_area2cloud_api(engine_mod, oracle_mod):
         assert np.median(d) == 0.0   # and almost always nothing moves at all
 
 
-@pytest.mark.parametrize("walk", [1, 2])
+@pytest.mark.parametrize("walk", [1, 2, 3])
 def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
-    """GenPath with Dynamic_adjustment = true (config.txt:13) for connect (walk 1) and connect1 (walk 2):
+    """GenPath with Dynamic_adjustment = true (config.txt:13) for connect (walk 1), connect1 (walk 2) and
+    Contact_Path_Generation of ./main (walk 3: brute pairing, 10 neighbours, inner samples only):
     every adjusted knot is a cloud point, so the knot lists must be identical."""
     pts, cfg = synth.make_config("small_40k")
     kw = dict(tool_radius=6.0, walk=walk, dynamic_adjustment=1)
+    if walk == 3:
+        kw.update(pairing=1, curvature_k=10, depth=0.005)
     o = oracle_mod.Oracle(pts, **kw)
     e = engine_mod.Engine(0, **kw)
     e.set_cloud(pts)
@@ -473,4 +478,5 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
     assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
     # and it differs from the equal-spacing path
     e2 = engine_mod.Engine(0, tool_radius=6.0, walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
-    assert np.abs(e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0] - e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]).max() > 0.05
+    a, b = e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0], e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]
+    assert a.shape != b.shape or np.abs(a - b).max() > 0.05   # v1 drops the end samples, so its paths get shorter
