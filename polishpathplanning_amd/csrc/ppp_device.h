@@ -124,9 +124,19 @@ __device__ inline unsigned long long ppp_stamp()
 }
 #define STAMP_BEGIN() const bool _st_on = (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0); unsigned long long _st_t = ppp_stamp()
 #define STAMP(kid, slot) do { unsigned long long _n = ppp_stamp(); if (_st_on) g_stamps[kid][slot] += _n - _st_t; _st_t = _n; } while (0)
+/* the same for helpers called from a kernel: the kernel owns the context and passes it down */
+struct StampCtx {
+    bool on; unsigned long long t; int kid;
+    __device__ inline void begin(int k, bool enable) { kid = k; on = enable; t = ppp_stamp(); }
+    __device__ inline void mark(int slot) { unsigned long long n = ppp_stamp(); if (on) g_stamps[kid][slot] += n - t; t = n; }
+};
 #else
 #define STAMP_BEGIN() do { } while (0)
 #define STAMP(kid, slot) do { } while (0)
+struct StampCtx {
+    __device__ inline void begin(int, bool) {}
+    __device__ inline void mark(int) {}
+};
 #endif
 
 /* ---- block-wide helpers (blockDim.x multiple of 64, <= 1024) ---- */

@@ -20,97 +20,122 @@ struct DynParams {
     double tool_radius, depth, toolthickness, adjust_threshold;
     int k;          /* 50: path_dynamic_alg.cpp:87 */
     float r0;       /* first search radius of the k-NN gather */
+    float r1;       /* first search radius of the 1-NN snap   */
 };
 
-struct DynWaveLds {
-    float d2[DYN_KNN_CAP];
+struct __attribute__((aligned(16))) DynWaveLds {
+    u64 key[DYN_KNN_CAP];  /* (bits of the squared distance) << 32 | cloud index: one compare ranks a candidate */
     int pos[DYN_KNN_CAP];
     int sel[64];
+    int off[65];  /* exclusive prefix of the y-window sizes of 64 neighbouring slabs */
+    int w0[64];   /* first position of each window                                  */
 };
 
 /* exact k nearest neighbours of q (ascending (distance, cloud index)): returns kk <= k, positions
-   in L.sel[0..kk).  All 64 lanes of the wave call this together. */
-__device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float qy, float qz, int k, float r0)
+   in L.sel[0..kk).  All 64 lanes of the wave call this together.
+   Every slab the search ball touches is binary-searched for its y-window by its own lane (the
+   searches are chains of dependent loads: side by side they cost one chain, not one per slab); the
+   windows are then walked as one flat list, 64 candidates per step. */
+__device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float qy, float qz, int k, float r0, StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
     const int B = V.m->B;
     const int total = V.m->n_valid;
     float r = r0;
     int count = 0;
-    for (int attempt = 0; attempt < 40; ++attempt) {
+    for (int attempt = 0; attempt < 48; ++attempt) {
         const float r2 = r * r;
         count = 0;
         bool overflow = false;
-        auto scan_slab = [&](int b) {
-            const int s0 = V.slab_start[b], s1 = V.slab_start[b + 1];
-            if (s0 >= s1) return;
-            const int w0 = lower_bound_y(V, s0, s1, qy - r);
-            for (int base = w0; base < s1; base += 64) {
-                const int i = base + lane;
-                bool in = false, stop = false;
+        const float pady = 1e-5f * (fabsf(qy) + r) + 1e-6f, padx = 1e-5f * (fabsf(qx) + r) + 1e-6f;
+        const float ylo = qy - r - pady, yhi = qy + r + pady;
+        int blo = slab_of(V.m, qx - r - padx) - 1, bhi = slab_of(V.m, qx + r + padx) + 1;
+        blo = blo < 0 ? 0 : blo;
+        bhi = bhi >= B ? B - 1 : bhi;
+        for (int cb = blo; cb <= bhi && !overflow; cb += 64) {
+            const int bb = cb + lane;
+            int a = 0, e = 0;
+            if (bb <= bhi) {
+                const int s0 = V.slab_start[bb], s1 = V.slab_start[bb + 1];
+                int l0 = s0, l1 = s1, u0 = s0, u1 = s1; /* first y >= ylo, first y > yhi */
+                while (l0 < l1 || u0 < u1) {
+                    if (l0 < l1) { const int mid = (l0 + l1) >> 1; if (V.at(mid).y < ylo) l0 = mid + 1; else l1 = mid; }
+                    if (u0 < u1) { const int mid = (u0 + u1) >> 1; if (V.at(mid).y <= yhi) u0 = mid + 1; else u1 = mid; }
+                }
+                a = l0; e = u0 < l0 ? l0 : u0;
+            }
+            const int cnt = e - a;
+            int inc = cnt;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+            const int T = __shfl(inc, 63, 64);
+            __builtin_amdgcn_wave_barrier();
+            L.off[lane] = inc - cnt; L.w0[lane] = a;
+            if (lane == 63) L.off[64] = T;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            for (int base = 0; base < T; base += 64) {
+                const int t = base + lane;
+                bool in = false;
                 float d = 0.f;
-                if (i < s1) {
+                int i = 0, id = 0;
+                if (t < T) {
+                    int lo = 0, hi = 63; /* the window holding flat position t: last lane with off <= t */
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= t) lo = mid; else hi = mid - 1; }
+                    i = L.w0[lo] + (t - L.off[lo]);
                     const float4 c = V.at(i);
-                    stop = (c.y - qy) > r;      /* ascending y: nothing further can be inside */
                     d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
+                    id = idx_of(c);
                     in = d <= r2;
                 }
                 const u64 mask = __ballot(in);
                 if (in) {
-                    int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (slot < DYN_KNN_CAP) { L.d2[slot] = d; L.pos[slot] = i; }
+                    const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.pos[slot] = i; }
                 }
                 count += __popcll(mask);
-                if (count > DYN_KNN_CAP) overflow = true;
-                if (__ballot(stop)) break;
+                if (count > DYN_KNN_CAP) { overflow = true; break; }
             }
-        };
-        const int b = slab_of(V.m, qx);
-        scan_slab(b);
-        for (int bb = b + 1; bb < B; ++bb) {
-            if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
-            float dx = V.slab_xmin[bb] - qx;
-            if (dx > 0.f && dx > r) break;
-            scan_slab(bb);
-        }
-        for (int bb = b - 1; bb >= 0; --bb) {
-            if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
-            float dx = qx - V.slab_xmax[bb];
-            if (dx > 0.f && dx > r) break;
-            scan_slab(bb);
         }
         if (overflow) { r *= 0.8f; continue; }
         if (count >= k || count >= total) break;
         r *= 1.5f;
     }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    sc.mark(2);
     const int kk = count < k ? count : k;
-    /* rank by counting: (distance, cloud index) is a total order */
+    /* rank by counting: (distance, cloud index) is a total order; d >= 0, so its bit pattern orders like the value.
+       The keys are read two per LDS access (every lane the same address: a broadcast), padded to a multiple of 8 */
+    const int cpad = (count + 7) & ~7;
+    for (int c = count + lane; c < cpad; c += 64) L.key[c] = ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     for (int c = lane; c < count; c += 64) {
-        const float dc = L.d2[c];
-        const int ic = idx_of(V.at(L.pos[c]));
+        const u64 kc = L.key[c];
         int rank = 0;
-        for (int o = 0; o < count; ++o) {
-            const float dd = L.d2[o];
-            if (dd < dc) rank++;
-            else if (dd == dc && o != c && idx_of(V.at(L.pos[o])) < ic) rank++;
+        const ulonglong2 *kv = (const ulonglong2 *)L.key;
+        for (int o = 0; o < cpad / 2; o += 4) {
+            const ulonglong2 a0 = kv[o], a1 = kv[o + 1], a2 = kv[o + 2], a3 = kv[o + 3];
+            rank += (a0.x < kc) + (a0.y < kc) + (a1.x < kc) + (a1.y < kc) + (a2.x < kc) + (a2.y < kc) + (a3.x < kc) + (a3.y < kc);
         }
         if (rank < kk) L.sel[rank] = L.pos[c];
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    sc.mark(3);
     return kk;
 }
 
 /* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative. */
 __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
                                        const float *__restrict__ ell_cs, const DynParams &D, const double point[3], int key,
-                                       float bound[3])
+                                       float bound[3], StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
     const float sp[3] = {(float)point[0], (float)point[1], (float)point[2]};
     bound[0] = bound[1] = bound[2] = NAN;
     if (!(sp[0] == sp[0] && sp[1] == sp[1] && sp[2] == sp[2])) return;
-    const int kk = wave_knn(V, L, sp[0], sp[1], sp[2], D.k, D.r0);
+    const int kk = wave_knn(V, L, sp[0], sp[1], sp[2], D.k, D.r0, sc);
     if (kk <= 0) return;
     /* computePointPrincipalCurvatures: lane r holds the neighbour of rank r */
     float nn[3] = {0.f, 0.f, 0.f};
@@ -157,6 +182,7 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
     for (int q = 0; q < 3; ++q) cv[q] = cp[bi][q] / len[bi];
     const float inv = 1.0f / (float)kk;
     const float pc0 = ev[2] * inv, pc1 = ev[1] * inv;
+    sc.mark(4);
     /* compute_transform: [n x c | c | n | p] */
     float cr[3];
     cross3f(n0, cv, cr);
@@ -206,6 +232,7 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
         if (take) { bx = ox; by = oy; bz = oz; ba = oa; have = true; }
     }
     if (have) { bound[0] = bx; bound[1] = by; bound[2] = bz; }
+    sc.mark(5);
 }
 
 /* API: Area2Cloud for k query points (one wave each) */
@@ -224,7 +251,8 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_area2cloud_api(DevMeta *m, D
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     double p[3] = {pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]};
     float b[3];
-    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, p, key, b);
+    StampCtx sc; sc.begin(15, false);
+    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, p, key, b, sc);
     if ((threadIdx.x & 63) == 0) { out[3 * q] = b[0]; out[3 * q + 1] = b[1]; out[3 * q + 2] = b[2]; }
 }
 
@@ -274,6 +302,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
         const int *__restrict__ node_start, const int *__restrict__ node_cnt, DynBuffers Bf)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
+    StampCtx sc; sc.begin(3, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
     if (m->err) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * DYN_WAVES + wv, chain = blockIdx.y;
@@ -283,15 +312,27 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     float4 *dst = Bf.bnd_pts + (size_t)chain * Bf.maxNB + j;
     if (mm < 3) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
     const double miny = (double)node_y[st], maxy = (double)node_y[st + mm - 1];
-    double dy = miny + 2;
-    for (int q = 0; q < j; ++q) dy += D.tool_radius / 4; /* dy += toolRadius/4 accumulates */
+    /* dy = miny + 2; dy += toolRadius/4 per sample.  When start and step are multiples of 2^-20 (float knots and the
+       usual radii are) every partial sum is exact in double and the closed form gives the same bits; else accumulate */
+    const double dstep = D.tool_radius / 4, dy0 = miny + 2;
+    double dy;
+    if (floor(dstep * 1048576.0) == dstep * 1048576.0 && floor(dy0 * 1048576.0) == dy0 * 1048576.0 &&
+        fabs(dy0) + (double)j * fabs(dstep) < 4294967296.0)
+        dy = dy0 + (double)j * dstep;
+    else {
+        dy = dy0;
+        for (int q = 0; q < j; ++q) dy += dstep;
+    }
     if (!(dy < maxy - 2)) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
+    sc.mark(0);
     double point[3];
     spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, point);
+    sc.mark(1);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     float b[3];
-    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, point, c.key, b);
+    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, point, c.key, b, sc);
     if (lane == 0) *dst = make_float4(b[0], b[1], b[2], 1.f);
+    sc.mark(6);
 }
 
 /* compute_boundary, second half (:211-234): std::map by y (last writer wins), two extra end knots */
@@ -379,6 +420,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
         const int *__restrict__ node_start, const int *__restrict__ node_cnt, DynBuffers Bf)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
+    StampCtx sc; sc.begin(4, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
     if (m->err) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * DYN_WAVES + wv, chain = blockIdx.y;
@@ -400,8 +442,10 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     double dy = ((maxy - miny) / NumOfNode * ii) + miny;
     if (dy > maxy) dy = maxy; /* B.13: the reference aborts in GSL when the last sample lands an ulp past the last knot */
     if (!(dy >= miny && dy <= maxy)) { if (lane == 0) set_err(m, DERR_DOMAIN, c.s); return; } /* gsl_spline_eval: GSL_EDOM */
+    sc.mark(0);
     double node[3];
     spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
+    sc.mark(1);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     const double *ky = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *kx = ky + (Bf.maxNB + 2);
     const double bminy = ky[0], bbigy = ky[nb - 1];
@@ -410,7 +454,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     /* bisection (:237-265), at most 6 Area2Cloud evaluations */
     for (int itr = 0; itr <= 5; ++itr) {
         float ab[3];
-        wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, node, c.key == 0 ? 1 : 0, ab);
+        wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, node, c.key == 0 ? 1 : 0, ab, sc);
         if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break;
         if (!(ab[1] == ab[1])) break;
         const int iv = gsl_bsearch(nb, (double)ab[1], BY);
@@ -419,15 +463,17 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
         if (fabs(norm0) < D.adjust_threshold) break;
         node[0] = node[0] - norm0;
         if (!(node[0] == node[0])) break;
+        sc.mark(6);
     }
+    sc.mark(7);
     /* kdtree.nearestKSearch(point, 3): only pointIdx[0] is used (:291-294) */
+    const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
+    const int got = (qx == qx && qy == qy && qz == qz) ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
     if (lane == 0) {
-        float4 p;
-        const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
-        int id = (qx == qx && qy == qy && qz == qz) ? nearest_in_slabs(V, qx, qy, qz, &p) : -1;
-        if (id < 0) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
-        else *dst = make_float4(p.y, p.x, p.z, 1.f);
+        if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
+        else { const float4 p = V.at(s_w[wv].sel[0]); *dst = make_float4(p.y, p.x, p.z, 1.f); }
     }
+    sc.mark(8);
 }
 
 /* dynamic_adjust_path, second half (:297-305): map by y, Spline::restart */

@@ -5,9 +5,11 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polishpathplanning_amd import engine, synth
 engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libppp_hip_stamps.so")
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_1m_s256"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if args else "cfg2_1m_s256"
+dynamic = 1 if "--dynamic" in sys.argv else 0
 pts, cfg = synth.make_config(name)
-e = engine.Engine(0, tool_radius=cfg["tool_radius"]); e.set_cloud(pts)
+e = engine.Engine(0, tool_radius=cfg["tool_radius"], dynamic_adjustment=dynamic); e.set_cloud(pts)
 out = (C.c_ulonglong * 256)()
 e.gen_path(); e.get_path(); engine.lib().ppp_dbg_stamps(out)  # warm-up + reset
 N = 10
@@ -17,6 +19,10 @@ e.sync(); engine.lib().ppp_dbg_stamps(out)
 labels = {0: ("k_slice_kd", ["gather", "band sort", "NN+lerp", "cand sort", "flatten"]),
           1: ("k_pose", ["staging", "dy+spline", "nearest", "normal", "pose+handeye"]),
           2: ("k_slab_scatter", ["zero", "count", "reserve", "scatter"])}
+if dynamic:
+    labels[3] = ("k_dyn_boundary_pts", ["prologue+dy", "spline", "knn search", "knn rank", "curvature", "ellipse", "store"])
+    labels[4] = ("k_dyn_adjust_pts", ["prologue", "spline", "knn search (all)", "knn rank (all)", "curvature", "ellipse",
+                                      "boundary eval", "-", "snap store"])
 for kid, (kn, ls) in labels.items():
     vals = [out[16 * kid + i] / N for i in range(len(ls))]
     tot = sum(vals) or 1
