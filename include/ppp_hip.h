@@ -68,12 +68,19 @@ typedef struct ppp_params {
     float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
     int    smooth_max_sweeps; /* cap of the smoothing loop                   */
     int    alignment;         /* Alignment / Smooth / RemoveOutlier: must be 0 (next rows)    */
-    int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306;
-                                 available for the kd pairing with the connect / connect1 walks */
+    int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306 for the connect /
+                                 connect1 walks, Path_Generation.cpp:362-634 for PPP_WALK_V1_CONTACT            */
     double depth;             /* depth            (config.txt:5)                              */
     double adjust_threshold;  /* Adjust_Threshold (config.txt:3)                              */
     double toolthickness;     /* toolthickness    (config.txt:4)                              */
     int    curvature_k;       /* neighbours of compute_transform: 50 (path_dynamic_alg.cpp:87) */
+    /* Slice-range sharding of ONE cloud over several GPUs (SURVEY.md 8e case ii): this handle plans the slices
+       [slice_begin, slice_end) of the walk only (slice_end <= 0: up to the last one).  Every handle still takes the
+       whole cloud (the walk needs its bounds) but indexes only the points within range_margin mm of its slices.
+       getPath then stops after HandEyeTransform (a12): postion_smooth couples neighbouring slices
+       (path_translation_alg.cpp:117-140), so it runs once on the gathered list -- ppp_finish_path_async. */
+    int    slice_begin, slice_end;
+    float  range_margin;      /* mm kept beyond the first/last band of the range (default 24) */
 } ppp_params;
 
 void ppp_default_params(ppp_params *p);
@@ -124,6 +131,17 @@ int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W);
 /* copies the list into a caller-owned DEVICE buffer (e.g. a framework tensor used as the
  * send buffer of the RCCL gather); asynchronous on the handle's stream after the count is known */
 int ppp_copy_waypoints_to_device(ppp_handle h, float *dst_dev, size_t cap, size_t *W);
+/* waypoints of every kept slice in list order (the sizes of the reference's per-slice vectors,
+ * path_translation_alg.cpp:156-169); zero for slices outside this handle's slice range */
+int ppp_get_waypoint_counts(ppp_handle h, int *counts, size_t cap, size_t *nkept);
+/* copies a W x 6 stage list (PPP_STAGE_WP_PRESMOOTH / PPP_STAGE_WP_SMOOTHED) into a caller-owned DEVICE buffer */
+int ppp_copy_stage_to_device(ppp_handle h, int stage, float *dst_dev, size_t cap, size_t *W);
+/* Second half of getPath on a list assembled elsewhere: postion_smooth, reduceRPY, TransFlangeposition
+ * (path_translation_alg.cpp:212-214) over `W` pre-smoothing waypoints in DEVICE memory (the blocks of
+ * the slice-range handles concatenated in slice order) with `counts[nkept]` waypoints per kept slice.
+ * Needs a handle planned for the same cloud and parameters (any slice range).  The result is read
+ * with ppp_get_waypoints / ppp_copy_waypoints_to_device / ppp_get_tail_index as after getPath. */
+int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const int *counts, size_t nkept);
 /* TailIndex (path_translation_alg.cpp:177,210) */
 int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n);
 

@@ -40,7 +40,7 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
 {
     const int lane = threadIdx.x & 63;
     const int B = V.m->B;
-    const int total = V.m->n_valid;
+    const int total = V.m->n_sorted;
     float r = r0;
     int count = 0;
     for (int attempt = 0; attempt < 48; ++attempt) {

@@ -60,6 +60,12 @@ struct ppp_handle_s {
     int B = 1, slab_cap = 4096, S_cap = 1, capb = 2048, W_cap = 1, node_cap = 1;
     float h_mn[3] = {0, 0, 0}, h_mx[3] = {0, 0, 0};
     int h_nvalid = 0;
+    /* slice-range handles (SURVEY.md 8e case ii) */
+    bool ranged = false;          /* plans a strict sub-range of the slices: getPath stops after a12 */
+    int sb = 0, se = 0;           /* the range, resolved against the walk */
+    float incl_lo = -INFINITY, incl_hi = INFINITY;
+    int n_range = 0;              /* expected number of indexed points */
+    bool list_final = false;      /* wp_out holds a finished WayPointsList */
 
     DevBuf<float> X, Y, Z;
     DevBuf<float4> unsorted4, sorted4;
@@ -143,6 +149,8 @@ DevParams dev_params(const ppp_handle h)
     memcpy(D.viewpoint, h->vp, sizeof(D.viewpoint));
     D.change_range = h->P.change_range; D.pairing = h->P.pairing; D.walk = h->P.walk; D.drop_ends = h->P.drop_ends;
     D.smooth = h->P.smooth; D.smooth_max_sweeps = h->P.smooth_max_sweeps;
+    D.slice_begin = h->P.slice_begin; D.slice_end = h->P.slice_end; D.ranged = h->ranged ? 1 : 0;
+    D.incl_lo = h->incl_lo; D.incl_hi = h->incl_hi;
     return D;
 }
 
@@ -180,6 +188,11 @@ int validate_params(ppp_handle h, const ppp_params *p)
     if (!(p->normal_radius > 0)) return fail(h, PPP_ERR_ARG, "normal_radius");
     if (p->smooth_max_sweeps < 1 || p->smooth_max_sweeps > SM_MAXS) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps must be in [1, 512]");
     if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
+    if (p->slice_begin < 0 || (p->slice_end > 0 && p->slice_end < p->slice_begin)) return fail(h, PPP_ERR_ARG, "slice_begin / slice_end");
+    if ((p->slice_begin > 0 || p->slice_end > 0) && !(p->range_margin >= 2 * p->normal_radius))
+        return fail(h, PPP_ERR_ARG, "range_margin must be at least twice the normal radius");
+    if ((p->slice_begin > 0 || p->slice_end > 0) && p->dynamic_adjustment)
+        return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment chains slice s to slice s-1: it does not shard by slice range (SURVEY.md 8e)");
     if (p->dynamic_adjustment) {
         if (p->walk != PPP_WALK_CENTER_INT && p->walk != PPP_WALK_SDIR_INT && p->walk != PPP_WALK_V1_CONTACT)
             return fail(h, PPP_ERR_UNSUPPORTED, "Dynamic_adjustment exists for the connect / connect1 / main planners only (walks center_int, sdir_int, v1_contact); SectPath and slicing_method have none");
@@ -240,7 +253,32 @@ int make_plan(ppp_handle h)
 {
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     const int n = (int)h->n;
-    /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS */
+    /* exact slice count from the cached bounds (the device recomputes the same walk) */
+    int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
+    if (S >= PPP_WALK_HARD_MAX) return fail(h, PPP_ERR_CAPACITY, "slice walk does not terminate");
+    /* slice range -> the x interval whose points this handle indexes */
+    h->sb = std::min(std::max(0, h->P.slice_begin), S);
+    h->se = (h->P.slice_end <= 0 || h->P.slice_end > S) ? S : h->P.slice_end;
+    h->ranged = S > 0 && (h->sb > 0 || h->se < S);
+    h->incl_lo = -INFINITY; h->incl_hi = INFINITY;
+    h->n_range = h->h_nvalid;
+    if (h->ranged) {
+        if (h->sb >= h->se) { h->incl_lo = INFINITY; h->incl_hi = -INFINITY; h->n_range = 0; } /* empty range: index nothing */
+        else {
+            std::vector<float> px((size_t)S);
+            ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, px.data(), S);
+            /* Path_set is ascending in x; band of slice s = [int(px) - 2, int(px) + 2] (rangedX_index) */
+            h->incl_lo = (float)((int)px[h->sb] - 2) - h->P.range_margin;
+            h->incl_hi = (float)((int)px[h->se - 1] + 2) + h->P.range_margin;
+            const double range = (double)h->h_mx[0] - (double)h->h_mn[0];
+            const double part = std::min((double)h->incl_hi, (double)h->h_mx[0]) - std::max((double)h->incl_lo, (double)h->h_mn[0]);
+            h->n_range = range > 0 ? (int)std::min((double)h->h_nvalid, std::max(0.0, part / range) * h->h_nvalid * 1.05 + 64) : h->h_nvalid;
+        }
+    }
+    /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS.  A slice-range handle
+       keeps the WHOLE cloud's slab grid and just leaves the slabs outside its interval empty: its slabs then hold
+       the same points in the same order as a whole-cloud handle's, so every sum over neighbours (normals) adds
+       in the same order and the sharded list is bit-identical to the unsharded one. */
     int B = (h->h_nvalid + 639) / 640;
     B = std::max(1, std::min(B, 8192));
     h->B = B;
@@ -253,9 +291,6 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->big_slabs.ensure(B));
     h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
     HIPCHK(h, h->mm_part.ensure(h->mm_grid));
-    /* exact slice count from the cached bounds (the device recomputes the same walk) */
-    int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
-    if (S >= PPP_WALK_HARD_MAX) return fail(h, PPP_ERR_CAPACITY, "slice walk does not terminate");
     h->S_cap = std::max(1, S);
     HIPCHK(h, h->big_slices.ensure(h->S_cap));
     /* band capacity: expected points in a 4 mm band, x2 margin, power of two in [1024, 4096] */
@@ -303,7 +338,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->sm_part.ensure((size_t)(SM_MAXS + SM_K + 1) * h->sm_tiles));
     HIPCHK(h, h->sm_chist.ensure(SM_MAXS + SM_K + 1));
     h->planned = true;
-    h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
     h->drop_graph(); /* buffer addresses and launch geometry are baked into the captured graph */
     return PPP_OK;
 }
@@ -320,7 +355,7 @@ int enqueue_index(ppp_handle h)
     const float slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f;
     LAUNCH(h, "k_minmax", k_minmax<false>, h->mm_grid, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, 0.f, 0.f, 0, (int *)nullptr);
     int gh = std::max(1, std::min((n / 4 + 256 * 8 - 1) / (256 * 8), 512));
-    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, slab_x0, slab_invw, h->B, h->slab_cnt.p);
+    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, slab_x0, slab_invw, h->B, h->slab_cnt.p, h->incl_lo, h->incl_hi);
     LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
            h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
@@ -411,6 +446,7 @@ int map_dev_err(ppp_handle h)
     case DERR_CAPACITY: return fail(h, PPP_ERR_CAPACITY, "device capacity exceeded (slab / band / node / waypoint buffer)");
     case DERR_DOMAIN: return fail(h, PPP_ERR_DOMAIN, "spline evaluated outside its knots");
     case DERR_QUERY: return fail(h, PPP_ERR_DOMAIN, "non-finite waypoint handed to the nearest-neighbour query");
+    case DERR_MARGIN: return fail(h, PPP_ERR_CAPACITY, "a waypoint's nearest neighbour or its normal neighbourhood reaches beyond the indexed slice range: raise range_margin");
     }
     return fail(h, PPP_ERR_HIP, "unknown device error");
 }
@@ -512,6 +548,7 @@ void ppp_default_params(ppp_params *p)
     p->smooth_max_sweeps = 32;
     p->alignment = 0; p->dynamic_adjustment = 0; /* config.txt says true: the planner classes pass it through */
     p->depth = 0.01; p->adjust_threshold = 1; p->toolthickness = 10; p->curvature_k = 50;
+    p->slice_begin = 0; p->slice_end = 0; p->range_margin = 24.f;
 }
 
 const char *ppp_version(void) { return PPP_VERSION_STR; }
@@ -628,6 +665,19 @@ int ppp_gen_path_async(ppp_handle h)
     return enqueue_meta_copy(h);
 }
 
+/* getPath's second half: postion_smooth, reduceRPY, TransFlangeposition (path_translation_alg.cpp:212-214) */
+int enqueue_finish(ppp_handle h, const DevParams &D)
+{
+    const int gw = std::max(1, (h->W_cap + 63) / 64);
+    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
+    const int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
+    for (int b = 0; b <= nb; ++b)
+        LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
+               h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
+    return PPP_OK;
+}
+
 int ppp_get_path_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
@@ -637,20 +687,37 @@ int ppp_get_path_async(ppp_handle h)
     LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
            h->wp_off.p, h->tail.p, h->W_cap, h->big_path ? 1 : 0);
     int nk = std::max(1, h->S_cap);
-    int gw = std::max(1, (h->W_cap + 63) / 64);
     LAUNCH(h, "k_pose", k_pose, nk, 256, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
            h->capb,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
-    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
-    {
-        int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
-        for (int b = 0; b <= nb; ++b)
-            LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
-    }
-    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
     h->path_done = true;
+    h->list_final = false;
+    /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
+    if (!h->ranged) {
+        int rc = enqueue_finish(h, D);
+        if (rc) return rc;
+        h->list_final = true;
+    }
+    return enqueue_meta_copy(h);
+}
+
+int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const int *counts, size_t nkept)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    if ((W && !pre6_dev) || (nkept && !counts)) return fail(h, PPP_ERR_ARG, "bad arguments");
+    if (W > (size_t)h->W_cap || nkept > (size_t)h->S_cap) return fail(h, PPP_ERR_CAPACITY, "the list is larger than this handle's plan (other cloud or parameters?)");
+    if (!h->index_built) { int rc = enqueue_index(h); if (rc) return rc; } /* the meta block is initialised by k_setup */
+    DevParams D = dev_params(h);
+    if (nkept) HIPCHK(h, hipMemcpyAsync(h->wp_cnt.p, counts, nkept * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, "k_count_given", k_count_given, 1, 1024, 0, h->meta.p, D, (int)nkept, (int)W, h->wp_cnt.p, h->wp_off.p, h->tail.p, h->W_cap);
+    if (W) LAUNCH(h, "k_load_pre", k_load_pre, (unsigned)((W + 255) / 256), 256, 0, h->meta.p, pre6_dev, h->wp_pre.p, h->sx.p);
+    int rc = enqueue_finish(h, D);
+    if (rc) return rc;
+    h->gen_done = true; h->path_done = true; h->list_final = true;
     return enqueue_meta_copy(h);
 }
 
@@ -715,10 +782,13 @@ int ppp_num_waypoints(ppp_handle h, size_t *W)
     return PPP_OK;
 }
 
+static const char *NOT_FINAL_MSG = "slice-range handle: the list ends before postion_smooth; gather the blocks and call ppp_finish_path_async";
+
 int ppp_get_waypoints(ppp_handle h, float *out6, size_t cap, size_t *W)
 {
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
+    if (!h->list_final) return fail(h, PPP_ERR_ARG, NOT_FINAL_MSG);
     rc = map_dev_err(h);
     if (rc) return rc;
     size_t w = (size_t)h->hmeta.W;
@@ -734,6 +804,7 @@ int ppp_get_waypoints_device(ppp_handle h, const float **dptr, size_t *W)
 {
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
+    if (!h->list_final) return fail(h, PPP_ERR_ARG, NOT_FINAL_MSG);
     rc = map_dev_err(h);
     if (rc) return rc;
     if (dptr) *dptr = h->wp_out.p;
@@ -745,6 +816,7 @@ int ppp_copy_waypoints_to_device(ppp_handle h, float *dst_dev, size_t cap, size_
 {
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
+    if (!h->list_final) return fail(h, PPP_ERR_ARG, NOT_FINAL_MSG);
     rc = map_dev_err(h);
     if (rc) return rc;
     size_t w = (size_t)h->hmeta.W;
@@ -761,6 +833,7 @@ int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n)
 {
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
+    if (!h->list_final) return fail(h, PPP_ERR_ARG, NOT_FINAL_MSG);
     rc = map_dev_err(h);
     if (rc) return rc;
     size_t nk = (size_t)h->hmeta.nkept;
@@ -768,6 +841,40 @@ int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n)
     if (tail && cap) {
         size_t k = std::min(cap, nk);
         if (k) HIPCHK(h, hipMemcpy(tail, h->tail.p, k * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+int ppp_get_waypoint_counts(ppp_handle h, int *counts, size_t cap, size_t *nkept)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    size_t nk = (size_t)h->hmeta.nkept;
+    if (nkept) *nkept = nk;
+    if (counts && cap) {
+        size_t k = std::min(cap, nk);
+        if (k) HIPCHK(h, hipMemcpy(counts, h->wp_cnt.p, k * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return PPP_OK;
+}
+
+int ppp_copy_stage_to_device(ppp_handle h, int stage, float *dst_dev, size_t cap, size_t *W)
+{
+    int rc = ensure_ready(h, true, true);
+    if (rc) return rc;
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    const float *src = stage == PPP_STAGE_WP_PRESMOOTH ? h->wp_pre.p : stage == PPP_STAGE_WP_SMOOTHED ? h->wp_smooth.p : nullptr;
+    if (!src) return fail(h, PPP_ERR_ARG, "stage must be PPP_STAGE_WP_PRESMOOTH or PPP_STAGE_WP_SMOOTHED");
+    if (stage == PPP_STAGE_WP_SMOOTHED && !h->list_final) return fail(h, PPP_ERR_ARG, NOT_FINAL_MSG);
+    size_t w = (size_t)h->hmeta.W;
+    if (W) *W = w;
+    size_t k = std::min(cap, w);
+    if (k && dst_dev) {
+        HIPCHK(h, hipMemcpyAsync(dst_dev, src, k * 24, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return PPP_OK;
 }
@@ -968,7 +1075,7 @@ int ppp_estimate_normals(ppp_handle h, float *out4)
     /* dropped (non-finite) points never enter the index: they keep the NaN fill */
     HIPCHK(h, hipMemsetAsync(h->scratch.p, 0xff, n * 16, h->stream));
     DevParams D = dev_params(h);
-    const int nsorted = h->hmeta.n_valid;
+    const int nsorted = h->hmeta.n_sorted;
     if (nsorted > 0)
         LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((nsorted + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
                h->slab_xmin.p, h->slab_xmax.p, nsorted, (float4 *)h->scratch.p);

@@ -29,6 +29,9 @@ struct DevMeta {
     int B;
     float slab_x0, slab_invw;
     int api_cnt, api_flag;
+    int sb, se;              /* slice range of this handle: [sb, se) */
+    float incl_lo, incl_hi;  /* x interval of the points this handle indexes */
+    int n_sorted;            /* points in the slab index */
 };
 
 struct DevParams {
@@ -37,9 +40,11 @@ struct DevParams {
     float handeye[6];
     float viewpoint[3];
     int change_range, pairing, walk, drop_ends, smooth, smooth_max_sweeps;
+    int slice_begin, slice_end, ranged;
+    float incl_lo, incl_hi;
 };
 
-enum { DERR_NONE = 0, DERR_SLICE = 1, DERR_CAPACITY = 2, DERR_DOMAIN = 3, DERR_QUERY = 4 };
+enum { DERR_NONE = 0, DERR_SLICE = 1, DERR_CAPACITY = 2, DERR_DOMAIN = 3, DERR_QUERY = 4, DERR_MARGIN = 5 };
 
 __device__ inline void set_err(DevMeta *m, int code, int slice)
 {
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     __shared__ int s_scan[17];
     __shared__ float s_mn[3][4], s_mx[3][4];
     __shared__ int s_cnt[4];
-    __shared__ int s_S;
+    __shared__ int s_S, s_total;
     __shared__ float s_front[4096];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
                 slab_cnt[b0 + k] = 0;
             }
         }
-        if (threadIdx.x == 0) slab_start[B] = total;
+        if (threadIdx.x == 0) { slab_start[B] = total; s_total = total; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -294,6 +299,10 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         r.B = B;
         r.slab_x0 = slab_x0;     /* the grid k_minmax<true> binned with */
         r.slab_invw = slab_invw;
+        r.sb = P.slice_begin < 0 ? 0 : (P.slice_begin > S ? S : P.slice_begin);
+        r.se = (P.slice_end <= 0 || P.slice_end > S) ? S : P.slice_end;
+        r.incl_lo = P.incl_lo; r.incl_hi = P.incl_hi;
+        r.n_sorted = s_total;
         *m = r;
         s_S = S;
     }
@@ -312,7 +321,8 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
 /* ------------------------------------------------------------------ */
 /* x-slab histogram: LDS-privatised, few workgroups (every workgroup flushes one global atomic per
    non-empty slab, so the grid stays small while each thread streams many points). */
-__global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, int n, float x0, float invw, int B, int *slab_cnt)
+__global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, int n, float x0, float invw, int B, int *slab_cnt,
+                                                   float xlo, float xhi)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
@@ -321,14 +331,15 @@ __global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, 
     const float4 *X4 = (const float4 *)X;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
         float4 x = X4[i];
-        if (x.x == x.x) atomicAdd(&s_hist[slab_of_grid(x.x, x0, invw, B)], 1);
-        if (x.y == x.y) atomicAdd(&s_hist[slab_of_grid(x.y, x0, invw, B)], 1);
-        if (x.z == x.z) atomicAdd(&s_hist[slab_of_grid(x.z, x0, invw, B)], 1);
-        if (x.w == x.w) atomicAdd(&s_hist[slab_of_grid(x.w, x0, invw, B)], 1);
+        /* NaN fails both comparisons; a whole-cloud handle passes -inf / +inf */
+        if (x.x >= xlo && x.x <= xhi) atomicAdd(&s_hist[slab_of_grid(x.x, x0, invw, B)], 1);
+        if (x.y >= xlo && x.y <= xhi) atomicAdd(&s_hist[slab_of_grid(x.y, x0, invw, B)], 1);
+        if (x.z >= xlo && x.z <= xhi) atomicAdd(&s_hist[slab_of_grid(x.z, x0, invw, B)], 1);
+        if (x.w >= xlo && x.w <= xhi) atomicAdd(&s_hist[slab_of_grid(x.w, x0, invw, B)], 1);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         float x = X[(n4 << 2) + threadIdx.x];
-        if (x == x) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
+        if (x >= xlo && x <= xhi) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -343,6 +354,7 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     const int B = m->B;
+    const float xlo = m->incl_lo, xhi = m->incl_hi;
     STAMP_BEGIN();
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
@@ -351,7 +363,7 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
     const int i1 = min(n, i0 + chunk);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         float x = X[i];
-        if (x == x) atomicAdd(&s_hist[slab_of(m, x)], 1);
+        if (x >= xlo && x <= xhi) atomicAdd(&s_hist[slab_of(m, x)], 1);
     }
     __syncthreads();
     STAMP(2, 1); /* count */
@@ -363,7 +375,7 @@ __global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ 
     STAMP(2, 2); /* reserve (global atomics) */
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         float x = X[i];
-        if (x == x) {
+        if (x >= xlo && x <= xhi) {
             int pos = atomicAdd(&s_hist[slab_of(m, x)], 1);
             unsorted4[pos] = make_float4(x, Y[i], Z[i], __int_as_float(i));
         }
@@ -678,6 +690,10 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
     __shared__ int s_n, s_base;
     const int s = blockIdx.x;
     if (s >= m->S) return;
+    if (s < m->sb || s >= m->se) { /* another handle's slice */
+        if (threadIdx.x == 0) { node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = 0; }
+        return;
+    }
     SliceLds L = carve_slice_lds(s_raw, capb);
     const float Px = px[s];
     int n = band_gather_sorted(L, capb, sorted4, slab_start, m, lo[s], hi[s], &s_n);
@@ -792,7 +808,13 @@ __global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sor
     if (ARENA) {
         if (s >= m->big_slices) return;
         s = big_list[s];
-    } else if (s >= m->S) return;
+    } else {
+        if (s >= m->S) return;
+        if (s < m->sb || s >= m->se) { /* another handle's slice */
+            if (threadIdx.x == 0) { node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = 0; }
+            return;
+        }
+    }
     STAMP_BEGIN();
     const float Px = px[s], blo = lo[s], bhi = hi[s];
     const int b0 = slab_of(m, blo), b1 = slab_of(m, bhi);
@@ -1034,10 +1056,12 @@ __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const f
         int cnt = 0;
         if (k < nk) {
             int s = k + m->first_kept;
-            int st = node_start[s], mm = node_cnt[s];
-            double miny = (double)node_y[st], bigy = (double)node_y[st + mm - 1];
-            double dy = miny + P.trim;
-            while (dy < bigy - P.trim && cnt <= W_cap) { cnt++; dy += P.path_resolution; }
+            if (s >= m->sb && s < m->se) {
+                int st = node_start[s], mm = node_cnt[s];
+                double miny = (double)node_y[st], bigy = (double)node_y[st + mm - 1];
+                double dy = miny + P.trim;
+                while (dy < bigy - P.trim && cnt <= W_cap) { cnt++; dy += P.path_resolution; }
+            }
         }
         int tot;
         int pre = block_exscan(cnt, scratch, &tot);
@@ -1057,6 +1081,57 @@ __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const f
         if (W > W_cap) { set_err(m, DERR_CAPACITY, -1); W = 0; }
         m->W = W;
         wp_off[nk] = W;
+    }
+}
+
+/* ppp_finish_path_async: the list was sampled elsewhere (slice-range handles); rebuild the per-run state
+   getPath's second half needs from the per-slice counts: offsets, TailIndex, the B.6 flag, W. */
+__global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,
+                                                      int W_cap)
+{
+    __shared__ int scratch[17];
+    __shared__ int s_run, s_short;
+    if (threadIdx.x == 0) { s_run = 0; s_short = 0; }
+    __syncthreads();
+    const int res_i = (int)P.rpy_resolution;
+    for (int base = 0; base < nk; base += blockDim.x) {
+        const int k = base + threadIdx.x;
+        const int cnt = k < nk ? wp_cnt[k] : 0;
+        int tot;
+        const int pre = block_exscan(cnt, scratch, &tot);
+        const int run = s_run;
+        if (k < nk) {
+            wp_off[k] = run + pre;
+            tail[k] = run + pre + cnt - 1;
+            if (P.rpy_resolution > 2 && cnt <= res_i) s_short = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->rpy_oob = 0; m->smooth_done = -1;
+        m->any_short = s_short;
+        m->nkept = nk;
+        m->big_slabs = 0; m->big_slices = 0; /* the index of this handle plays no part in what follows */
+        int W = s_run;
+        if (W != W_given || W > W_cap) { m->err = DERR_CAPACITY; W = 0; }
+        m->W = W;
+        wp_off[nk] = W;
+    }
+}
+
+/* ... and the list itself into the layouts k_pose leaves behind (AoS for the output stages, SoA positions
+   for the smoothing tiles) */
+__global__ void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float *__restrict__ pre6, float *wp_pre, float *sx)
+{
+    const int W = m->W;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m->err || w >= W) return;
+    for (int d = 0; d < 6; ++d) {
+        const float v = pre6[6 * (size_t)w + d];
+        wp_pre[6 * (size_t)w + d] = v;
+        if (d < 3) sx[(size_t)d * W + w] = v;
     }
 }
 
@@ -1296,6 +1371,13 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
         if (q.x == q.x && q.y == q.y && q.z == q.z) {
             float4 p;
             id = nearest_in_slabs(V, q.x, q.y, q.z, &p);
+            if (P.ranged && id >= 0) {
+                /* only part of the cloud is indexed: the answer is the whole cloud's as long as the ball that
+                   proves the nearest neighbour and the normal's radius search stay inside the indexed interval */
+                const float dq = sqrtf(dist2_flann(q.x, q.y, q.z, p.x, p.y, p.z)) * 1.0001f;
+                const float need_lo = fminf(q.x - dq, p.x - P.normal_radius * 1.0001f), need_hi = fmaxf(q.x + dq, p.x + P.normal_radius * 1.0001f);
+                if ((need_lo < m->incl_lo && m->incl_lo > m->mn[0]) || (need_hi > m->incl_hi && m->incl_hi < m->mx[0])) set_err(m, DERR_MARGIN, s);
+            }
             STAMP(1, 2); /* nearest */
             if (id >= 0) normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
             STAMP(1, 3); /* normal */
@@ -1339,7 +1421,7 @@ __global__ void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, co
                                                      const float *__restrict__ slab_xmax, int nsorted, float4 *out4)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (nsorted < 0 ? m->n_valid : nsorted)) return;
+    if (i >= (nsorted < 0 ? m->n_sorted : nsorted)) return;
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     const float4 p = sorted4[i];
     float n4[4];

@@ -51,6 +51,9 @@ class Params(C.Structure):
         ("adjust_threshold", C.c_double),
         ("toolthickness", C.c_double),
         ("curvature_k", C.c_int),
+        ("slice_begin", C.c_int),
+        ("slice_end", C.c_int),
+        ("range_margin", C.c_float),
     ]
 
 
@@ -74,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file",
+    "ppp_write_path_file", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -123,6 +126,9 @@ def lib():
         L.ppp_get_waypoints_device.argtypes = [vp, C.POINTER(vp), szp]
         L.ppp_copy_waypoints_to_device.argtypes = [vp, vp, sz, szp]
         L.ppp_get_tail_index.argtypes = [vp, ip, sz, szp]
+        L.ppp_get_waypoint_counts.argtypes = [vp, ip, sz, szp]
+        L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
+        L.ppp_finish_path_async.argtypes = [vp, vp, sz, ip, sz]
         L.ppp_minmax.argtypes = [vp, fp, fp]
         L.ppp_get_slice_positions.argtypes = [vp, fp, sz, szp]
         L.ppp_get_slice_indices.argtypes = [vp, C.c_int, ip, sz, szp]
@@ -320,6 +326,26 @@ class Engine:
         w = C.c_size_t()
         self._chk(self.L.ppp_copy_waypoints_to_device(self.h, C.c_void_p(dptr), cap, C.byref(w)))
         return w.value
+
+    def waypoint_counts(self):
+        """Waypoints per kept slice in list order (zero outside this handle's slice range)."""
+        n = C.c_size_t()
+        self._chk(self.L.ppp_get_waypoint_counts(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.int32)
+        self._chk(self.L.ppp_get_waypoint_counts(self.h, _i(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    def copy_stage_to_device(self, stage, dptr, cap):
+        """D2D copy of the pre-smoothing (or smoothed) W x 6 list into a caller-owned device buffer; returns W."""
+        w = C.c_size_t()
+        self._chk(self.L.ppp_copy_stage_to_device(self.h, stage, C.c_void_p(dptr), cap, C.byref(w)))
+        return w.value
+
+    def finish_path_async(self, dptr, W, counts):
+        """postion_smooth + reduceRPY + TransFlangeposition over a gathered pre-smoothing list in device memory
+        (SURVEY.md 8e case ii: the blocks of the slice-range handles, concatenated in slice order)."""
+        counts = np.ascontiguousarray(counts, np.int32)
+        self._chk(self.L.ppp_finish_path_async(self.h, C.c_void_p(dptr), int(W), _i(counts), counts.size))
 
     def tail_index(self):
         n = C.c_size_t()

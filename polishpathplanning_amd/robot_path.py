@@ -44,6 +44,30 @@ def gather_robot_path(local_wp, dist=None, device=None, counts=None):
     return [recv[r * wmax: r * wmax + counts[r]] for r in range(world)]
 
 
+def slice_ranges(num_slices, world):
+    """SURVEY.md 8e case (ii): GPU g plans the slices [g*S/world, (g+1)*S/world) of ONE cloud."""
+    return [(g * num_slices // world, (g + 1) * num_slices // world) for g in range(world)]
+
+
+def gather_slice_blocks(local_pre, local_counts, dist=None, device=None):
+    """Slice-range sharding: every rank holds the pre-smoothing waypoints (a12 output, [W_g, 6] float32 on
+    `device`) of its own slice range and the per-kept-slice counts (zero outside its range).  Returns on
+    rank 0 (pre_all [W, 6] in slice order, counts_all int32[nkept]); (None, None) elsewhere.  postion_smooth
+    couples neighbouring slices (path_translation_alg.cpp:117-140), so rank 0 then finishes the list once
+    (Engine.finish_path_async).  Ranges ascend with the rank, so rank order is slice order."""
+    import torch
+    local_counts = np.ascontiguousarray(local_counts, np.int32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_pre, local_counts
+    dev = local_pre.device if device is None else device
+    cnt = torch.from_numpy(local_counts.astype(np.int64)).to(dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # disjoint supports: the sum is the global per-slice count vector
+    blocks = gather_robot_path(local_pre, dist, dev)
+    if dist.get_rank() != 0:
+        return None, None
+    return torch.cat(blocks, dim=0), cnt.cpu().numpy().astype(np.int32)
+
+
 def concat_robot_path(blocks):
     """Rank-0 side: one W_total x 6 array, workpiece after workpiece."""
     import torch

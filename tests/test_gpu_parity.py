@@ -480,3 +480,93 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
     e2 = engine_mod.Engine(0, tool_radius=6.0, walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
     a, b = e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0], e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]
     assert a.shape != b.shape or np.abs(a - b).max() > 0.05   # v1 drops the end samples, so its paths get shorter
+
+
+# ---------------- slice-range sharding of one cloud (SURVEY.md 8e case ii) ----------------
+def _sharded_path(engine_mod, pts, world, **kw):
+    """What bench.py --mode slices does with `world` GPUs, on one GPU: one handle per slice range, blocks
+    concatenated in rank order, the list finished once on handle 0."""
+    from polishpathplanning_amd.robot_path import slice_ranges
+    probe = engine_mod.Engine(0, **kw); probe.set_cloud(pts)
+    S = len(probe.slice_positions())
+    W_cap = probe.gen_path() and probe.get_path()
+    gathered = _DeviceBuffer(max(W_cap, 1) * 24)         # stands in for the RCCL receive buffer on rank 0
+    engines, counts, W = [], None, 0
+    for b, e in slice_ranges(S, world):
+        if b == e:                                       # more ranks than slices: this rank contributes nothing
+            continue
+        eng = engine_mod.Engine(0, slice_begin=b, slice_end=e, **kw)
+        eng.set_cloud(pts)
+        eng.gen_path(); w = eng.get_path()
+        c = eng.waypoint_counts()
+        assert c.sum() == w
+        k0 = 1 if kw.get("drop_ends", 1) else 0
+        assert all(c[k] == 0 for k in range(len(c)) if not (b <= k + k0 < e))
+        assert eng.copy_stage_to_device(engine_mod.STAGE_WP_PRESMOOTH, gathered.ptr + 24 * W, W_cap - W) == w
+        W += w
+        counts = c if counts is None else counts + c
+        engines.append(eng)
+    fin = engines[0]
+    fin.finish_path_async(gathered.ptr, W, counts)
+    fin.sync()
+    return fin, gathered.to_host(W * 6), counts, engines
+
+
+class _DeviceBuffer:
+    """hipMalloc'ed bytes through the HIP runtime the engine already loaded (no torch in these tests)."""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        self.hip = C.CDLL("libamdhip64.so")
+        p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def to_host(self, nfloats):
+        import ctypes as C
+        out = np.empty(nfloats, np.float32)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(4 * nfloats), 2) == 0
+        return out.reshape(-1, 6)
+
+    def __del__(self):
+        import ctypes as C
+        self.hip.hipFree(C.c_void_p(self.ptr))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_slice_range_sharding_is_bit_identical_to_one_handle(engine_mod, world):
+    pts, cfg = synth.make_config("small_40k")
+    one = engine_mod.Engine(0, tool_radius=6.0); one.set_cloud(pts); one.gen_path(); W = one.get_path()
+    fin, pre, counts, engines = _sharded_path(engine_mod, pts, world, tool_radius=6.0)
+    assert pre.shape[0] == W and np.array_equal(counts, one.waypoint_counts())
+    assert np.array_equal(pre, one.stage(engine_mod.STAGE_WP_PRESMOOTH))
+    assert fin.num_waypoints() == W
+    assert fin.waypoints().tobytes() == one.waypoints().tobytes()
+    assert np.array_equal(fin.tail_index(), one.tail_index())
+    assert fin.smooth_sweeps() == one.smooth_sweeps()
+    # a range handle has no final list of its own
+    with pytest.raises(engine_mod.PPPError):
+        engines[1].waypoints()
+
+
+def test_slice_range_sharding_cfg5_parity_with_the_oracle(engine_mod, oracle_mod):
+    """cfg 3 geometry (250 k points, 128 slices) through 8 range handles, against the oracle's list."""
+    pts, cfg = synth.make_config("cfg3_250k_s128")
+    fin, pre, counts, _ = _sharded_path(engine_mod, pts, 8, tool_radius=cfg["tool_radius"])
+    o = oracle_mod.Oracle(pts, tool_radius=cfg["tool_radius"])
+    o.gen_path(); Wo = o.get_path()
+    assert fin.num_waypoints() == Wo
+    d = np.linalg.norm(fin.waypoints()[:, :3] - o.waypoints()[:, :3], axis=1)
+    assert d.max() <= TOL_M
+    assert np.array_equal(fin.tail_index(), o.tail_index())
+
+
+def test_slice_range_margin_too_small_is_reported(engine_mod):
+    pts, cfg = synth.make_config("small_40k")
+    e = engine_mod.Engine(0, tool_radius=6.0, slice_begin=5, slice_end=9, range_margin=5.0, normal_radius=2.5)
+    e.set_cloud(pts)
+    e.gen_path(); e.get_path()      # 5 mm cover the NN ball and the 2.5 mm normal neighbourhood of a waypoint on its plane
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.Engine(0, tool_radius=6.0, slice_begin=5, slice_end=9, range_margin=1.0)  # < 2 x normal radius
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.Engine(0, tool_radius=6.0, slice_begin=5, slice_end=9, dynamic_adjustment=1)

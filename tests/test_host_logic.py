@@ -88,6 +88,54 @@ def test_robot_path_gather_world2_gloo():
     assert np.array_equal(full, want)
 
 
+def _slice_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from polishpathplanning_amd.robot_path import gather_slice_blocks, slice_ranges
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, first_kept, nkept = 11, 1, 9              # drop_ends: slices 1..9 are kept
+    per_slice = np.array([3 + (k % 4) for k in range(nkept)], np.int32)
+    b, e = slice_ranges(S, world)[rank]
+    counts = np.array([per_slice[k] if b <= k + first_kept < e else 0 for k in range(nkept)], np.int32)
+    rows = []
+    for k in range(nkept):                       # waypoint value = 100 * kept slice + position
+        rows += [[100.0 * k + t] * 6 for t in range(counts[k])]
+    local = torch.tensor(rows, dtype=torch.float32).reshape(-1, 6)
+    pre, cnt = gather_slice_blocks(local, counts, dist)
+    if rank == 0:
+        q.put((pre.numpy(), cnt))
+    else:
+        assert pre is None and cnt is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slice_range_gather_world2_gloo():
+    """SURVEY.md 8e case (ii): ranks hold disjoint slice ranges; rank 0 gets the list in slice order plus
+    the global per-slice counts it needs for TailIndex."""
+    import torch.multiprocessing as mp
+    from polishpathplanning_amd.robot_path import slice_ranges
+    assert slice_ranges(11, 2) == [(0, 5), (5, 11)] and slice_ranges(1024, 8)[7] == (896, 1024)
+    assert slice_ranges(3, 8)[0] == (0, 0)       # more GPUs than slices: empty ranges are legal
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slice_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pre, cnt = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    per_slice = np.array([3 + (k % 4) for k in range(9)], np.int32)
+    assert np.array_equal(cnt, per_slice)
+    want = np.concatenate([[100.0 * k + t for t in range(per_slice[k])] for k in range(9)]).astype(np.float32)
+    assert np.array_equal(pre[:, 0], want) and pre.shape == (per_slice.sum(), 6)
+
+
 def test_gather_without_process_group():
     import torch
     from polishpathplanning_amd.robot_path import gather_robot_path
