@@ -6,6 +6,9 @@ over one synthetic workpiece cloud that is already resident in HBM, ending with 
 WayPointsList assembled on rank 0.  N = 1 runs configs[1] (1M-point wavy plate, 256 slices).
 N > 1 shards a batch of workpieces one per GPU (weak scaling, no data-path collective) and
 gathers the per-GPU robot paths to rank 0 over RCCL inside the timed region.
+--mode slices (SURVEY.md 8e case ii, meant for cfg5_10m_s1024) instead shards the SLICES of one cloud:
+GPU g plans slices [g*S/N, (g+1)*S/N), the pre-smoothing blocks are gathered to rank 0, which runs
+postion_smooth / reduceRPY / flange offset once over the whole list (strong scaling).
 
 Launch: python bench.py --gpus N --steps K --warmup W     (N > 1 via torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -48,6 +51,8 @@ def main():
     ap.add_argument("--config", default="cfg2_1m_s256")
     ap.add_argument("--batch", type=int, default=1,
                     help="workpieces per GPU per step, one engine handle (= one HIP stream) each (BASELINE config 3)")
+    ap.add_argument("--mode", choices=["workpieces", "slices"], default="workpieces",
+                    help="N > 1: one workpiece per GPU (weak scaling, default) or the slice ranges of ONE cloud (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=20)
     args = ap.parse_args()
@@ -69,6 +74,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "slices" and world > 1:
+        return bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
 
     # ---- synthetic workpiece of this rank (untimed: generation + H2D) ----
     base_seed = sorted(synth.CONFIGS).index(args.config) + 1
@@ -197,6 +205,88 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth):
+    """One cloud, slices sharded over the GPUs (no data-path collective until the gather); rank 0 finishes the list."""
+    from polishpathplanning_amd.robot_path import exchange_counts, gather_robot_path, slice_ranges
+    base_seed = sorted(synth.CONFIGS).index(args.config) + 1
+    pts, cfg = synth.make_config(args.config, seed=base_seed)      # every rank: the same cloud
+    probe = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+    probe.set_cloud(pts)
+    S = len(probe.slice_positions())
+    probe.close()
+    b, e = slice_ranges(S, world)[rank]
+    eng = None
+    nkept = max(S - 2, 0)
+    counts_local = np.zeros(nkept, np.int32)
+    w_local = 0
+    if b < e:
+        eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], slice_begin=b, slice_end=e)
+        eng.set_cloud(pts)
+        eng.gen_path()
+        w_local = eng.get_path()
+        counts_local = eng.waypoint_counts()
+    elif rank == 0:          # more GPUs than slices: rank 0 still needs a handle, it finishes the list
+        eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], slice_begin=0, slice_end=1)
+        eng.set_cloud(pts)
+    cnt = torch.from_numpy(counts_local.astype(np.int64)).to(dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    counts_all = cnt.cpu().numpy().astype(np.int32)                  # fixed workload: exchanged once
+    w_ranks = exchange_counts(w_local, dist, dev)
+    W = int(counts_all.sum())
+    send = torch.zeros((max(w_local, 1), 6), dtype=torch.float32, device=dev)
+
+    def step():
+        w = 0
+        if eng is not None and b < e:
+            eng.run_async()                                          # a2..a12 of this rank's slices, one hipGraph launch
+            w = eng.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, send.data_ptr(), send.shape[0])
+        blocks = gather_robot_path(send[:w], dist, dev, w_ranks)
+        if rank == 0:
+            pre = torch.cat(blocks, dim=0).contiguous()
+            eng.finish_path_async(pre.data_ptr(), pre.shape[0], counts_all)   # a13..a15 once, over the whole list
+            eng.sync()
+            return pre.shape[0]
+        return 0
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    out = None
+    if rank == 0:
+        assert got == W
+        n_points = int(pts.shape[0])
+        alg_bytes = 12.0 * n_points + 24.0 * W
+        out = {
+            "metric": "polishing waypoints/sec for 1M-pt cloud, 256 slices; path L2 err vs ref",
+            "value": W * args.steps / elapsed, "unit": "waypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "points_per_workpiece": n_points, "slices": S, "waypoints_per_workpiece": W,
+                       "workpieces": 1, "parallelism": "slice ranges of one cloud, one range per GPU; RCCL gather of the pre-smoothing "
+                       "blocks; postion_smooth/reduceRPY/flange once on rank 0", "tool_radius_mm": cfg["tool_radius"]},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": alg_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                         "note": "whole pipeline, every rank reads the whole cloud once (k_minmax) and indexes its own x interval"},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
     return out
 
 
