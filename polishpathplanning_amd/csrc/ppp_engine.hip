@@ -745,6 +745,7 @@ int ppp_run_async(ppp_handle h)
     }
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     h->index_built = true; h->gen_done = true; h->path_done = true;
+    h->list_final = !h->ranged;
     h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
     return PPP_OK;
 }
