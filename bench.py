@@ -103,12 +103,18 @@ def main():
     # the batch is fixed, so is every rank's waypoint count: exchanged once, checked on every gather
     counts = exchange_counts(sum(w_all), dist, dev) if world > 1 else None
 
+    offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
+
     def step():
-        for e in engines:  # every handle has its own stream: the workpieces overlap on the GPU
-            e.run_async()    # GenPath + getPath, one captured hipGraph launch per workpiece
-        w = 0
-        for e in engines:  # waits for that handle's stream, then D2D into the gather buffer
-            w += e.copy_waypoints_to_device(send.data_ptr() + 24 * w, send.shape[0] - w)
+        if len(engines) == 1:
+            engines[0].run_async()   # GenPath + getPath: one captured hipGraph launch
+            w = engines[0].copy_waypoints_to_device(send.data_ptr(), send.shape[0])
+        else:
+            # one hipGraph for the whole batch, a branch per workpiece; every branch ends by copying its list
+            # to its place in the gather buffer
+            engine.run_batch_async(engines, send.data_ptr(), offs, w_all)
+            engine.sync_batch(engines)
+            w = int(sum(w_all))
         blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev, counts)
         return w, blocks
 

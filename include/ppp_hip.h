@@ -116,6 +116,16 @@ int ppp_get_path_async(ppp_handle h);
  * this is what keeps a batch of small workpieces from being host-launch-bound).  Falls back to
  * the two plain calls while kernel timing is enabled. */
 int ppp_run_async(ppp_handle h);
+/* Batched form (SURVEY.md 8b / BASELINE config 3: many small workpieces on ONE GPU): GenPath + getPath of
+ * `count` handles of the same device as ONE hipGraph whose branches (one per handle) run side by side --
+ * one host call per batch instead of one per workpiece.  When dst_dev is not NULL every branch ends by
+ * copying its WayPointsList to dst_dev + 6 * offset_rows[i] (at most cap_rows[i] rows; a longer list is an
+ * error of that handle), so the batch lands in one caller-owned device buffer (the RCCL send buffer)
+ * without a host round trip.  The graph is cached in hs[0] and rebuilt when the handle list, a handle's
+ * plan or the destination changes.  Follow with ppp_sync_batch (or any per-handle call, which waits). */
+int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows);
+/* waits for the batch, returns the first handle's error (index in *failed when not NULL) */
+int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed);
 /* waits for the stream, then reports deferred device-side errors */
 int ppp_sync(ppp_handle h);
 int ppp_failed_slice(ppp_handle h);

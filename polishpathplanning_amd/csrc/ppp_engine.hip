@@ -99,6 +99,9 @@ struct ppp_handle_s {
     bool meta_in_flight = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
+    hipStream_t pending_stream = nullptr; /* a batch graph launched on another handle's stream carries this handle's work */
+    struct BatchGraph *batch = nullptr;   /* cached batch graph (lead handle only) */
     bool timing = false;
     std::vector<KTimer> timers;
 
@@ -107,7 +110,9 @@ struct ppp_handle_s {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
         graph_exec = nullptr; graph = nullptr;
+        ++epoch;
     }
+    void drop_batch();
     ~ppp_handle_s()
     {
         (void)hipSetDevice(device);
@@ -119,11 +124,31 @@ struct ppp_handle_s {
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
         drop_graph();
+        drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+struct BatchGraph {
+    std::vector<ppp_handle> hs;
+    std::vector<unsigned> epochs;
+    float *dst = nullptr;
+    std::vector<size_t> off, cap;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> join;
+    ~BatchGraph()
+    {
+        if (ge) (void)hipGraphExecDestroy(ge);
+        if (g) (void)hipGraphDestroy(g);
+        if (fork) (void)hipEventDestroy(fork);
+        for (auto e : join) if (e) (void)hipEventDestroy(e);
+    }
+};
+void ppp_handle_s::drop_batch() { delete batch; batch = nullptr; }
 
 namespace {
 
@@ -172,6 +197,7 @@ KTimer *timer_for(ppp_handle h, const char *name)
     do {                                                                                              \
         KTimer *_t = (h)->timing ? timer_for((h), name) : nullptr;                                    \
         if (_t) (void)hipEventRecord(_t->e0[_t->used], (h)->stream);                                  \
+        (void)hipGetLastError(); /* the check below must not pick up an older, unrelated error */     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (h)->stream, __VA_ARGS__);         \
         if (_t) { (void)hipEventRecord(_t->e1[_t->used], (h)->stream); _t->used++; }                  \
         hipError_t _le = hipGetLastError();                                                           \
@@ -412,8 +438,19 @@ int enqueue_dynamic(ppp_handle h)
     return PPP_OK;
 }
 
+/* work enqueued for this handle by a batch graph runs on the lead handle's stream */
+int settle(ppp_handle h)
+{
+    if (h->pending_stream) {
+        HIPCHK(h, hipStreamSynchronize(h->pending_stream));
+        h->pending_stream = nullptr;
+    }
+    return PPP_OK;
+}
+
 int fetch_meta(ppp_handle h)
 {
+    { int rc = settle(h); if (rc) return rc; }
     if (h->meta_in_flight) { /* GenPath / getPath already enqueued the copy behind their last kernel */
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->hmeta = *h->hmeta_pinned;
@@ -505,6 +542,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
     HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
     if (n) {
+        (void)hipGetLastError();
         hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, raw_dev, stride_bytes, (int)n,
                            h->P.change_range, h->X.p, h->Y.p, h->Z.p);
         HIPCHK(h, hipGetLastError());
@@ -513,6 +551,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     {
         int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
         HIPCHK(h, h->mm_part.ensure(g));
+        (void)hipGetLastError();
         hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
                            (int *)nullptr);
         HIPCHK(h, hipGetLastError());
@@ -606,7 +645,11 @@ int ppp_set_params(ppp_handle h, const ppp_params *p)
     bool rescale = h->have_cloud && (p->change_range != h->P.change_range);
     h->P = *p;
     if (rescale) return fail(h, PPP_ERR_ARG, "ChangeRange changed after the cloud was set: set the cloud again");
-    if (h->have_cloud) { HIPCHK(h, hipSetDevice(h->device)); return make_plan(h); }
+    if (h->have_cloud) {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rcs = settle(h);
+        return rcs ? rcs : make_plan(h);
+    }
     return PPP_OK;
 }
 
@@ -614,6 +657,7 @@ int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_b
 {
     if (!h || (!xyz_host && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     size_t bytes = n * stride_bytes;
     HIPCHK(h, h->scratch.ensure(bytes));
     if (bytes) HIPCHK(h, hipMemcpyAsync(h->scratch.p, xyz_host, bytes, hipMemcpyHostToDevice, h->stream));
@@ -624,6 +668,7 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
 {
     if (!h || (!xyz_dev && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
 }
 
@@ -638,6 +683,7 @@ int ppp_gen_path_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
@@ -682,6 +728,7 @@ int ppp_get_path_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
     DevParams D = dev_params(h);
     LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
@@ -706,6 +753,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if ((W && !pre6_dev) || (nkept && !counts)) return fail(h, PPP_ERR_ARG, "bad arguments");
@@ -725,6 +773,7 @@ int ppp_run_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if (h->timing) {
@@ -747,6 +796,114 @@ int ppp_run_async(ppp_handle h)
     h->index_built = true; h->gen_done = true; h->path_done = true;
     h->list_final = !h->ranged;
     h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
+    return PPP_OK;
+}
+
+int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows)
+{
+    if (!hs || !count || !hs[0]) return PPP_ERR_ARG;
+    ppp_handle lead = hs[0];
+    if (dst_dev && (!offset_rows || !cap_rows)) return fail(lead, PPP_ERR_ARG, "offset_rows / cap_rows are needed with a destination");
+    HIPCHK(lead, hipSetDevice(lead->device));
+    bool plain = false;
+    for (size_t i = 0; i < count; ++i) {
+        ppp_handle h = hs[i];
+        if (!h) return fail(lead, PPP_ERR_ARG, "null handle in the batch");
+        if (h->device != lead->device) return fail(lead, PPP_ERR_ARG, "a batch lives on one device");
+        for (size_t j = 0; j < i; ++j) if (hs[j] == h) return fail(lead, PPP_ERR_ARG, "a handle appears twice in the batch");
+        if (!h->have_cloud) return fail(lead, PPP_ERR_ARG, "a handle of the batch has no cloud");
+        int rc = settle(h);
+        if (rc) return rc;
+        if (!h->planned) { rc = make_plan(h); if (rc) { lead->err = h->err; return rc; } }
+        plain = plain || h->timing;
+    }
+    if (plain) { /* kernel timing brackets every launch with events: plain per-handle calls */
+        for (size_t i = 0; i < count; ++i) {
+            int rc = ppp_gen_path_async(hs[i]);
+            if (rc == PPP_OK) rc = ppp_get_path_async(hs[i]);
+            if (rc == PPP_OK && dst_dev && !hs[i]->ranged)
+                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((6 * (size_t)hs[i]->W_cap + 255) / 256)), dim3(256), 0, hs[i]->stream, hs[i]->meta.p,
+                                   hs[i]->wp_out.p, dst_dev + 6 * offset_rows[i], (int)std::min<size_t>(cap_rows[i], 0x7fffffff));
+            if (rc) { lead->err = hs[i]->err; return rc; }
+        }
+        return PPP_OK;
+    }
+    BatchGraph *bg = lead->batch;
+    bool fresh = bg && bg->hs.size() == count && bg->dst == dst_dev;
+    for (size_t i = 0; fresh && i < count; ++i)
+        fresh = bg->hs[i] == hs[i] && bg->epochs[i] == hs[i]->epoch && (!dst_dev || (bg->off[i] == offset_rows[i] && bg->cap[i] == cap_rows[i]));
+    if (!fresh) {
+        lead->drop_batch();
+        bg = new BatchGraph();
+        lead->batch = bg;
+        bg->hs.assign(hs, hs + count);
+        bg->dst = dst_dev;
+        if (dst_dev) { bg->off.assign(offset_rows, offset_rows + count); bg->cap.assign(cap_rows, cap_rows + count); }
+        HIPCHK(lead, hipEventCreateWithFlags(&bg->fork, hipEventDisableTiming));
+        bg->join.resize(count, nullptr);
+        for (size_t i = 1; i < count; ++i) HIPCHK(lead, hipEventCreateWithFlags(&bg->join[i], hipEventDisableTiming));
+        /* one capture: the lead stream forks into every other handle's stream and joins them again */
+        HIPCHK(lead, hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
+        int rc = PPP_OK;
+        const char *where = "";
+        hipError_t e = hipEventRecord(bg->fork, lead->stream);
+        if (e != hipSuccess) where = "fork record";
+        for (size_t i = 1; i < count && e == hipSuccess; ++i) {
+            e = hipStreamWaitEvent(hs[i]->stream, bg->fork, 0);
+            if (e != hipSuccess) where = "fork wait";
+        }
+        for (size_t i = 0; i < count && e == hipSuccess && rc == PPP_OK; ++i) {
+            ppp_handle h = hs[i];
+            rc = ppp_gen_path_async(h);
+            if (rc == PPP_OK) rc = ppp_get_path_async(h);
+            if (rc == PPP_OK && dst_dev && !h->ranged) {
+                (void)hipGetLastError();
+                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((6 * (size_t)h->W_cap + 255) / 256)), dim3(256), 0, h->stream, h->meta.p,
+                                   h->wp_out.p, dst_dev + 6 * offset_rows[i], (int)std::min<size_t>(cap_rows[i], 0x7fffffff));
+                e = hipGetLastError();
+                if (e != hipSuccess) where = "copy-out launch";
+                /* the copy may flag an overflow: refresh the host copy of the meta block behind it */
+                if (e == hipSuccess) rc = enqueue_meta_copy(h);
+            }
+            if (rc != PPP_OK) lead->err = "batch member " + std::to_string(i) + ": " + h->err;
+            if (i && e == hipSuccess && rc == PPP_OK) {
+                e = hipEventRecord(bg->join[i], h->stream);
+                if (e != hipSuccess) where = "join record";
+                if (e == hipSuccess) { e = hipStreamWaitEvent(lead->stream, bg->join[i], 0); if (e != hipSuccess) where = "join wait"; }
+            }
+        }
+        hipGraph_t g = nullptr;
+        hipError_t e2 = hipStreamEndCapture(lead->stream, &g);
+        if (rc != PPP_OK || e != hipSuccess || e2 != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            lead->drop_batch();
+            if (rc != PPP_OK) return rc;
+            return fail(lead, PPP_ERR_HIP, std::string("batch capture (") + where + "): " + hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        bg->g = g;
+        e = hipGraphInstantiate(&bg->ge, bg->g, nullptr, nullptr, 0);
+        if (e != hipSuccess) { lead->drop_batch(); return fail(lead, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        bg->epochs.resize(count);
+        for (size_t i = 0; i < count; ++i) bg->epochs[i] = hs[i]->epoch;
+    }
+    HIPCHK(lead, hipGraphLaunch(bg->ge, lead->stream));
+    for (size_t i = 0; i < count; ++i) {
+        ppp_handle h = hs[i];
+        h->index_built = true; h->gen_done = true; h->path_done = true;
+        h->list_final = !h->ranged;
+        h->meta_in_flight = true;
+        h->pending_stream = (i == 0) ? nullptr : lead->stream;
+    }
+    return PPP_OK;
+}
+
+int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed)
+{
+    if (!hs || !count) return PPP_ERR_ARG;
+    for (size_t i = 0; i < count; ++i) {
+        int rc = ppp_sync(hs[i]);
+        if (rc) { if (failed) *failed = i; return rc; }
+    }
     return PPP_OK;
 }
 

@@ -1084,6 +1084,16 @@ __global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const f
     }
 }
 
+/* ppp_run_batch_async: the finished list of one branch into the batch's device buffer */
+__global__ void __launch_bounds__(256) k_copy_out(DevMeta *m, const float *__restrict__ src, float *dst, int cap_rows)
+{
+    const int W = m->W;
+    if (m->err || W == 0) return;
+    if (W > cap_rows) { if (blockIdx.x == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1); return; }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * W) dst[i] = src[i];
+}
+
 /* ppp_finish_path_async: the list was sampled elsewhere (slice-range handles); rebuild the per-run state
    getPath's second half needs from the per-slice counts: offsets, TailIndex, the B.6 flag, W. */
 __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,

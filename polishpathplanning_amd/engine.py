@@ -77,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
         L.ppp_copy_waypoints_to_device.argtypes = [vp, vp, sz, szp]
         L.ppp_get_tail_index.argtypes = [vp, ip, sz, szp]
         L.ppp_get_waypoint_counts.argtypes = [vp, ip, sz, szp]
+        L.ppp_run_batch_async.argtypes = [C.POINTER(vp), sz, vp, szp, szp]
+        L.ppp_sync_batch.argtypes = [C.POINTER(vp), sz, szp]
         L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_finish_path_async.argtypes = [vp, vp, sz, ip, sz]
         L.ppp_minmax.argtypes = [vp, fp, fp]
@@ -217,6 +219,32 @@ def _d(a):
 
 def _i(a):
     return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def run_batch_async(engines, dst_ptr=None, offsets=None, caps=None):
+    """GenPath + getPath of several handles of one GPU as ONE hipGraph with a branch per handle (BASELINE config 3).
+    With dst_ptr every list is also copied to dst_ptr + 24 * offsets[i] bytes (at most caps[i] rows)."""
+    L = lib()
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e.h for e in engines])
+    if dst_ptr is None:
+        rc = L.ppp_run_batch_async(hs, n, None, None, None)
+    else:
+        off = (C.c_size_t * n)(*[int(x) for x in offsets])
+        cap = (C.c_size_t * n)(*[int(x) for x in caps])
+        rc = L.ppp_run_batch_async(hs, n, C.c_void_p(dst_ptr), off, cap)
+    if rc:
+        raise PPPError(rc, L.ppp_last_error(engines[0].h).decode())
+
+
+def sync_batch(engines):
+    L = lib()
+    n = len(engines)
+    hs = (C.c_void_p * n)(*[e.h for e in engines])
+    bad = C.c_size_t(0)
+    rc = L.ppp_sync_batch(hs, n, C.byref(bad))
+    if rc:
+        raise PPPError(rc, "handle %d of the batch: %s" % (bad.value, L.ppp_last_error(engines[bad.value].h).decode()))
 
 
 class Engine:

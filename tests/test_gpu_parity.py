@@ -570,3 +570,36 @@ def test_slice_range_margin_too_small_is_reported(engine_mod):
         engine_mod.Engine(0, tool_radius=6.0, slice_begin=5, slice_end=9, range_margin=1.0)  # < 2 x normal radius
     with pytest.raises(engine_mod.PPPError):
         engine_mod.Engine(0, tool_radius=6.0, slice_begin=5, slice_end=9, dynamic_adjustment=1)
+
+
+def test_run_batch_graph_matches_single_handles(engine_mod):
+    """ppp_run_batch_async: several workpieces as one hipGraph with a branch each, lists landing in one device buffer."""
+    kinds = [("small_40k", 1), ("tiny_5k", 2), ("small_40k", 3), ("tiny_5k", 4), ("small_40k", 5)]
+    clouds = [synth.make_config(n, seed=s)[0] for n, s in kinds]
+    want = []
+    for pts in clouds:
+        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path(); e.get_path()
+        want.append(e.waypoints())
+    engines = []
+    for pts in clouds:
+        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); engines.append(e)
+    ws = [len(w) for w in want]
+    offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
+    buf = _DeviceBuffer(sum(ws) * 24)
+    for _ in range(3):                                   # capture, then two replays
+        engine_mod.run_batch_async(engines, buf.ptr, offs, ws)
+        engine_mod.sync_batch(engines)
+    got = buf.to_host(sum(ws) * 6)
+    assert got.tobytes() == np.concatenate(want).tobytes()
+    for e, w in zip(engines, want):
+        assert e.waypoints().tobytes() == w.tobytes()
+    # a destination slot that is too small is that handle's error, not silent truncation
+    caps = list(ws); caps[2] -= 1
+    engine_mod.run_batch_async(engines, buf.ptr, offs, caps)
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.sync_batch(engines)
+    # without a destination, and after a parameter change of one member (its plan epoch changes)
+    engines[1].set_params(path_resolution=5.0)
+    engine_mod.run_batch_async(engines)
+    engine_mod.sync_batch(engines)
+    assert engines[1].num_waypoints() > ws[1] and engines[0].waypoints().tobytes() == want[0].tobytes()
