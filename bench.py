@@ -186,6 +186,17 @@ def main():
                    "sample": "1 full pass of %s (GenPath + getPath), single thread, reference-complexity "
                              "mode: per-slice O(N) PassThrough scans, whole-cloud normal estimation twice" % args.config,
                    "seconds": t_cpu, "host_cores_available": os.cpu_count()}
+            # context only: the same pass with OpenMP over the slices and over the points of the normal
+            # estimation; the kd-tree builds stay serial, as FLANN's are in the reference
+            nt = os.cpu_count() or 1
+            if nt > 1:
+                o2 = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1, threads=nt)
+                t2 = time.perf_counter()
+                o2.gen_path()
+                wo2 = o2.get_path()
+                t_all = time.perf_counter() - t2
+                cpu["all_cores"] = {"value": wo2 / t_all, "cores": nt, "seconds": t_all,
+                                    "note": "not the reference's behaviour (its hot path is single-threaded): context only"}
             gw = eng.waypoints()
             ow = o.waypoints()
             if gw.shape == ow.shape and len(gw):

@@ -39,6 +39,7 @@ class Params(C.Structure):
         ("adjust_threshold", C.c_double),
         ("toolthickness", C.c_double),
         ("curvature_k", C.c_int),
+        ("threads", C.c_int),
     ]
 
 

@@ -583,7 +583,9 @@ struct ppo_handle {
         normals.assign(4 * n, 0.f);
         normal_done.assign(n, 1);
         rebuild_tree();
-        for (size_t i = 0; i < n; ++i) point_normal((int)i, &normals[4 * i]);
+        const int nt = P.threads > 1 ? P.threads : 1; /* all-cores context figure of bench.py; 1 = the reference */
+#pragma omp parallel for schedule(static, 4096) num_threads(nt) if (nt > 1)
+        for (long long i = 0; i < (long long)n; ++i) point_normal((int)i, &normals[4 * (size_t)i]);
     }
     const float *normal_lazy(int idx)
     {
@@ -1007,16 +1009,24 @@ struct ppo_handle {
         if (!P.reference_complexity) bucket_slices(px, slice_idx);
         else slice_idx.resize(S);
         path_set.resize(S);
+        int first_bad = S; /* the reference stops at the first slice that aborts */
+        const int nt = P.threads > 1 ? P.threads : 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt) if (nt > 1)
         for (int s = 0; s < S; ++s) {
             /* OnePath / path_track: rangedX_index(int(plane_point[0])) */
             if (P.reference_complexity) slice_idx[s] = ranged_x_index((int)px[s]);
             std::map<double, std::array<double, 2>> Node;
             int m = insert_point(slice_idx[s], px[s], Node);
-            if (m < 3) return -(1 + s); /* gsl_spline_alloc / FLANN would abort */
+            if (m < 3) { /* gsl_spline_alloc / FLANN would abort */
+#pragma omp critical
+                first_bad = std::min(first_bad, s);
+                continue;
+            }
             Spline &sp = path_set[s];
             for (auto &kv : Node) { sp.y.push_back(kv.first); sp.x.push_back(kv.second[0]); sp.z.push_back(kv.second[1]); }
             sp.fit();
         }
+        if (first_bad < S) return -(1 + first_bad);
         if (P.dynamic_adjustment) {
             int rc = adjust_all();
             if (rc) return rc;
@@ -1092,6 +1102,7 @@ void ppo_default_params(ppo_params *p)
     p->normal_radius = 2.5f;
     p->reference_complexity = 0;
     p->smooth_max_sweeps = 32;
+    p->threads = 1;
     p->dynamic_adjustment = 0; /* config.txt says true; the benchmarks of this round run without */
     p->depth = 0.01; p->adjust_threshold = 1; p->toolthickness = 10; p->curvature_k = 50;
 }

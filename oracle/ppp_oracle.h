@@ -56,6 +56,8 @@ typedef struct ppo_params {
     double adjust_threshold;     /* Adjust_Threshold  (config.txt:3)                  */
     double toolthickness;        /* toolthickness     (config.txt:4)                  */
     int    curvature_k;          /* 50 (path_dynamic_alg.cpp:87); 10 in Path_Generation.cpp:372 */
+    int    threads;              /* 1 = as the reference (single-threaded hot path); > 1: OpenMP over the slices and over
+                                    the points of the normal estimation, for bench.py's all-cores context figure only */
 } ppo_params;
 
 typedef struct ppo_handle ppo_handle;
