@@ -198,10 +198,11 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
 
 /* ---- host-side file formats of the reference (no device work) ---- */
 /* pcl::io::loadPCDFile<PointXYZRGB> (path_slicing_alg.cpp:10, Path_Generation.cpp:8): PCD v0.7,
- * DATA ascii | binary, fields matched by name, x y z as F4 or F8.  *xyz receives n x 3 packed
- * floats allocated by the library (release with ppp_free); viewpoint = the 7 VIEWPOINT numbers
- * (tx ty tz qw qx qy qz).  binary_compressed -> PPP_ERR_UNSUPPORTED. */
+ * DATA ascii | binary | binary_compressed (LZF, field-major), fields matched by name, x y z as F4 or F8.
+ * *xyz receives n x 3 packed floats allocated by the library (release with ppp_free); viewpoint = the 7
+ * VIEWPOINT numbers (tx ty tz qw qx qy qz). */
 int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7]);
+/* binary: 0 = ascii (pcl::io::savePCDFileASCII, path_slicing_alg.cpp:138), 1 = binary, 2 = binary_compressed */
 int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary);
 void ppp_free(void *p);
 /* SectPath::read_config / path_generater::read_config (path_slicing_alg.cpp:32-67,

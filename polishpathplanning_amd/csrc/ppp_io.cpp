@@ -38,6 +38,70 @@ double read_scalar(const unsigned char *p, int size, char type)
     }
     return NAN;
 }
+
+/* LZF (Marc Lehmann's liblzf, the codec of PCD "binary_compressed"): control byte < 32 = literal run of
+   ctrl + 1 bytes; otherwise a back reference of length (ctrl >> 5) + 2 (7 = one more length byte follows)
+   at distance ((ctrl & 31) << 8 | next byte) + 1.  Returns the decoded size, 0 on malformed input. */
+size_t lzf_decompress(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len)
+{
+    const unsigned char *ip = in, *in_end = in + in_len;
+    unsigned char *op = out, *out_end = out + out_len;
+    while (ip < in_end) {
+        unsigned ctrl = *ip++;
+        if (ctrl < 32) {
+            ctrl++;
+            if (op + ctrl > out_end || ip + ctrl > in_end) return 0;
+            memcpy(op, ip, ctrl);
+            op += ctrl; ip += ctrl;
+        } else {
+            size_t len = ctrl >> 5;
+            if (ip >= in_end) return 0;
+            if (len == 7) { len += *ip++; if (ip >= in_end) return 0; }
+            const size_t dist = ((size_t)(ctrl & 0x1f) << 8) + *ip++ + 1;
+            len += 2;
+            if (dist > (size_t)(op - out) || op + len > out_end) return 0;
+            const unsigned char *ref = op - dist;
+            for (size_t k = 0; k < len; ++k) op[k] = ref[k]; /* may overlap: byte by byte */
+            op += len;
+        }
+    }
+    return (size_t)(op - out);
+}
+
+/* greedy LZF encoder (3-byte hash, distances <= 8192, matches <= 264); any liblzf decoder reads it */
+std::vector<unsigned char> lzf_compress(const unsigned char *in, size_t n)
+{
+    std::vector<unsigned char> out;
+    out.reserve(n + n / 16 + 64);
+    std::vector<long long> table(1 << 14, -1);
+    size_t lit_start = 0, i = 0;
+    auto flush_literals = [&](size_t end) {
+        while (lit_start < end) {
+            size_t run = std::min<size_t>(32, end - lit_start);
+            out.push_back((unsigned char)(run - 1));
+            out.insert(out.end(), in + lit_start, in + lit_start + run);
+            lit_start += run;
+        }
+    };
+    while (i + 2 < n) {
+        const unsigned h = ((in[i] << 16 | in[i + 1] << 8 | in[i + 2]) * 2654435761u) >> 18;
+        const long long cand = table[h];
+        table[h] = (long long)i;
+        if (cand >= 0 && i - (size_t)cand <= 8192 && in[cand] == in[i] && in[cand + 1] == in[i + 1] && in[cand + 2] == in[i + 2]) {
+            size_t len = 3;
+            while (i + len < n && len < 264 && in[cand + len] == in[i + len]) ++len;
+            flush_literals(i);
+            const size_t dist = i - (size_t)cand - 1, l = len - 2;
+            if (l < 7) out.push_back((unsigned char)((l << 5) | (dist >> 8)));
+            else { out.push_back((unsigned char)((7u << 5) | (dist >> 8))); out.push_back((unsigned char)(l - 7)); }
+            out.push_back((unsigned char)(dist & 0xff));
+            i += len;
+            lit_start = i;
+        } else ++i;
+    }
+    flush_literals(n);
+    return out;
+}
 } // namespace
 
 extern "C" {
@@ -115,9 +179,29 @@ int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
             out[3 * i + 1] = (float)read_scalar(p + fields[iy].offset, fields[iy].size, fields[iy].type);
             out[3 * i + 2] = (float)read_scalar(p + fields[iz].offset, fields[iz].size, fields[iz].type);
         }
+    } else if (data_kind == "binary_compressed") {
+        /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream; the decoded block is
+           field-major (all x, then all y, ...) */
+        unsigned char hdr[8];
+        f.read((char *)hdr, 8);
+        if (f.gcount() != 8) { free(out); return PPP_ERR_IO; }
+        uint32_t csize, usize;
+        memcpy(&csize, hdr, 4); memcpy(&usize, hdr + 4, 4);
+        if ((size_t)usize != (size_t)off * points) { free(out); return PPP_ERR_IO; }
+        std::vector<unsigned char> comp(csize), raw(usize);
+        f.read((char *)comp.data(), (std::streamsize)csize);
+        if ((size_t)f.gcount() != (size_t)csize) { free(out); return PPP_ERR_IO; }
+        if (usize && lzf_decompress(comp.data(), csize, raw.data(), usize) != usize) { free(out); return PPP_ERR_IO; }
+        const int idx3[3] = {ix, iy, iz};
+        for (int d = 0; d < 3; ++d) {
+            const Field &fd = fields[idx3[d]];
+            const size_t per = (size_t)fd.size * std::max(1, fd.count);
+            const unsigned char *base = raw.data() + (size_t)fd.offset * points; /* blocks follow the record order */
+            for (size_t i = 0; i < points; ++i) out[3 * i + d] = (float)read_scalar(base + i * per, fd.size, fd.type);
+        }
     } else {
         free(out);
-        return PPP_ERR_UNSUPPORTED; /* binary_compressed (LZF): SURVEY.md 8f rank 3 */
+        return PPP_ERR_UNSUPPORTED;
     }
     *xyz = out; *n = points;
     if (viewpoint) memcpy(viewpoint, vp, sizeof(vp));
@@ -133,7 +217,18 @@ int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_flo
     const float *vp = viewpoint ? viewpoint : dvp;
     fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n");
     fprintf(f, "WIDTH %zu\nHEIGHT 1\nVIEWPOINT %g %g %g %g %g %g %g\nPOINTS %zu\nDATA %s\n", n, vp[0], vp[1], vp[2], vp[3], vp[4], vp[5],
-            vp[6], n, binary ? "binary" : "ascii");
+            vp[6], n, binary == 2 ? "binary_compressed" : (binary ? "binary" : "ascii"));
+    if (binary == 2) { /* pcl::PCDWriter::writeBinaryCompressed layout */
+        std::vector<float> soa(3 * n);
+        for (size_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) soa[(size_t)d * n + i] = xyz[i * stride_floats + d];
+        std::vector<unsigned char> comp = lzf_compress((const unsigned char *)soa.data(), 12 * n);
+        if (comp.size() > 0xffffffffull || 12 * n > 0xffffffffull) { fclose(f); return PPP_ERR_CAPACITY; }
+        const uint32_t csize = (uint32_t)comp.size(), usize = (uint32_t)(12 * n);
+        fwrite(&csize, 4, 1, f); fwrite(&usize, 4, 1, f);
+        if (csize) fwrite(comp.data(), 1, csize, f);
+        fclose(f);
+        return PPP_OK;
+    }
     for (size_t i = 0; i < n; ++i) {
         const float *p = xyz + i * stride_floats;
         if (binary) fwrite(p, 4, 3, f);

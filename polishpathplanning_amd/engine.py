@@ -194,7 +194,8 @@ def load_pcd(path):
 def save_pcd(path, xyz, viewpoint=None, binary=True):
     xyz = np.ascontiguousarray(xyz, np.float32)
     vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
-    rc = lib().ppp_save_pcd(path.encode(), _f(xyz), xyz.shape[0], xyz.shape[1], vp, 1 if binary else 0)
+    mode = 2 if binary == "compressed" else (1 if binary else 0)
+    rc = lib().ppp_save_pcd(path.encode(), _f(xyz), xyz.shape[0], xyz.shape[1], vp, mode)
     if rc:
         raise PPPError(rc, "cannot write PCD %s" % path)
 

@@ -157,6 +157,48 @@ def test_pcd_roundtrip(engine_mod, tmp_path, binary):
     assert np.isnan(back[3]).all() and np.allclose(vp, [0.1, 0.2, 0.3, 1, 0, 0, 0])
 
 
+def _lzf_literal_only(raw):
+    """A second, independent LZF encoder (literal runs only) for the decoder test."""
+    out = bytearray()
+    for i in range(0, len(raw), 32):
+        run = raw[i:i + 32]
+        out.append(len(run) - 1)
+        out += run
+    return bytes(out)
+
+
+def test_pcd_binary_compressed(engine_mod, tmp_path):
+    """PCD DATA binary_compressed (what pcl::io::savePCDFileBinaryCompressed writes): LZF stream of the field-major block."""
+    import struct
+    rng = np.random.default_rng(7)
+    pts = rng.normal(size=(5000, 3)).astype(np.float32)
+    pts[::7] = pts[0]                                   # repeats: the encoder emits back references
+    pts[:, 2] = 0.25                                    # a flat plate: the z block is one long run
+    p = str(tmp_path / "c.pcd")
+    engine_mod.save_pcd(p, pts, viewpoint=[1, 2, 3, 1, 0, 0, 0], binary="compressed")
+    raw = open(p, "rb").read()
+    assert b"DATA binary_compressed" in raw and len(raw) < 60000 * 0.75   # it did compress
+    got, vp = engine_mod.load_pcd(p)
+    assert np.array_equal(got, pts) and list(vp[:3]) == [1, 2, 3]
+    # a stream from an independent encoder, with an rgb field between the coordinates (field-major layout) and double z
+    n = 257
+    x = rng.normal(size=n).astype(np.float32); y = rng.normal(size=n).astype(np.float32); z = rng.normal(size=n)
+    rgb = rng.integers(0, 2 ** 24, size=n, dtype=np.uint32)
+    block = x.tobytes() + rgb.tobytes() + y.tobytes() + z.astype(np.float64).tobytes()
+    comp = _lzf_literal_only(block)
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS x rgb y z\nSIZE 4 4 4 8\nTYPE F U F F\nCOUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n" % (n, n)).encode()
+    q = str(tmp_path / "d.pcd")
+    open(q, "wb").write(hdr + struct.pack("<II", len(comp), len(block)) + comp)
+    got, _ = engine_mod.load_pcd(q)
+    assert np.array_equal(got, np.stack([x, y, z.astype(np.float32)], axis=1))
+    # a back reference that points before the start of the output is rejected, not followed
+    bad = str(tmp_path / "bad.pcd")
+    open(bad, "wb").write(hdr + struct.pack("<II", 4, len(block)) + b"\xe0\x05\x00\x00")   # reference before the start
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.load_pcd(bad)
+
+
 def test_pcd_with_extra_fields_and_double_xyz(engine_mod, tmp_path):
     # FIELDS in any order / F8 coordinates / rgb packed as U4, as PCL writes them
     n = 5
@@ -176,6 +218,10 @@ def test_pcd_errors(engine_mod, tmp_path):
     assert ei.value.code == engine_mod.ERR_IO
     p = tmp_path / "z.pcd"
     p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n")
+    with pytest.raises(engine_mod.PPPError) as ei:       # truncated: no size words, no stream
+        engine_mod.load_pcd(str(p))
+    assert ei.value.code == engine_mod.ERR_IO
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA zstd\n")
     with pytest.raises(engine_mod.PPPError) as ei:
         engine_mod.load_pcd(str(p))
     assert ei.value.code == engine_mod.ERR_UNSUPPORTED
