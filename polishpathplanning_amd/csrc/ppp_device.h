@@ -8,6 +8,7 @@
  * without fast-math, so what is written here is what executes.
  */
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -138,6 +139,17 @@ struct StampCtx {
     __device__ inline void mark(int) {}
 };
 #endif
+
+/* a, a + step, a + 2 step, ... accumulated in double (the reference's `dy += PathResolution` loops): when a and step
+   are multiples of 2^-39 and the sums stay below 2^13 every partial sum has at most 52 significant bits, so no
+   addition rounds and a + k * step computed directly has the same bits as k accumulated additions. */
+__host__ __device__ inline bool sums_exact(double a, double step, double kmax)
+{
+    const double S = 549755813888.0; /* 2^39 */
+    if (!(fabs(a) < 8192.0) || !(fabs(step) < 8192.0)) return false;
+    const double as = a * S, ss = step * S;
+    return floor(as) == as && floor(ss) == ss && fabs(a) + kmax * fabs(step) < 8192.0;
+}
 
 /* ---- block-wide helpers (blockDim.x multiple of 64, <= 1024) ---- */
 template <typename T>

@@ -176,6 +176,12 @@ DevParams dev_params(const ppp_handle h)
     D.smooth = h->P.smooth; D.smooth_max_sweeps = h->P.smooth_max_sweeps;
     D.slice_begin = h->P.slice_begin; D.slice_end = h->P.slice_end; D.ranged = h->ranged ? 1 : 0;
     D.incl_lo = h->incl_lo; D.incl_hi = h->incl_hi;
+    {   /* mean spacing of a sheet-like cloud from its bounding rectangle; only a search hint, never a cut-off */
+        const double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
+        const double spacing = (area > 0 && h->h_nvalid > 0) ? std::sqrt(area / h->h_nvalid) : 1.0;
+        const double r = std::max(1.0, 3.0 * spacing);
+        D.nn_hint2 = (float)(r * r);
+    }
     return D;
 }
 
@@ -690,11 +696,11 @@ int ppp_gen_path_async(ppp_handle h)
     int rc = enqueue_index(h);
     if (rc) return rc;
     if (h->P.pairing == PPP_PAIR_KD) {
-        LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, 256, slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
+        LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, SLICE_KD_T, slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
                h->px.p, h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
         if (h->big_path)
-            LAUNCH(h, "k_slice_kd_arena", k_slice_kd<true>, h->S_cap, 256, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+            LAUNCH(h, "k_slice_kd_arena", k_slice_kd<true>, h->S_cap, SLICE_KD_T, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                    h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                    h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
     } else {
@@ -734,7 +740,7 @@ int ppp_get_path_async(ppp_handle h)
     LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
            h->wp_off.p, h->tail.p, h->W_cap, h->big_path ? 1 : 0);
     int nk = std::max(1, h->S_cap);
-    LAUNCH(h, "k_pose", k_pose, nk, 256, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+    LAUNCH(h, "k_pose", k_pose, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
            h->capb,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);

@@ -42,6 +42,7 @@ struct DevParams {
     int change_range, pairing, walk, drop_ends, smooth, smooth_max_sweeps;
     int slice_begin, slice_end, ranged;
     float incl_lo, incl_hi;
+    float nn_hint2; /* (a few mean point spacings)^2: first search bound of the waypoints' 1-NN queries */
 };
 
 enum { DERR_NONE = 0, DERR_SLICE = 1, DERR_CAPACITY = 2, DERR_DOMAIN = 3, DERR_QUERY = 4, DERR_MARGIN = 5 };
@@ -794,7 +795,10 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
 /* ARENA = false: the band lives in LDS (capb points); a slice whose band does not fit is appended
    to a work list.  ARENA = true: second pass over that list, same code on a global arena. */
 template <bool ARENA>
-__global__ void __launch_bounds__(256) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+#ifndef SLICE_KD_T
+#define SLICE_KD_T 1024
+#endif
+__global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                   DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                   const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
                                                   float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
@@ -1311,6 +1315,159 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
     out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; out[3] = curv;
 }
 
+/* ---- the same two queries with G lanes per query (G = 1, 2, 4 or 8 consecutive lanes of a wave) ----
+   The cost of a query is its chain of dependent binary-search reads, one chain per slab it touches; a group walks G
+   slabs side by side: round r gives lane g the slab at offset 0, +1, -1, +2, -2, ... (position r*G + g of that list)
+   from the query's own slab.  A side is closed by the first slab that lies outside the grid or, being non-empty, is
+   farther in x than the current bound -- every slab beyond it is farther still.  All lanes of a group call these
+   together (inactive queries included: the shuffles are executed by whole groups) and all receive the result. */
+__device__ inline int group_signed_offset(int o) { return o == 0 ? 0 : ((o & 1) ? (o + 1) / 2 : -(o / 2)); }
+
+template <int G>
+__device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, float qx, float qy, float qz, float4 *found, int g, float bound2)
+{
+    const int B = V.m->B;
+    /* bound2: only points closer than this are looked for (INFINITY = all).  A lane that starts in a far slab has no
+       candidate of its own yet, and without a bound it would scan that slab's whole y-window; with the caller's guess
+       (a few point spacings) far slabs are closed by their x gap at once.  Nothing found within the guess -> the
+       caller repeats the query unbounded, so the result is exact either way. */
+    float best = bound2;
+    int bidx = 0x7fffffff;
+    float4 bp = make_float4(NAN, NAN, NAN, 0.f);
+    const int b = slab_of(V.m, qx);
+    int right_closed = active ? 0 : 1, left_closed = right_closed;
+    for (int round = 0; !(right_closed && left_closed); ++round) {
+        const int so = group_signed_offset(round * G + g);
+        const int bb = b + so;
+        int rc = 0, lc = 0;
+        const bool side_closed = (so > 0 && right_closed) || (so < 0 && left_closed);
+        if (!side_closed) {
+            if (bb < 0) lc = 1;
+            else if (bb >= B) rc = 1;
+            else {
+                const int s0 = V.slab_start[bb], s1 = V.slab_start[bb + 1];
+                if (s0 < s1) {
+                    const float dx = so > 0 ? V.slab_xmin[bb] - qx : (so < 0 ? qx - V.slab_xmax[bb] : 0.f);
+                    if (dx > 0.f && dx * dx > best) { if (so > 0) rc = 1; else lc = 1; }
+                    else {
+                        const int p = lower_bound_y(V, s0, s1, qy);
+                        for (int i = p; i < s1; ++i) {
+                            const float4 c = V.at(i);
+                            const float dy = qy - c.y;
+                            if (dy * dy > best) break;
+                            const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
+                            const int id = idx_of(c);
+                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                        }
+                        for (int i = p - 1; i >= s0; --i) {
+                            const float4 c = V.at(i);
+                            const float dy = qy - c.y;
+                            if (dy * dy > best) break;
+                            const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
+                            const int id = idx_of(c);
+                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                        }
+                    }
+                }
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) { /* group minimum on (distance, cloud index); closings are OR-ed */
+            const float od = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bidx, o, 64);
+            const float ox = __shfl_xor(bp.x, o, 64), oy = __shfl_xor(bp.y, o, 64), oz = __shfl_xor(bp.z, o, 64), ow = __shfl_xor(bp.w, o, 64);
+            if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bp = make_float4(ox, oy, oz, ow); }
+            rc |= __shfl_xor(rc, o, 64);
+            lc |= __shfl_xor(lc, o, 64);
+        }
+        right_closed |= rc; left_closed |= lc;
+    }
+    *found = bp;
+    return bidx == 0x7fffffff ? -1 : bidx;
+}
+
+/* normal_at_point with G lanes: every lane sums the neighbours of its slabs, the partial sums are added pairwise across
+   the group (a fixed tree, so the result depends on the slab contents only -- identical for a slice-range handle and a
+   whole-cloud handle) */
+template <int G>
+__device__ inline void normal_at_point_group(const SlabView &V, bool active, const float4 p, float radius, const float vp[3], float out[4], int g)
+{
+    const int B = V.m->B;
+    const float r2 = radius * radius;
+    float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int count = 0;
+    const int b = slab_of(V.m, p.x);
+    int right_closed = active ? 0 : 1, left_closed = right_closed;
+    for (int round = 0; !(right_closed && left_closed); ++round) {
+        const int so = group_signed_offset(round * G + g);
+        const int bb = b + so;
+        int rc = 0, lc = 0;
+        const bool side_closed = (so > 0 && right_closed) || (so < 0 && left_closed);
+        if (!side_closed) {
+            if (bb < 0) lc = 1;
+            else if (bb >= B) rc = 1;
+            else {
+                const int s0 = V.slab_start[bb], s1 = V.slab_start[bb + 1];
+                if (s0 < s1) {
+                    const float dx = so > 0 ? V.slab_xmin[bb] - p.x : (so < 0 ? p.x - V.slab_xmax[bb] : 0.f);
+                    if (dx > 0.f && dx * dx > r2) { if (so > 0) rc = 1; else lc = 1; }
+                    else {
+                        const int q0 = lower_bound_y(V, s0, s1, p.y);
+                        for (int i = q0; i < s1; ++i) {
+                            const float4 c = V.at(i);
+                            const float dy = p.y - c.y;
+                            if (dy * dy > r2) break;
+                            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
+                                const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
+                                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+                                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+                                accu[6] += x; accu[7] += y; accu[8] += z;
+                                count++;
+                            }
+                        }
+                        for (int i = q0 - 1; i >= s0; --i) {
+                            const float4 c = V.at(i);
+                            const float dy = p.y - c.y;
+                            if (dy * dy > r2) break;
+                            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
+                                const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
+                                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+                                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+                                accu[6] += x; accu[7] += y; accu[8] += z;
+                                count++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) { rc |= __shfl_xor(rc, o, 64); lc |= __shfl_xor(lc, o, 64); }
+        right_closed |= rc; left_closed |= lc;
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) {
+        for (int i = 0; i < 9; ++i) accu[i] += __shfl_xor(accu[i], o, 64);
+        count += __shfl_xor(count, o, 64);
+    }
+    if (count < 3) { out[0] = out[1] = out[2] = out[3] = NAN; return; }
+    float cnt = (float)count;
+    for (int i = 0; i < 9; ++i) accu[i] /= cnt;
+    float cov[9];
+    cov[0] = accu[0] - accu[6] * accu[6];
+    cov[1] = accu[1] - accu[6] * accu[7];
+    cov[2] = accu[2] - accu[6] * accu[8];
+    cov[4] = accu[3] - accu[7] * accu[7];
+    cov[5] = accu[4] - accu[7] * accu[8];
+    cov[8] = accu[5] - accu[8] * accu[8];
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, n[3];
+    pcl_eigen33_smallest(cov, &ev, n);
+    float eig_sum = cov[0] + cov[4] + cov[8];
+    float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+    float vx = vp[0] - p.x, vy = vp[1] - p.y, vz = vp[2] - p.z;
+    float cos_theta = vx * n[0] + vy * n[1] + vz * n[2];
+    if (cos_theta < 0) { n[0] *= -1; n[1] *= -1; n[2] *= -1; }
+    out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; out[3] = curv;
+}
+
 /* One workgroup per kept slice: a9 (sampling, path_translation_alg.cpp:156-169), then for every
    waypoint the nearest cloud point, its PCL normal, the tool frame and the hand-eye transform
    (:178-211).  The slabs within POSE_PAD mm of the plane and the slice's spline knots are staged
@@ -1321,7 +1478,13 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
 #define POSE_PAD 8.0f
 __host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 12; }
 
-__global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+#ifndef POSE_T
+#define POSE_T 1024
+#endif
+#ifndef POSE_GMAX
+#define POSE_GMAX 4
+#endif
+__global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
                                               const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                               const float *__restrict__ slab_xmax, const float *__restrict__ px,
                                               const float *__restrict__ node_x, const float *__restrict__ node_y,
@@ -1364,24 +1527,30 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
     auto Zf = [&](int i) { return (double)nz[i]; };
     auto Xf = [&](int i) { return (double)nx[i]; };
     const double start = (double)ny[0] + P.trim;
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-        double dy = start;
-        for (int r = 0; r < t; ++r) dy += P.path_resolution; /* the reference accumulates */
-        const int iv = gsl_bsearch(mm, dy, Yf);
-        const double xd = steffen_eval_at(iv, mm, dy, Yf, Xf);
-        const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
-        /* Vector4f(point) then invTransAlign (identity: Alignment=false); std::reverse on every second slice */
-        const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
-        const float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
-        wp_xyz[w] = q;
-        STAMP(1, 1); /* dy accumulation + spline */
-        float wp[6];
-        float n4[4];
-        int id = -1;
-        if (q.x == q.x && q.y == q.y && q.z == q.z) {
-            float4 p;
-            id = nearest_in_slabs(V, q.x, q.y, q.z, &p);
-            if (P.ranged && id >= 0) {
+    /* G lanes per waypoint: as many as the workgroup has to spare (the two searches walk G slabs side by side) */
+    const bool dy_closed_form = sums_exact(start, P.path_resolution, (double)cnt);
+    auto run = [&](auto gtag) {
+        constexpr int G = decltype(gtag)::value;
+        const int g = threadIdx.x & (G - 1), per = blockDim.x / G;
+        for (int base = 0; base < cnt; base += per) {
+            const int t = base + threadIdx.x / G;
+            const bool act = t < cnt; /* groups without a waypoint run along (the group shuffles need whole groups) and store nothing */
+            double dy = start;
+            if (dy_closed_form) dy = start + (double)(act ? t : 0) * P.path_resolution; /* every partial sum is exact: same bits */
+            else for (int r = 0; r < (act ? t : 0); ++r) dy += P.path_resolution;       /* the reference accumulates */
+            const int iv = gsl_bsearch(mm, dy, Yf);
+            const double xd = steffen_eval_at(iv, mm, dy, Yf, Xf);
+            const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
+            /* Vector4f(point) then invTransAlign (identity: Alignment=false); std::reverse on every second slice */
+            const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
+            const float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
+            STAMP(1, 1); /* dy accumulation + spline */
+            float n4[4] = {NAN, NAN, NAN, NAN};
+            const bool finite = q.x == q.x && q.y == q.y && q.z == q.z;
+            float4 p = make_float4(NAN, NAN, NAN, 0.f);
+            int id = nearest_in_slabs_group<G>(V, act && finite, q.x, q.y, q.z, &p, g, P.nn_hint2);
+            if (id < 0) id = nearest_in_slabs_group<G>(V, act && finite, q.x, q.y, q.z, &p, g, INFINITY); /* a hole in the cloud */
+            if (P.ranged && act && finite && id >= 0 && g == 0) {
                 /* only part of the cloud is indexed: the answer is the whole cloud's as long as the ball that
                    proves the nearest neighbour and the normal's radius search stay inside the indexed interval */
                 const float dq = sqrtf(dist2_flann(q.x, q.y, q.z, p.x, p.y, p.z)) * 1.0001f;
@@ -1389,22 +1558,31 @@ __global__ void __launch_bounds__(256) k_pose(DevMeta *m, DevParams P, const flo
                 if ((need_lo < m->incl_lo && m->incl_lo > m->mn[0]) || (need_hi > m->incl_hi && m->incl_hi < m->mx[0])) set_err(m, DERR_MARGIN, s);
             }
             STAMP(1, 2); /* nearest */
-            if (id >= 0) normal_at_point(V, p, P.normal_radius, P.viewpoint, n4);
+            normal_at_point_group<G>(V, act && finite && id >= 0, p, P.normal_radius, P.viewpoint, n4, g);
             STAMP(1, 3); /* normal */
+            if (act && g == 0) {
+                if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
+                float wp[6], rpy[3];
+                pose_from_normal(n4, rpy);
+                if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
+                else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
+                wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
+                handeye_transform(P.handeye, wp);
+                wp_xyz[w] = q;
+                wp_nn[w] = id;
+                wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];
+                for (int d = 0; d < 3; ++d) sx[(size_t)d * W + w] = wp[d];
+            }
+            STAMP(1, 4); /* pose + hand-eye */
         }
-        if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
-        float rpy[3];
-        pose_from_normal(n4, rpy);
-        if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
-        else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
-        wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
-        handeye_transform(P.handeye, wp);
-        STAMP(1, 4); /* pose + hand-eye */
-        wp_nn[w] = id;
-        wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
-        for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];
-        for (int d = 0; d < 3; ++d) sx[(size_t)d * W + w] = wp[d];
-    }
+    };
+    int G = 1;
+    while (G < POSE_GMAX && cnt * (2 * G) <= (int)blockDim.x) G *= 2;
+    if (G == 8) run(std::integral_constant<int, 8>{});
+    else if (G == 4) run(std::integral_constant<int, 4>{});
+    else if (G == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
 }
 
 __global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
