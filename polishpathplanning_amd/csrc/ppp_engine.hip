@@ -97,6 +97,7 @@ struct ppp_handle_s {
     DevMeta hmeta;
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
     bool meta_in_flight = false;
+    bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
@@ -714,6 +715,7 @@ int ppp_gen_path_async(ppp_handle h)
     }
     h->gen_done = true;
     h->path_done = false;
+    if (h->chain_calls) return PPP_OK; /* getPath follows in the same enqueue and ends with the copy */
     return enqueue_meta_copy(h);
 }
 
@@ -788,7 +790,9 @@ int ppp_run_async(ppp_handle h)
     }
     if (!h->graph_exec) {
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->chain_calls = true;
         int rc = ppp_gen_path_async(h);
+        h->chain_calls = false;
         if (rc == PPP_OK) rc = ppp_get_path_async(h);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(h->stream, &g);
@@ -860,7 +864,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         }
         for (size_t i = 0; i < count && e == hipSuccess && rc == PPP_OK; ++i) {
             ppp_handle h = hs[i];
+            h->chain_calls = true;
             rc = ppp_gen_path_async(h);
+            h->chain_calls = false;
             if (rc == PPP_OK) rc = ppp_get_path_async(h);
             if (rc == PPP_OK && dst_dev && !h->ranged) {
                 (void)hipGetLastError();

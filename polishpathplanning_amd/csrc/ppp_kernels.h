@@ -242,10 +242,12 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     __shared__ int s_scan[17];
     __shared__ float s_mn[3][4], s_mx[3][4];
     __shared__ int s_cnt[4];
-    __shared__ int s_S, s_total;
+    __shared__ int s_S, s_total, s_nfront, s_c;
+    __shared__ float s_mid;
     __shared__ float s_front[4096];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
+    STAMP_BEGIN();
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
         MinMaxPart r = part[i];
         cnt += r.cnt;
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
     cnt = wave_sum(cnt);
     if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
+    STAMP(5, 0); /* partials */
     /* exclusive scan of the slab histogram (k_minmax<true> filled it) -> CSR offsets + scatter
        cursors; the histogram is cleared for the next run */
     {
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         if (threadIdx.x == 0) { slab_start[B] = total; s_total = total; }
     }
     __syncthreads();
+    STAMP(5, 1); /* slab scan */
     if (threadIdx.x == 0) {
         int c = 0;
         for (int w = 0; w < 4; ++w) c += s_cnt[w];
@@ -291,7 +295,20 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
         r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1;
         r.big_slabs = 0; r.big_slices = 0; r.arena_cursor = 0;
-        int S = c ? slice_walk_device(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap, s_front, 4096) : 0;
+        int S = 0;
+        s_nfront = -1;
+        const int istep = (int)(P.tool_radius * 2);
+        if (c && P.walk == 1 /* centre-out integer walk */ && istep > 0 && r.mn[0] <= r.mx[0]) {
+            /* the centre-out integer walk is a closed form per index: only the counts here, every thread fills its
+               own entries below (one thread writing S values was two thirds of this kernel) */
+            const int imin = (int)r.mn[0], imax = (int)r.mx[0];
+            const int cc = (imax + imin) / 2;
+            int nfront = 0, nback = 0;
+            if (imax > cc - istep && cc - istep > imin) nfront = (cc - imin - 1) / istep;
+            if (imax > cc + istep && cc + istep > imin) nback = (imax - cc - 1) / istep;
+            S = nfront + 1 + nback;
+            s_nfront = nfront; s_c = cc; s_mid = (r.mn[0] + r.mx[0]) / 2;
+        } else if (c) S = slice_walk_device(P.walk, r.mn[0], r.mx[0], P.tool_radius, px, S_cap, s_front, 4096);
         if (S > S_cap) { r.err = DERR_CAPACITY; S = S_cap; }
         r.S = S;
         r.first_kept = P.drop_ends ? 1 : 0;
@@ -308,12 +325,16 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
         s_S = S;
     }
     __syncthreads();
+    STAMP(5, 2); /* bounds + slice walk (one thread) */
     const int S = s_S;
+    const int nfront = s_nfront, istep = (int)(P.tool_radius * 2);
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        if (nfront >= 0) px[s] = s < nfront ? (float)(s_c - (nfront - s) * istep) : (s == nfront ? s_mid : (float)(s_c + (s - nfront) * istep));
         int position = (int)px[s];
         lo[s] = (float)(-2 + position);
         hi[s] = (float)(2 + position);
     }
+    STAMP(5, 3); /* band limits */
 }
 
 /* ------------------------------------------------------------------ */
