@@ -739,12 +739,10 @@ int ppp_get_path_async(ppp_handle h)
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
     DevParams D = dev_params(h);
-    LAUNCH(h, "k_count", k_count, 1, 1024, 0, h->meta.p, D, h->node_y.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p,
-           h->wp_off.p, h->tail.p, h->W_cap, h->big_path ? 1 : 0);
     int nk = std::max(1, h->S_cap);
     LAUNCH(h, "k_pose", k_pose, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
-           h->capb,
+           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
     h->path_done = true;
     h->list_final = false;

@@ -1062,51 +1062,23 @@ __global__ void __launch_bounds__(256) k_insert_api(const float *__restrict__ X,
 /* ------------------------------------------------------------------ */
 /* a9: getPath sampling (path_translation_alg.cpp:149-169)              */
 /* ------------------------------------------------------------------ */
-__global__ void __launch_bounds__(1024) k_count(DevMeta *m, DevParams P, const float *__restrict__ node_y,
-                                                const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                                int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran)
+/* waypoints of one path: the reference's `dy = miny + trim; while (dy < bigy - trim) { ...; dy += res; }`
+   (path_translation_alg.cpp:158-166).  Closed form when the accumulated sums are exact, the loop otherwise. */
+__device__ inline int sample_count(double miny, double bigy, double trim, double res, int cap)
 {
-    __shared__ int scratch[17];
-    __shared__ int s_run;
-    if (threadIdx.x == 0) {
-        s_run = 0;
-        /* work was left for the arena passes but they were not launched: report, the host re-runs */
-        if (!arena_ran && (m->big_slabs > 0 || m->big_slices > 0)) atomicCAS(&m->err, 0, DERR_CAPACITY);
+    double dy = miny + trim;
+    const double lim = bigy - trim;
+    if (!(dy < lim)) return 0;
+    const double est = (lim - dy) / res;
+    if (est < 1.0e6 && sums_exact(dy, res, est + 2.0)) {
+        int j = (int)floor(est) - 1; /* never above the count; dy + j * res is exact for these j */
+        if (j < 0) j = 0;
+        while (dy + (double)j * res < lim) ++j;
+        return j > cap ? cap + 1 : j;
     }
-    __syncthreads();
-    const int nk = m->err ? 0 : m->nkept;
-    const int res_i = (int)P.rpy_resolution;
-    for (int base = 0; base < nk; base += blockDim.x) {
-        int k = base + threadIdx.x;
-        int cnt = 0;
-        if (k < nk) {
-            int s = k + m->first_kept;
-            if (s >= m->sb && s < m->se) {
-                int st = node_start[s], mm = node_cnt[s];
-                double miny = (double)node_y[st], bigy = (double)node_y[st + mm - 1];
-                double dy = miny + P.trim;
-                while (dy < bigy - P.trim && cnt <= W_cap) { cnt++; dy += P.path_resolution; }
-            }
-        }
-        int tot;
-        int pre = block_exscan(cnt, scratch, &tot);
-        int run = s_run;
-        if (k < nk) {
-            wp_cnt[k] = cnt;
-            wp_off[k] = run + pre;
-            tail[k] = run + pre + cnt - 1; /* TailIndex.push_back(WayPointsList.size()-1) */
-            if (P.rpy_resolution > 2 && cnt <= res_i) m->any_short = 1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_run = run + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int W = s_run;
-        if (W > W_cap) { set_err(m, DERR_CAPACITY, -1); W = 0; }
-        m->W = W;
-        wp_off[nk] = W;
-    }
+    int cnt = 0;
+    while (dy < lim && cnt <= cap) { cnt++; dy += res; }
+    return cnt;
 }
 
 /* ppp_run_batch_async: the finished list of one branch into the batch's device buffer */
@@ -1511,7 +1483,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                                               const float *__restrict__ node_x, const float *__restrict__ node_y,
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                              const int *__restrict__ wp_cnt, const int *__restrict__ wp_off, int capb,
+                                              int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
                                               float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -1519,12 +1491,46 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
     float *s_ny = (float *)(s_pts + POSE_STAGE_CAP);
     float *s_nz = s_ny + capb;
     float *s_nx = s_nz + capb;
+    __shared__ int s_scan[17];
+    __shared__ int s_mycnt, s_myoff, s_run;
     const int k = blockIdx.x;
-    const int W = m->W;
-    if (m->err || k >= m->nkept || W == 0) return;
+    const int nk = m->nkept;
+    if (m->err || k >= nk) return;
+    /* work was left for the arena passes but they were not launched: report, the host re-runs */
+    if (!arena_ran && (m->big_slabs > 0 || m->big_slices > 0)) { if (threadIdx.x == 0) atomicCAS(&m->err, 0, DERR_CAPACITY); return; }
+    /* a9 bookkeeping (the former k_count launch): the waypoint count of EVERY kept slice is recomputed in every
+       workgroup -- two knots and a closed form each -- so each workgroup knows its own offset in the list and W */
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nk; base += blockDim.x) {
+        const int k2 = base + threadIdx.x;
+        int c2 = 0;
+        if (k2 < nk) {
+            const int s2 = k2 + m->first_kept;
+            if (s2 >= m->sb && s2 < m->se) {
+                const int st2 = node_start[s2], mm2 = node_cnt[s2];
+                if (mm2 >= 1) c2 = sample_count((double)node_y[st2], (double)node_y[st2 + mm2 - 1], P.trim, P.path_resolution, W_cap);
+            }
+        }
+        int tot;
+        const int pre = block_exscan(c2, s_scan, &tot);
+        const int run = s_run;
+        if (k2 == k) { s_mycnt = c2; s_myoff = run + pre; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + tot;
+        __syncthreads();
+    }
+    const int W = s_run, cnt = s_mycnt, off = s_myoff;
+    if (W > W_cap) { if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, -1); if (k == 0) m->W = 0; } return; }
+    if (threadIdx.x == 0) {
+        wp_cnt[k] = cnt; wp_off[k] = off;
+        tail[k] = off + cnt - 1; /* TailIndex.push_back(WayPointsList.size()-1) */
+        if (P.rpy_resolution > 2 && cnt <= (int)P.rpy_resolution) m->any_short = 1;
+        if (k == 0) { m->W = W; wp_off[nk] = W; }
+    }
+    if (W == 0 || cnt == 0) return;
     const int s = k + m->first_kept;
-    const int st = node_start[s], mm = node_cnt[s], cnt = wp_cnt[k], off = wp_off[k];
-    if (cnt == 0) return;
+    const int st = node_start[s], mm = node_cnt[s];
     const float Px = px[s];
     STAMP_BEGIN();
     /* slabs to stage: widest symmetric range around the plane's slab that fits */
