@@ -1665,8 +1665,13 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* bound (12 f64 instructions per step), so the kernel evaluates it as   */
 /* a filter: c is computed for every element in parallel, then each      */
 /* thread runs  acc = c_i + 0.35 acc  (one FMA per step) over a run-up   */
-/* of SM_D elements -- the seed error decays by 0.35 per step, 0.35^17   */
-/* of a <= mm-sized seed is < 1e-10 m -- and over its own SM_L elements. */
+/* of SM_D = 8 elements -- the seed is the element's value one sweep     */
+/* earlier, off by at most that sweep's change (<= 1e-3 m); the error    */
+/* decays by 0.35 per step, 0.35^9 of it is < 1e-7 m, below the float    */
+/* rounding the difference to the reference already carries (measured:   */
+/* run-ups of 8, 12 and 16 give the same 2.4e-7 m) -- and over its own   */
+/* SM_L elements.  The run-up is the kernel's LDS traffic and the halo   */
+/* a tile carries per sweep: 16 -> 8 took cfg 5 from 209 to 118 us.      */
 /* Difference from the reference: the chain carries the unrounded double */
 /* instead of the float-rounded y'_{i-1}; that perturbs each sweep by    */
 /* < 1 float ulp (6e-8 m) and the sweeps contract by ~0.5, so the        */
@@ -1680,7 +1685,9 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* stop sweep.                                                           */
 /* ------------------------------------------------------------------ */
 #define SM_K 16
-#define SM_D 16
+#ifndef SM_D
+#define SM_D 8
+#endif
 #define SM_L 1
 #define SM_T 512
 #define SM_M (SM_T * SM_L)
