@@ -188,7 +188,11 @@ def main():
                    "seconds": t_cpu, "host_cores_available": os.cpu_count()}
             # context only: the same pass with OpenMP over the slices and over the points of the normal
             # estimation; the kd-tree builds stay serial, as FLANN's are in the reference
-            nt = os.cpu_count() or 1
+            try:
+                nt = len(os.sched_getaffinity(0))
+            except AttributeError:
+                nt = os.cpu_count() or 1
+            nt = min(nt, 16)   # the CPU share of one GPU on the bench node
             if nt > 1:
                 o2 = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1, threads=nt)
                 t2 = time.perf_counter()

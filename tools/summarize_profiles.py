@@ -13,12 +13,23 @@ if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
 
 
+def kernel_key(name):
+    """'void k_slice_kd<false>(HIP_vector_type<...' -> 'k_slice_kd' (the name bench.py's event timers use; the <true>
+    instantiations are the arena passes, timed as '<kernel>_arena')."""
+    base = name.split("(")[0].replace("void ", "").strip()
+    if "<" in base:
+        base, targ = base.split("<", 1)
+        if targ.startswith("true"):
+            base += "_arena"
+    return base
+
+
 def pmc(sub, name):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
-                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                acc[kernel_key(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
@@ -31,7 +42,7 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     table[k] = {"fetch_size_kb": f, "write_size_kb": w, "launches_sampled": nf.get(k, nw.get(k, 0)),
                 "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
-json.dump({"tag": tag, "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE in KB, mean per launch; hbm_bytes = (2*FETCH + WRITE)*1024",
+json.dump({"tag": tag, "workload": os.environ.get("PPP_PROFILE_WORKLOAD", "cfg2_1m_s256"), "units": "rocprofv3 FETCH_SIZE/WRITE_SIZE in KB, mean per launch; hbm_bytes = (2*FETCH + WRITE)*1024",
            "kernels": table}, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print(open(os.path.join(dst, "%s_traffic.json" % tag)).read()[:3000])
 if stats:
