@@ -106,15 +106,11 @@ def main():
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
 
     def step():
-        if len(engines) == 1:
-            engines[0].run_async()   # GenPath + getPath: one captured hipGraph launch
-            w = engines[0].copy_waypoints_to_device(send.data_ptr(), send.shape[0])
-        else:
-            # one hipGraph for the whole batch, a branch per workpiece; every branch ends by copying its list
-            # to its place in the gather buffer
-            engine.run_batch_async(engines, send.data_ptr(), offs, w_all)
-            engine.sync_batch(engines)
-            w = int(sum(w_all))
+        # GenPath + getPath of every workpiece of this rank as ONE hipGraph launch (a branch per workpiece); every
+        # branch ends by copying its WayPointsList to its place in the gather buffer, so the host waits once
+        engine.run_batch_async(engines, send.data_ptr(), offs, w_all)
+        engine.sync_batch(engines)
+        w = int(sum(w_all))
         blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev, counts)
         return w, blocks
 

@@ -98,6 +98,7 @@ struct ppp_handle_s {
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
     bool meta_in_flight = false;
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
+    bool chain_copy_out = false;    /* getPath is followed by the batch's copy-out kernel, which ends with the copy */
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
@@ -752,6 +753,7 @@ int ppp_get_path_async(ppp_handle h)
         if (rc) return rc;
         h->list_final = true;
     }
+    if (h->chain_copy_out) return PPP_OK;
     return enqueue_meta_copy(h);
 }
 
@@ -865,7 +867,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
             h->chain_calls = true;
             rc = ppp_gen_path_async(h);
             h->chain_calls = false;
+            h->chain_copy_out = dst_dev && !h->ranged;
             if (rc == PPP_OK) rc = ppp_get_path_async(h);
+            h->chain_copy_out = false;
             if (rc == PPP_OK && dst_dev && !h->ranged) {
                 (void)hipGetLastError();
                 hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((6 * (size_t)h->W_cap + 255) / 256)), dim3(256), 0, h->stream, h->meta.p,
