@@ -74,8 +74,15 @@ public:
         /* local id = position in ids (like the per-slice sub-clouds cloudEl / cloudEr) */
         if (ids) sub_.assign(ids, ids + n);
         else sub_.clear();
-        order_.resize(n);
-        for (int i = 0; i < n; ++i) order_[i] = i;
+        /* pcl::KdTreeFLANN::convertCloudToArray leaves non-finite points out of the index (a cloud read with NaNs is
+           not dense); they would also break the ordering the median split relies on */
+        order_.clear();
+        order_.reserve(n);
+        for (int i = 0; i < n; ++i) {
+            const float *c = p(i);
+            if (std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2])) order_.push_back(i);
+        }
+        n = (int)order_.size();
         nodes_.clear();
         if (n > 0) { nodes_.reserve(2 * n / kLeaf + 8); build_rec(0, n); }
     }

@@ -126,6 +126,33 @@ def test_nearest_and_radius_match_brute_force(small):
         assert np.array_equal(got, want)
 
 
+def test_kdtree_leaves_non_finite_points_out(oracle_mod):
+    """pcl::KdTreeFLANN indexes finite points only (a cloud read with NaNs is not dense); found by tools/fuzz_parity.py:
+    NaNs inside the median split used to corrupt the tree and return a far point for ~1 % of the queries."""
+    from polishpathplanning_amd import synth
+    pts = synth.make_plate(200, 80, kind="wavy", amp=20.0, seed=5)
+    rng = np.random.default_rng(3)
+    pts[rng.integers(0, len(pts), 25)] = np.nan
+    pts[rng.integers(0, len(pts), 5), 1] = np.inf
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    cloud = o.points()
+    finite = np.isfinite(cloud).all(axis=1)
+    for _ in range(1500):
+        qi = cloud[rng.integers(0, len(cloud))]
+        if not np.isfinite(qi).all():
+            continue
+        qi = qi + rng.normal(0, 0.7, 3).astype(np.float32)
+        diff = qi[None, :] - cloud
+        with np.errstate(invalid="ignore"):
+            d = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+        d[~finite] = np.inf
+        i, d2 = o.nearest(qi)
+        assert i == int(np.argmin(d)) and d2 == d.min()
+        got = np.sort(o.radius_search(qi, 2.5))
+        assert np.array_equal(got, np.nonzero(d <= np.float32(6.25))[0])
+        assert np.array_equal(o.knn(qi, 10), np.lexsort((np.arange(len(d)), d))[:10])
+
+
 # ---------------- A.4: normals vs numpy eigh -----------------
 def test_normals_match_eigh(small):
     pts, o = small

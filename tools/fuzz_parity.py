@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle sweep over cloud shapes, tool radii, walks, pairings and the dynamic adjustment.
+Every case must agree on S, the knots of every slice (bit-exact), W and the waypoints (<= 1e-4 m), or both
+sides must report the same failing slice.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polishpathplanning_amd import engine, synth  # noqa: E402
+from oracle import ppo  # noqa: E402
+
+
+def one_case(rng, i, only=None, verbose=False):
+    kind = rng.choice(["dome", "wavy", "blade", "flat"])
+    nx = int(rng.integers(120, 420)); ny = int(rng.integers(40, 160))
+    amp = float(rng.uniform(2.0, 40.0))
+    R = float(rng.choice([4.0, 5.0, 6.0, 7.5, 9.0, 12.0, 15.0]))
+    walk = int(rng.integers(0, 5))
+    dyn = int(walk in (1, 2, 3) and rng.random() < 0.5)
+    pairing = 1 if walk in (3, 4) else int(rng.random() < 0.25)
+    x0 = float(rng.uniform(-300.0, 300.0))
+    pts = synth.make_plate(nx, ny, kind=kind, amp=amp, seed=int(rng.integers(1 << 30)), x0_mm=x0)
+    if rng.random() < 0.2:    # duplicated points (coordinate ties, map key collisions)
+        k = int(rng.integers(1, 50))
+        pts = np.concatenate([pts, pts[rng.integers(0, len(pts), k)]])
+    if rng.random() < 0.15:   # a few non-finite points, skipped by every PCL stage
+        pts[rng.integers(0, len(pts), 3)] = np.nan
+    kw = dict(tool_radius=R, walk=walk, pairing=pairing, dynamic_adjustment=dyn,
+              path_resolution=float(rng.choice([3.0, 5.0, 7.0, 7.3])), rpy_resolution=float(rng.choice([0.0, 3.0, 7.0])),
+              trim=float(rng.choice([5.0, 10.0])), smooth=int(rng.random() < 0.8))
+    if walk == 3 and dyn:
+        kw.update(curvature_k=10, depth=0.005)
+    desc = "case %d: %s %dx%d amp %.1f R %.1f walk %d pairing %d dyn %d res %.1f rpy %.0f trim %.0f smooth %d n %d" % (
+        i, kind, nx, ny, amp, R, walk, pairing, dyn, kw["path_resolution"], kw["rpy_resolution"], kw["trim"], kw["smooth"], len(pts))
+    if only is not None and i != only:
+        return None, "skipped"
+    if verbose:
+        np.save("gpurun_out/fuzz_case_%d.npy" % i, pts)
+        print(kw)
+    o = ppo.Oracle(pts, **kw)
+    So = o.gen_path()
+    e = engine.Engine(0, **kw)
+    e.set_cloud(pts)
+    try:
+        S = e.gen_path()
+    except engine.PPPError as ex:
+        if So < 0 and e.failed_slice() == -(So + 1):
+            return "both fail at slice %d" % e.failed_slice(), desc
+        return "GPU error %s (oracle S=%d)" % (ex, So), desc
+    if So < 0:
+        return "oracle fails at slice %d, GPU S=%d" % (-(So + 1), S), desc
+    if S != So:
+        return "S %d != %d" % (S, So), desc
+    bad = [s for s in range(S) if not all(np.array_equal(a, b) for a, b in zip(e.nodes(s), o.nodes(s)))]
+    if bad:
+        return "knots differ in slices %s" % bad[:5], desc
+    Wo = o.get_path()
+    try:
+        W = e.get_path()
+    except engine.PPPError as ex:
+        return "GPU getPath error %s (oracle W=%d)" % (ex, Wo), desc
+    if W != Wo:
+        return "W %d != %d" % (W, Wo), desc
+    if W:
+        dv = np.linalg.norm(e.waypoints()[:, :3] - o.waypoints()[:, :3], axis=1)
+        d = dv.max()
+        if verbose:
+            for st, name in ((engine.STAGE_WP_XYZ, "xyz"), (engine.STAGE_WP_PRESMOOTH, "presmooth"), (engine.STAGE_WP_SMOOTHED, "smoothed")):
+                g = e.stage(st)
+                w = {"xyz": o.waypoints_xyz, "presmooth": o.waypoints_presmooth, "smoothed": o.waypoints_smoothed}[name]()
+                print(name, "max diff", np.abs(g[:, :3] - w[:, :3]).max())
+            nn_g, nn_o = e.stage(engine.STAGE_WP_NN), o.waypoint_nn()
+            print("nn equal", np.array_equal(nn_g, nn_o), "worst waypoints", np.argsort(-dv)[:5], dv[np.argsort(-dv)[:5]])
+            P = (pts * np.float32(1000)).astype(np.float32)
+            Q = e.stage(engine.STAGE_WP_XYZ)
+            for w in np.nonzero(nn_g != nn_o)[0][:6]:
+                def d2(i):
+                    dx, dy, dz = Q[w, 0] - P[i, 0], Q[w, 1] - P[i, 1], Q[w, 2] - P[i, 2]
+                    return np.float32(np.float32(dx * dx + dy * dy) + dz * dz)
+                allf = ((Q[w, 0] - P[:, 0]) ** 2 + (Q[w, 1] - P[:, 1]) ** 2) + (Q[w, 2] - P[:, 2]) ** 2
+                print(" waypoint", w, Q[w], "gpu nn", nn_g[w], d2(nn_g[w]), P[nn_g[w]], "oracle nn", nn_o[w], d2(nn_o[w]), P[nn_o[w]], "brute", np.nanargmin(allf), np.nanmin(allf))
+            n_g, n_o = e.stage(engine.STAGE_WP_NORMAL), o.waypoint_normals()
+            ang = np.arctan2(np.linalg.norm(np.cross(n_g[:, :3], n_o[:, :3]), axis=1), np.sum(n_g[:, :3] * n_o[:, :3], axis=1))
+            print("normal angle max", ang.max(), "at", ang.argmax(), n_g[ang.argmax()], n_o[ang.argmax()])
+            print("rpy g", e.waypoints()[dv.argmax()], "o", o.waypoints()[dv.argmax()])
+        if not d <= 1e-4:
+            return "waypoints differ by %.3e m" % d, desc
+        r = np.abs(e.waypoints()[:, 3:] - o.waypoints()[:, 3:]); r = np.minimum(r, np.abs(r - 2 * np.pi)).max()
+        if not r <= 2e-3:
+            return "angles differ by %.3e rad" % r, desc
+        if not np.array_equal(e.tail_index(), o.tail_index()):
+            return "TailIndex differs", desc
+    return None, desc
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    rng = np.random.default_rng(seed)
+    fails = 0
+    t0 = time.time()
+    for i in range(n):
+        res, desc = one_case(rng, i, only, verbose=only is not None)
+        if desc == "skipped":
+            continue
+        ok = res is None or res.startswith("both fail")
+        if not ok:
+            fails += 1
+        print(("ok   " if ok else "FAIL ") + desc + ("" if res is None else " -> " + res), flush=True)
+    print("%d cases, %d failures, %.0f s" % (n, fails, time.time() - t0))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
