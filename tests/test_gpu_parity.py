@@ -516,21 +516,12 @@ class _DeviceBuffer:
     """hipMalloc'ed bytes through the HIP runtime the engine already loaded (no torch in these tests)."""
 
     def __init__(self, nbytes):
-        import ctypes as C
-        self.hip = C.CDLL("libamdhip64.so")
-        p = C.c_void_p()
-        assert self.hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
-        self.ptr, self.nbytes = p.value, nbytes
+        from polishpathplanning_amd.hipbuf import DeviceBuffer
+        self._b = DeviceBuffer(nbytes)
+        self.ptr, self.nbytes = self._b.ptr, nbytes
 
     def to_host(self, nfloats):
-        import ctypes as C
-        out = np.empty(nfloats, np.float32)
-        assert self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(4 * nfloats), 2) == 0
-        return out.reshape(-1, 6)
-
-    def __del__(self):
-        import ctypes as C
-        self.hip.hipFree(C.c_void_p(self.ptr))
+        return self._b.to_host(nfloats).reshape(-1, 6)
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -13,6 +13,35 @@ from polishpathplanning_amd import engine, synth  # noqa: E402
 from oracle import ppo  # noqa: E402
 
 
+rng2 = np.random.default_rng(12345)  # choices that must not disturb the case stream
+
+
+def sharded_matches(one, pts, kw, S, world):
+    """slice-range handles + ppp_finish_path_async against the single handle: must be byte-identical"""
+    from polishpathplanning_amd.hipbuf import DeviceBuffer
+    from polishpathplanning_amd.robot_path import slice_ranges
+    W = one.num_waypoints()
+    buf = DeviceBuffer(max(W, 1) * 24)
+    off, counts, engines = 0, None, []
+    for b, e_ in slice_ranges(S, world):
+        if b == e_:
+            continue
+        g = engine.Engine(0, slice_begin=b, slice_end=e_, **kw)
+        g.set_cloud(pts)
+        g.gen_path(); g.get_path()
+        off += g.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, buf.ptr + 24 * off, W - off)
+        c = g.waypoint_counts()
+        counts = c if counts is None else counts + c
+        engines.append(g)
+    if off != W:
+        return "sharded (%d ranges): %d waypoints, single handle %d" % (world, off, W)
+    fin = engines[0]
+    fin.finish_path_async(buf.ptr, W, counts); fin.sync()
+    if fin.waypoints().tobytes() != one.waypoints().tobytes() or not np.array_equal(fin.tail_index(), one.tail_index()):
+        return "sharded (%d ranges) list differs from the single handle by %.3e" % (world, np.abs(fin.waypoints() - one.waypoints()).max())
+    return None
+
+
 def one_case(rng, i, only=None, verbose=False):
     kind = rng.choice(["dome", "wavy", "blade", "flat"])
     nx = int(rng.integers(120, 420)); ny = int(rng.integers(40, 160))
@@ -93,6 +122,10 @@ def one_case(rng, i, only=None, verbose=False):
             return "angles differ by %.3e rad" % r, desc
         if not np.array_equal(e.tail_index(), o.tail_index()):
             return "TailIndex differs", desc
+        if not dyn:
+            res = sharded_matches(e, pts, kw, S, int(rng2.integers(2, 6)))
+            if res:
+                return res, desc
     return None, desc
 
 
