@@ -126,6 +126,9 @@ int ppp_run_async(ppp_handle h);
 int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows);
 /* waits for the batch, returns the first handle's error (index in *failed when not NULL) */
 int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed);
+/* the handle's HIP stream (hipStream_t), so a framework can order its own work after the planner's on the GPU
+ * (e.g. torch.cuda.ExternalStream + wait_stream before the RCCL gather) instead of waiting on the host */
+int ppp_get_stream(ppp_handle h, void **stream);
 /* waits for the stream, then reports deferred device-side errors */
 int ppp_sync(ppp_handle h);
 int ppp_failed_slice(ppp_handle h);

@@ -911,6 +911,13 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     return PPP_OK;
 }
 
+int ppp_get_stream(ppp_handle h, void **stream)
+{
+    if (!h || !stream) return PPP_ERR_ARG;
+    *stream = (void *)h->stream;
+    return PPP_OK;
+}
+
 int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed)
 {
     if (!hs || !count) return PPP_ERR_ARG;

@@ -77,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
         L.ppp_get_waypoint_counts.argtypes = [vp, ip, sz, szp]
         L.ppp_run_batch_async.argtypes = [C.POINTER(vp), sz, vp, szp, szp]
         L.ppp_sync_batch.argtypes = [C.POINTER(vp), sz, szp]
+        L.ppp_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_finish_path_async.argtypes = [vp, vp, sz, ip, sz]
         L.ppp_minmax.argtypes = [vp, fp, fp]
@@ -355,6 +356,12 @@ class Engine:
         w = C.c_size_t()
         self._chk(self.L.ppp_copy_waypoints_to_device(self.h, C.c_void_p(dptr), cap, C.byref(w)))
         return w.value
+
+    def stream_ptr(self):
+        """hipStream_t of this handle as an integer (torch.cuda.ExternalStream(ptr) orders framework work behind it)."""
+        p = C.c_void_p()
+        self._chk(self.L.ppp_get_stream(self.h, C.byref(p)))
+        return p.value
 
     def waypoint_counts(self):
         """Waypoints per kept slice in list order (zero outside this handle's slice range)."""
