@@ -99,9 +99,11 @@ def main():
     for e in engines[1:]:
         e.gen_path()
         w_all.append(e.get_path())
-    send = torch.zeros((sum(w_all) + 64 * args.batch, 6), dtype=torch.float32, device=dev)
-    # the batch is fixed, so is every rank's waypoint count: exchanged once, checked on every gather
-    counts = exchange_counts(sum(w_all), dist, dev) if world > 1 else None
+    # the batch is fixed, so is every rank's waypoint count: exchanged once; the engines write straight into the
+    # gatherer's send buffer, so a step's exchange is one collective and no copy
+    from polishpathplanning_amd.robot_path import RobotPathGatherer
+    gatherer = RobotPathGatherer(sum(w_all), dist if world > 1 else None, dev)
+    send = gatherer.send
 
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
 
@@ -113,7 +115,7 @@ def main():
         engine.run_batch_async(engines, send.data_ptr(), offs, w_all)
         engine.sync_batch(engines)
         w = int(sum(w_all))
-        blocks = gather_robot_path(send[:w], dist if world > 1 else None, dev, counts)
+        blocks = gatherer.gather()
         return w, blocks
 
     def fence():

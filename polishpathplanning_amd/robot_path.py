@@ -44,6 +44,41 @@ def gather_robot_path(local_wp, dist=None, device=None, counts=None):
     return [recv[r * wmax: r * wmax + counts[r]] for r in range(world)]
 
 
+class RobotPathGatherer:
+    """The same exchange with its buffers allocated once: the planner writes its W_local x 6 list straight into
+    `send` (ppp_run_batch_async / ppp_copy_waypoints_to_device), gather() is then ONE collective and no copy.
+    counts are exchanged at construction (a fixed batch has fixed counts; set_local_count() re-exchanges)."""
+
+    def __init__(self, w_local, dist=None, device=None):
+        import torch
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.device = device
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.torch = torch
+        self.send = None
+        self.set_local_count(w_local)
+
+    def set_local_count(self, w_local):
+        torch = self.torch
+        self.w_local = int(w_local)
+        self.counts = exchange_counts(self.w_local, self.dist, self.device) if self.dist else [self.w_local]
+        wmax = max(max(self.counts), 1)
+        if self.send is None or self.send.shape[0] != wmax:
+            self.send = torch.zeros((wmax, 6), dtype=torch.float32, device=self.device)
+            self.recv = torch.empty((self.world * wmax, 6), dtype=torch.float32, device=self.device) if self.dist else None
+        self.wmax = wmax
+
+    def gather(self):
+        """rank 0: list of per-rank [W_r, 6] views in rank order; other ranks: None"""
+        if not self.dist:
+            return [self.send[: self.w_local]]
+        self.dist.all_gather_into_tensor(self.recv, self.send)
+        if self.rank != 0:
+            return None
+        return [self.recv[r * self.wmax: r * self.wmax + self.counts[r]] for r in range(self.world)]
+
+
 def slice_ranges(num_slices, world):
     """SURVEY.md 8e case (ii): GPU g plans the slices [g*S/world, (g+1)*S/world) of ONE cloud."""
     return [(g * num_slices // world, (g + 1) * num_slices // world) for g in range(world)]

@@ -60,12 +60,20 @@ def _worker(rank, world, port, q):
     from polishpathplanning_amd.robot_path import exchange_counts
     counts = exchange_counts(w, dist, local.device)
     again = gather_robot_path(local, dist, counts=counts)       # cached counts: no count exchange
+    from polishpathplanning_amd.robot_path import RobotPathGatherer
+    g = RobotPathGatherer(w, dist, local.device)                # preallocated form: the planner writes into g.send
+    assert g.counts == counts and g.send.shape == (max(counts), 6)
+    third = None
+    for _ in range(2):                                          # buffers are reused from step to step
+        g.send[:w] = local
+        third = g.gather()
     if rank == 0:
         full = concat_robot_path(blocks)
         assert torch.equal(full, concat_robot_path(again))
+        assert torch.equal(full, concat_robot_path(third))
         q.put(([b.shape[0] for b in blocks], full.numpy()))
     else:
-        assert blocks is None and again is None
+        assert blocks is None and again is None and third is None
     dist.barrier()
     dist.destroy_process_group()
 
