@@ -394,10 +394,10 @@ int enqueue_index(ppp_handle h)
            h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
-    int chunk = 4096;
+    int chunk = SCAT_CHUNK;
     while (chunk < 32768 && (n + chunk - 1) / chunk > 768) chunk <<= 1;
     int gs = std::max(1, (n + chunk - 1) / chunk);
-    LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
+    LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
            h->slab_cursor.p, h->unsorted4.p);
     size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
     LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,

@@ -370,7 +370,13 @@ __global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, 
     }
 }
 
-__global__ void __launch_bounds__(256) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
+#ifndef SCAT_T
+#define SCAT_T 1024
+#endif
+#ifndef SCAT_CHUNK
+#define SCAT_CHUNK 4096
+#endif
+__global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
                                                       const float *__restrict__ Z, int n, int chunk, const DevMeta *m,
                                                       int *slab_cursor, float4 *unsorted4)
 {
