@@ -98,7 +98,8 @@ struct ppp_handle_s {
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
     bool meta_in_flight = false;
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
-    bool chain_copy_out = false;    /* getPath is followed by the batch's copy-out kernel, which ends with the copy */
+    float *out2 = nullptr;          /* batched form: k_finish also writes the list here (at most out2_cap rows) */
+    int out2_cap = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
@@ -729,8 +730,8 @@ int enqueue_finish(ppp_handle h, const DevParams &D)
     for (int b = 0; b <= nb; ++b)
         LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
                h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
-    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p);
-    return PPP_OK;
+    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p, h->out2, h->out2_cap);
+    return enqueue_meta_copy(h);
 }
 
 int ppp_get_path_async(ppp_handle h)
@@ -749,11 +750,11 @@ int ppp_get_path_async(ppp_handle h)
     h->list_final = false;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
     if (!h->ranged) {
-        int rc = enqueue_finish(h, D);
+        int rc = enqueue_finish(h, D); /* publishes the meta block itself */
         if (rc) return rc;
         h->list_final = true;
+        return PPP_OK;
     }
-    if (h->chain_copy_out) return PPP_OK;
     return enqueue_meta_copy(h);
 }
 
@@ -774,7 +775,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
     int rc = enqueue_finish(h, D);
     if (rc) return rc;
     h->gen_done = true; h->path_done = true; h->list_final = true;
-    return enqueue_meta_copy(h);
+    return PPP_OK;
 }
 
 int ppp_run_async(ppp_handle h)
@@ -830,10 +831,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     if (plain) { /* kernel timing brackets every launch with events: plain per-handle calls */
         for (size_t i = 0; i < count; ++i) {
             int rc = ppp_gen_path_async(hs[i]);
+            if (dst_dev) { hs[i]->out2 = dst_dev + 6 * offset_rows[i]; hs[i]->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
             if (rc == PPP_OK) rc = ppp_get_path_async(hs[i]);
-            if (rc == PPP_OK && dst_dev && !hs[i]->ranged)
-                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((6 * (size_t)hs[i]->W_cap + 255) / 256)), dim3(256), 0, hs[i]->stream, hs[i]->meta.p,
-                                   hs[i]->wp_out.p, dst_dev + 6 * offset_rows[i], (int)std::min<size_t>(cap_rows[i], 0x7fffffff));
+            hs[i]->out2 = nullptr; hs[i]->out2_cap = 0;
             if (rc) { lead->err = hs[i]->err; return rc; }
         }
         return PPP_OK;
@@ -867,18 +867,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
             h->chain_calls = true;
             rc = ppp_gen_path_async(h);
             h->chain_calls = false;
-            h->chain_copy_out = dst_dev && !h->ranged;
-            if (rc == PPP_OK) rc = ppp_get_path_async(h);
-            h->chain_copy_out = false;
-            if (rc == PPP_OK && dst_dev && !h->ranged) {
-                (void)hipGetLastError();
-                hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((6 * (size_t)h->W_cap + 255) / 256)), dim3(256), 0, h->stream, h->meta.p,
-                                   h->wp_out.p, dst_dev + 6 * offset_rows[i], (int)std::min<size_t>(cap_rows[i], 0x7fffffff));
-                e = hipGetLastError();
-                if (e != hipSuccess) where = "copy-out launch";
-                /* the copy may flag an overflow: refresh the host copy of the meta block behind it */
-                if (e == hipSuccess) rc = enqueue_meta_copy(h);
-            }
+            if (dst_dev) { h->out2 = dst_dev + 6 * offset_rows[i]; h->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
+            if (rc == PPP_OK) rc = ppp_get_path_async(h); /* k_finish also writes the list to its place in dst_dev */
+            h->out2 = nullptr; h->out2_cap = 0;
             if (rc != PPP_OK) lead->err = "batch member " + std::to_string(i) + ": " + h->err;
             if (i && e == hipSuccess && rc == PPP_OK) {
                 e = hipEventRecord(bg->join[i], h->stream);

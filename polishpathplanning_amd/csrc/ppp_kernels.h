@@ -1087,16 +1087,6 @@ __device__ inline int sample_count(double miny, double bigy, double trim, double
     return cnt;
 }
 
-/* ppp_run_batch_async: the finished list of one branch into the batch's device buffer */
-__global__ void __launch_bounds__(256) k_copy_out(DevMeta *m, const float *__restrict__ src, float *dst, int cap_rows)
-{
-    const int W = m->W;
-    if (m->err || W == 0) return;
-    if (W > cap_rows) { if (blockIdx.x == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1); return; }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 6 * W) dst[i] = src[i];
-}
-
 /* ppp_finish_path_async: the list was sampled elsewhere (slice-range handles); rebuild the per-run state
    getPath's second half needs from the per-slice counts: offsets, TailIndex, the B.6 flag, W. */
 __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,
@@ -1895,7 +1885,7 @@ __device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int
 /* reduceRPY (path_translation_alg.cpp:37-86) per waypoint -- the key waypoints (every RPYres-th
    of a slice) are never modified, so every interval is independent --, then the -180..180 limit
    (:81-85) and TransFlangeposition (:89-112).  src: smoothed list; out: final WayPointsList. */
-__global__ void __launch_bounds__(64) k_finish(const DevMeta *m, DevParams P, const int *__restrict__ tail,
+__device__ inline void finish_waypoints(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
                                                const float *__restrict__ src, float *out)
 {
     const int W = m->W;
@@ -1964,4 +1954,27 @@ __global__ void __launch_bounds__(64) k_finish(const DevMeta *m, DevParams P, co
     for (int i = 0; i < 3; ++i) t[i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
     out[6 * (size_t)w + 0] = t[0]; out[6 * (size_t)w + 1] = t[1]; out[6 * (size_t)w + 2] = t[2];
     out[6 * (size_t)w + 3] = p[3]; out[6 * (size_t)w + 4] = p[4]; out[6 * (size_t)w + 5] = p[5];
+}
+
+/* The launch: finish_waypoints, then (batched form) the list's copy into the caller's buffer -- the pass ends without a
+   separate copy-out launch.  (Also publishing the meta block from the last workgroup to retire, instead of the
+   device-to-host blit that follows, was measured and is slower: ~400 same-address tickets + stores across PCIe.) */
+__global__ void __launch_bounds__(64) k_finish(DevMeta *m, DevParams P, const int *__restrict__ tail, const float *__restrict__ src,
+                                               float *out, float *dst2, int cap2)
+{
+    finish_waypoints(m, P, tail, src, out);
+    const int W = m->W;
+    if (dst2 && !m->err && W > 0) {
+        if (W > cap2) { if (blockIdx.x == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1); }
+        else if (P.rpy_resolution > 2 && m->any_short) {
+            /* the sequential B.6 path finished the whole list in thread 0 of workgroup 0: that workgroup copies it */
+            if (blockIdx.x == 0) {
+                __syncthreads();
+                for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = out[i];
+            }
+        } else {
+            const int w = blockIdx.x * blockDim.x + threadIdx.x;
+            if (w < W) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)w + d] = out[6 * (size_t)w + d];
+        }
+    }
 }

@@ -565,15 +565,19 @@ def test_slice_range_margin_too_small_is_reported(engine_mod):
 
 def test_run_batch_graph_matches_single_handles(engine_mod):
     """ppp_run_batch_async: several workpieces as one hipGraph with a branch each, lists landing in one device buffer."""
-    kinds = [("small_40k", 1), ("tiny_5k", 2), ("small_40k", 3), ("tiny_5k", 4), ("small_40k", 5)]
-    clouds = [synth.make_config(n, seed=s)[0] for n, s in kinds]
+    # the last member has slices shorter than RPYres + 1 waypoints: the sequential B.6 path of k_finish, which copies
+    # its list into the batch buffer from one workgroup
+    kinds = [("small_40k", 1, {}), ("tiny_5k", 2, {}), ("small_40k", 3, {}), ("tiny_5k", 4, {}), ("small_40k", 5, {}),
+             ("tiny_5k", 6, dict(path_resolution=9.0))]
+    clouds = [synth.make_config(n, seed=s)[0] for n, s, _ in kinds]
     want = []
-    for pts in clouds:
-        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path(); e.get_path()
+    for pts, (_, _, kw) in zip(clouds, kinds):
+        e = engine_mod.Engine(0, tool_radius=6.0, **kw); e.set_cloud(pts); e.gen_path(); e.get_path()
         want.append(e.waypoints())
+    assert e.waypoint_counts().max() <= 7
     engines = []
-    for pts in clouds:
-        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); engines.append(e)
+    for pts, (_, _, kw) in zip(clouds, kinds):
+        e = engine_mod.Engine(0, tool_radius=6.0, **kw); e.set_cloud(pts); engines.append(e)
     ws = [len(w) for w in want]
     offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
     buf = _DeviceBuffer(sum(ws) * 24)
