@@ -1685,7 +1685,9 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 #define SM_D 8
 #endif
 #define SM_L 1
+#ifndef SM_T
 #define SM_T 512
+#endif
 #define SM_M (SM_T * SM_L)
 #define SM_HB ((SM_D + 1) * SM_K + 1)
 #define SM_OWN (SM_M - SM_HB - SM_K)
@@ -1774,6 +1776,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
     }
 
     /* ---- SM_K more sweeps from the state after SM_K*b sweeps ---- */
+    STAMP_BEGIN();
     const int base = t0 - SM_HB; /* LDS slot l <-> list index base + l */
     for (int j = 0; j < 3; ++j) {
         const float *X = sx + (size_t)j * W;
@@ -1786,6 +1789,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
         }
     }
     __syncthreads();
+    STAMP(6, 0); /* tile load */
     float (*cur)[SM_M] = s_a, (*nxt)[SM_M] = s_b;
     const int l0 = threadIdx.x * SM_L; /* this thread's LDS slots l0 .. l0+SM_L-1 */
     for (int k = 1; k <= SM_K; ++k) {
@@ -1805,6 +1809,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
             }
         }
         lds_barrier();
+        STAMP(6, 1); /* c_i */
         const int a = max(base + l0, lo_k), e = min(base + l0 + SM_L, hi_k);
         double change = 0;
         if (a < e) {
@@ -1812,7 +1817,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
             double acc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[j] = (double)cur[j][rs - 1 - base];
-            for (int i = rs; i < a; ++i) {
+            for (int i = rs; i < a; ++i) { /* (hoisting all reads in front of a predicated, unrolled chain measured slower) */
                 const int l = i - base;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[j] = s_c[j][l] + weight_smooth * acc[j];
@@ -1831,12 +1836,14 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
         s_chg[k - 1][threadIdx.x] = change; /* reduced once, after the last sweep (a block reduction per
                                                sweep cost more than the sweep itself) */
         lds_barrier(); /* publishes nxt; the snapshot stores below stay in flight */
+        STAMP(6, 2); /* run-up + own element */
         float (*t)[SM_M] = cur; cur = nxt; nxt = t;
         /* snapshot of level k (owned range; the last level is the next launch's input) */
         for (int j = 0; j < 3; ++j) {
             float *D = snap + smooth_snap_off(b & 1, k, j, W_cap);
             for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) D[g] = cur[j][g - base];
         }
+        STAMP(6, 3); /* snapshot stores */
     }
     /* per-sweep sums of this tile, fixed summation order: one wave per sweep */
     {
@@ -1848,6 +1855,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
             if (lane == 0) part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
         }
     }
+    STAMP(6, 4); /* per-sweep sums */
 }
 
 /* ------------------------------------------------------------------ */
