@@ -102,6 +102,15 @@ int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_b
 /* same, the buffer already lives on this handle's device */
 int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
 int ppp_num_points(ppp_handle h, size_t *n);
+/* the resident cloud (after the x1000 and any preprocessing) as n x 3 packed floats in index order */
+int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n);
+
+/* ---- preprocessing of the constructors, on the resident cloud ---- */
+/* SectPath::remove_outlier() (path_slicing_alg.cpp:101-108): pcl::StatisticalOutlierRemoval, setMeanK(mean_k = 50),
+ * setStddevMulThresh(stddev_mul = 1.0), sor.filter(*cloud): the filtered cloud replaces the resident one (same order,
+ * new indices), the plan is rebuilt.  n_kept / threshold (mean + mul * stddev of the per-point mean neighbour
+ * distances) are optional outputs.  mean_k <= 63. */
+int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_kept, double *threshold);
 
 /* ---- whole hot path, asynchronous on the handle's stream ---- */
 /* GenPath(): getMinMax3D + slice walk + rangedX_index + insert_point + Spline for every

@@ -80,6 +80,13 @@ public:
         loaded_ = true;
         return true;
     }
+    bool remove_outlier(int mean_k, double stddev_mul)
+    {
+        if (!ok()) return false;
+        size_t n = 0;
+        int rc = ppp_remove_outlier(h_, mean_k, stddev_mul, &n, nullptr);
+        return rc == PPP_OK ? true : report(rc);
+    }
     bool apply_params()
     {
         int rc = ppp_set_params(h_, &cfg_.params);

@@ -70,6 +70,7 @@ def lib():
         L.ppo_num_points.restype = C.c_size_t
         L.ppo_num_points.argtypes = [vp]
         L.ppo_get_points.argtypes = [vp, fp]
+        L.ppo_remove_outlier.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_double), fp]
         L.ppo_minmax.argtypes = [vp, fp, fp]
         L.ppo_slice_positions.argtypes = [vp, fp, C.c_int]
         L.ppo_ranged_x_index.argtypes = [vp, C.c_int, ip, C.c_int]
@@ -265,6 +266,19 @@ class Oracle:
         out = np.empty(4, np.float32)
         self.L.ppo_normal_at(self.h, int(idx), _f(out))
         return out
+
+    def num_points(self):
+        return int(self.L.ppo_num_points(self.h))
+
+    def remove_outlier(self, mean_k=50, std_mul=1.0):
+        """SectPath::remove_outlier; returns (new size, threshold, mean distances of the original points)"""
+        n0 = self.num_points()
+        thr = C.c_double()
+        dist = np.zeros(max(n0, 1), np.float32)
+        rc = self.L.ppo_remove_outlier(self.h, int(mean_k), float(std_mul), C.byref(thr), _f(dist))
+        if rc >= 0:
+            self.n = rc
+        return rc, thr.value, dist[:n0]
 
     def knn(self, q, k):
         q = np.ascontiguousarray(q, np.float32)

@@ -1001,6 +1001,47 @@ struct ppo_handle {
         return 0; /* SectPath::GenPath and slicing_method have no adjustment */
     }
 
+    /* SectPath::remove_outlier (path_slicing_alg.cpp:101-108): pcl::StatisticalOutlierRemoval, setMeanK(50),
+       setStddevMulThresh(1.0), filter(*cloud) -- PCL 1.12 filters/impl/statistical_outlier_removal.hpp, applyFilterIndices.
+       Returns the new size, or -1 where PCL reads past its neighbour vectors (fewer than mean_k + 1 finite points). */
+    int remove_outlier(int mean_k, double std_mul)
+    {
+        rebuild_tree();
+        const size_t n = cloud.size();
+        std::vector<float> distances(n, 0.f);
+        int valid = 0;
+        std::vector<std::pair<float, int>> nb;
+        for (size_t i = 0; i < n; ++i) {
+            const Pt &q = cloud[i];
+            if (!std::isfinite(q.x) || !std::isfinite(q.y) || !std::isfinite(q.z)) { distances[i] = 0.f; continue; }
+            tree.knn(&q.x, mean_k + 1, nb);
+            if ((int)nb.size() < mean_k + 1) return -1;
+            double dist_sum = 0.0;
+            for (int k = 1; k < mean_k + 1; ++k) dist_sum += std::sqrt(nb[k].first); /* float sqrt, double sum */
+            distances[i] = static_cast<float>(dist_sum / mean_k);
+            valid++;
+        }
+        double sum = 0, sq_sum = 0;
+        for (const float &distance : distances) { sum += distance; sq_sum += distance * distance; } /* float product */
+        double mean = sum / static_cast<double>(valid);
+        double variance = (sq_sum - sum * sum / static_cast<double>(valid)) / (static_cast<double>(valid) - 1);
+        double stddev = std::sqrt(variance);
+        double distance_threshold = mean + std_mul * stddev;
+        std::vector<Pt> kept;
+        kept.reserve(n);
+        for (size_t i = 0; i < n; ++i)
+            if (!(distances[i] > distance_threshold)) kept.push_back(cloud[i]); /* non-finite points carry 0 and stay */
+        sor_threshold = distance_threshold;
+        sor_distances.swap(distances);
+        cloud.swap(kept);
+        tree_built = false;
+        normals.clear(); normal_done.clear();
+        path_set.clear(); slice_idx.clear();
+        return (int)cloud.size();
+    }
+    double sor_threshold = 0;
+    std::vector<float> sor_distances;
+
     int gen_path()
     {
         path_set.clear();
@@ -1208,6 +1249,17 @@ void ppo_estimate_normals(ppo_handle *h, float *n4)
     memcpy(n4, h->normals.data(), h->normals.size() * sizeof(float));
 }
 void ppo_normal_at(ppo_handle *h, int idx, float n4[4]) { h->point_normal(idx, n4); }
+int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *threshold, float *distances)
+{
+    const size_t n0 = h->cloud.size();
+    int rc = h->remove_outlier(mean_k, std_mul);
+    if (rc >= 0) {
+        if (threshold) *threshold = h->sor_threshold;
+        if (distances) memcpy(distances, h->sor_distances.data(), n0 * sizeof(float));
+    }
+    return rc;
+}
+
 int ppo_knn(ppo_handle *h, const float q[3], int k, int *out)
 {
     h->ensure_tree();

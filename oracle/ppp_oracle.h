@@ -106,6 +106,9 @@ int  ppo_rpy_oob(const ppo_handle *h);                            /* B.6 hazard 
 /* whole-cloud normal estimation (a10), nx ny nz curvature per point */
 void ppo_estimate_normals(ppo_handle *h, float *n4);
 void ppo_normal_at(ppo_handle *h, int idx, float n4[4]);
+/* SectPath::remove_outlier (path_slicing_alg.cpp:101-108; pcl::StatisticalOutlierRemoval): replaces the cloud, returns
+   the new size (or -1); threshold / distances (one float per ORIGINAL point) are optional outputs for the tests */
+int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *threshold, float *distances);
 /* dynamic adjustment building blocks (for the cross-check tests) */
 /* kdtree.nearestKSearch(q, k): ascending distance; returns the count */
 int ppo_knn(ppo_handle *h, const float q[3], int k, int *out);

@@ -8,7 +8,7 @@
  * There is no CPU fallback: without a HIP device every entry point fails loudly.
  */
 #include "ppp_kernels.h"
-#include "ppp_dynamic.h"
+#include "ppp_preproc.h"
 #include "../../include/ppp_hip.h"
 
 #include <algorithm>
@@ -544,19 +544,10 @@ int slice_lds_ok(ppp_handle h, int capb)
     return std::max(slice_lds_bytes(capb), slice_kd_bytes(capb)) + 1024 <= (size_t)h->max_lds;
 }
 
-int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+/* cache the bounds of the resident cloud for the plan (sizing only; the hot path recomputes them on device), then plan */
+int refresh_bounds_and_plan(ppp_handle h)
 {
-    if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
-    h->n = n;
-    if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
-    HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
-    if (n) {
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, raw_dev, stride_bytes, (int)n,
-                           h->P.change_range, h->X.p, h->Y.p, h->Z.p);
-        HIPCHK(h, hipGetLastError());
-    }
-    /* cache the bounds for the plan (sizing only; the hot path recomputes them on device) */
+    const size_t n = h->n;
     {
         int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
         HIPCHK(h, h->mm_part.ensure(g));
@@ -577,8 +568,25 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     }
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->normals_valid = false;
     return make_plan(h);
 }
+
+int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+{
+    if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
+    h->n = n;
+    if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
+    HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
+    if (n) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, raw_dev, stride_bytes, (int)n,
+                           h->P.change_range, h->X.p, h->Y.p, h->Z.p);
+        HIPCHK(h, hipGetLastError());
+    }
+    return refresh_bounds_and_plan(h);
+}
+
 
 } // namespace
 
@@ -679,6 +687,88 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
+}
+
+int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_kept, double *threshold)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (mean_k < 1 || mean_k > 63) return fail(h, PPP_ERR_ARG, "mean_k must be in [1, 63]");
+    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    if (overflowed_fast_path(h)) { h->big_path = true; h->drop_graph(); HIPCHK(h, h->arena.ensure((size_t)64 * std::max<size_t>(h->n, 1) + (1u << 20))); rc = enqueue_index(h); if (rc) return rc; rc = fetch_meta(h); if (rc) return rc; }
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    const int n = (int)h->n, ns = h->hmeta.n_sorted;
+    if (ns < mean_k + 1) return fail(h, PPP_ERR_ARG, "fewer finite points than mean_k + 1 (PCL reads past its neighbour vectors here)");
+    /* first radius of the k-NN gather: mean_k + 1 points of a sheet of the cloud's mean areal density, +25 % */
+    const double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
+    const double rho = (area > 0 && h->h_nvalid > 0) ? (double)h->h_nvalid / area : 1.0;
+    const float r0 = (float)std::max(0.5, 1.25 * std::sqrt((double)(mean_k + 1) / (3.14159265358979 * rho)));
+    const int nblocks = (n + SOR_CHUNK - 1) / SOR_CHUNK, nparts = std::max(1, std::min(1024, (n + 255) / 256));
+    DevBuf<float> dist, X2, Y2, Z2;
+    DevBuf<double> part;
+    DevBuf<int> bcnt;
+    DevBuf<SorStats> st;
+    auto cleanup = [&]() { dist.release(); X2.release(); Y2.release(); Z2.release(); part.release(); bcnt.release(); st.release(); };
+    hipError_t e = dist.ensure(n);
+    if (e == hipSuccess) e = X2.ensure(n);
+    if (e == hipSuccess) e = Y2.ensure(n);
+    if (e == hipSuccess) e = Z2.ensure(n);
+    if (e == hipSuccess) e = part.ensure(2 * (size_t)nparts);
+    if (e == hipSuccess) e = bcnt.ensure(nblocks);
+    if (e == hipSuccess) e = st.ensure(1);
+    if (e != hipSuccess) { cleanup(); return fail(h, PPP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    SorStats hst;
+    auto run = [&]() -> int {
+        HIPCHK(h, hipMemsetAsync(dist.p, 0, sizeof(float) * (size_t)n, h->stream)); /* non-finite points: distance 0 */
+        LAUNCH(h, "k_sor_dist", k_sor_dist, (unsigned)((ns + DYN_WAVES - 1) / DYN_WAVES), 64 * DYN_WAVES, 0, h->meta.p, h->sorted4.p, h->slab_start.p,
+               h->slab_xmin.p, h->slab_xmax.p, mean_k, r0, dist.p);
+        LAUNCH(h, "k_sor_partial", k_sor_partial, nparts, 256, 0, dist.p, n, part.p);
+        LAUNCH(h, "k_sor_threshold", k_sor_threshold, 1, 256, 0, h->meta.p, part.p, nparts, stddev_mul, st.p);
+        LAUNCH(h, "k_sor_count", k_sor_count, nblocks, 256, 0, dist.p, n, st.p, bcnt.p);
+        LAUNCH(h, "k_sor_scan", k_sor_scan, 1, 1024, 0, bcnt.p, nblocks, st.p);
+        LAUNCH(h, "k_sor_compact", k_sor_compact, nblocks, 256, 0, dist.p, n, st.p, bcnt.p, h->X.p, h->Y.p, h->Z.p, X2.p, Y2.p, Z2.p);
+        HIPCHK(h, hipMemcpyAsync(&hst, st.p, sizeof(SorStats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    rc = run();
+    if (rc == PPP_OK) { h->meta_in_flight = false; rc = fetch_meta(h); }
+    if (rc == PPP_OK) rc = map_dev_err(h);
+    if (rc != PPP_OK) { cleanup(); return rc; }
+    /* the filtered cloud replaces the resident one (sor.filter(*cloud)) */
+    std::swap(h->X, X2); std::swap(h->Y, Y2); std::swap(h->Z, Z2);
+    h->n = (size_t)hst.n_kept;
+    if (n_kept) *n_kept = h->n;
+    if (threshold) *threshold = hst.threshold;
+    cleanup();
+    h->drop_graph();
+    return refresh_bounds_and_plan(h);
+}
+
+int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (n) *n = h->n;
+    const size_t k = std::min(cap, h->n);
+    if (xyz && k) {
+        std::vector<float> t(3 * k);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(t.data(), h->X.p, 4 * k, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(t.data() + k, h->Y.p, 4 * k, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(t.data() + 2 * k, h->Z.p, 4 * k, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < k; ++i) { xyz[3 * i] = t[i]; xyz[3 * i + 1] = t[k + i]; xyz[3 * i + 2] = t[2 * k + i]; }
+    }
+    return PPP_OK;
 }
 
 int ppp_num_points(ppp_handle h, size_t *n)

@@ -290,21 +290,27 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize("dynamic", [0, 1])
-def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic):
+@pytest.mark.parametrize("dynamic,remove", [(0, 0), (1, 0), (0, 1)])
+def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remove):
     """The drop-in C++ classes (include/Path_Generate_Algorithm.h) driven like src/connect.cpp:
-    PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13)."""
+    PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13) and RemoveOutlier (config.txt:11)."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "connect1", "main"], stdout=subprocess.DEVNULL)
     pts, cfg = synth.make_config("small_40k")
+    if remove:   # a few points floating above the sheet
+        rng = np.random.default_rng(9)
+        fly = pts[rng.integers(0, len(pts), 30)].copy()
+        fly[:, 2] += rng.uniform(0.005, 0.03, 30).astype(np.float32)
+        pts = np.concatenate([pts, fly])
     pcd = str(tmp_path / "workpiece.pcd")
-    engine_mod.save_pcd(pcd, pts, binary=True)
+    engine_mod.save_pcd(pcd, pts, binary="compressed" if remove else True)
     out = str(tmp_path / "WayPoints.txt")
     conf = tmp_path / "config.txt"
     conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
-                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = %s\n"
-                    "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n" % (out, "true" if dynamic else "false"))
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = %s\nDynamic_adjustment = %s\n"
+                    "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n"
+                    % (out, "true" if remove else "false", "true" if dynamic else "false"))
     env = dict(os.environ, PPP_CONFIG=str(conf))
     for exe, walk in (("connect", 1), ("connect1", 2)):
         if os.path.exists(out):
@@ -314,6 +320,8 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic):
         assert "!!!!! GOT PATH !!!!!" in r.stdout
         got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
         o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk, dynamic_adjustment=dynamic)
+        if remove:
+            assert o.remove_outlier(50, 1.0)[0] < len(pts)
         o.gen_path(); o.get_path()
         want = o.waypoints()
         assert got.shape == want.shape
@@ -617,3 +625,22 @@ def test_randomised_sweep_against_the_oracle(engine_mod, oracle_mod):
         if res is not None and not res.startswith("both fail"):
             bad.append((desc, res))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["small_40k", "tiny_5k"])
+def test_remove_outlier_matches_the_oracle(engine_mod, oracle_mod, name):
+    """SectPath::remove_outlier (RemoveOutlier = true): same threshold, identical filtered cloud, same path afterwards."""
+    pts, cfg = synth.make_config(name)
+    rng = np.random.default_rng(4)
+    out = pts[rng.integers(0, len(pts), 60)].copy()
+    out[:, 2] += rng.uniform(0.004, 0.03, 60).astype(np.float32)
+    pts = np.concatenate([pts, out])[rng.permutation(len(pts) + 60)]
+    pts[7] = np.nan
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    n_o, thr_o, _ = o.remove_outlier(50, 1.0)
+    n_e, thr_e = e.remove_outlier(50, 1.0)
+    assert n_e == n_o < len(pts) and abs(thr_e - thr_o) <= 1e-9 * thr_o
+    assert np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(o.points()))
+    assert_full_parity(engine_mod, e, o)

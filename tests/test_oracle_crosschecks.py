@@ -153,6 +153,34 @@ def test_kdtree_leaves_non_finite_points_out(oracle_mod):
         assert np.array_equal(o.knn(qi, 10), np.lexsort((np.arange(len(d)), d))[:10])
 
 
+def test_remove_outlier_matches_a_scipy_restatement(oracle_mod):
+    """pcl::StatisticalOutlierRemoval (SectPath::remove_outlier): mean distance to the 50 nearest neighbours, threshold
+    mean + 1 sigma over the cloud, non-finite points stay."""
+    from polishpathplanning_amd import synth
+    pts = synth.make_plate(150, 60, kind="wavy", amp=10, seed=3)
+    rng = np.random.default_rng(0)
+    out = pts[rng.integers(0, len(pts), 40)].copy()
+    out[:, 2] += rng.uniform(0.004, 0.03, 40).astype(np.float32)      # 4 .. 30 mm above the sheet
+    pts = np.concatenate([pts, out])
+    pts[5] = np.nan
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    P = o.points()
+    n2, thr, dist = o.remove_outlier(50, 1.0)
+    fin = np.isfinite(P).all(axis=1)
+    d, _ = cKDTree(P[fin].astype(np.float64)).query(P[fin].astype(np.float64), k=51)
+    md = np.zeros(len(P))
+    md[fin] = np.sqrt((d[:, 1:] ** 2).astype(np.float32)).astype(np.float64).mean(axis=1)
+    valid = fin.sum()
+    mean = md.sum() / valid
+    var = ((md ** 2).sum() - md.sum() ** 2 / valid) / (valid - 1)
+    thr2 = mean + np.sqrt(var)
+    assert abs(thr - thr2) < 1e-6 and np.abs(md[fin] - dist[fin]).max() < 1e-5
+    keep = ~(md.astype(np.float32) > thr2)
+    assert n2 == keep.sum() and not keep[-40:].any() and keep[5]       # every planted outlier goes, the NaN point stays
+    assert np.array_equal(np.nan_to_num(o.points()), np.nan_to_num(P[keep]))
+    assert o.gen_path() > 5                                            # and the planner runs on the filtered cloud
+
+
 # ---------------- A.4: normals vs numpy eigh -----------------
 def test_normals_match_eigh(small):
     pts, o = small
