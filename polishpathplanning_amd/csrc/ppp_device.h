@@ -193,29 +193,6 @@ __device__ inline int block_exscan(int v, int *scratch, int *total)
     return pre;
 }
 
-/* In-place bitonic sort of P (power of two) 64-bit keys in LDS, ascending.
-   Optional u16 payload array swapped alongside. */
-template <bool PAYLOAD>
-__device__ inline void bitonic_lds(u64 *k, u16 *pl, int P)
-{
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
-                int lo = 2 * t - (t & (stride - 1));
-                int hi = lo + stride;
-                bool up = ((lo & size) == 0);
-                u64 a = k[lo], b = k[hi];
-                if ((a > b) == up) {
-                    k[lo] = b; k[hi] = a;
-                    if (PAYLOAD) { u16 pa = pl[lo]; pl[lo] = pl[hi]; pl[hi] = pa; }
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
 /* ---------------------------------------------------------------------- */
 /* Block sort of 256*E 64-bit keys held in registers (blocked layout: thread */
 /* t owns elements t*E .. t*E+E-1), ascending, for a 256-thread workgroup.   */
@@ -319,7 +296,7 @@ __device__ inline void block_sort_lds(u64 *keys, int n)
 }
 
 /* ---------------------------------------------------------------------- */
-/* Exact LDS bucket sort for a 256-thread workgroup: n <= 4096 keys.         */
+/* Exact LDS bucket sort for one workgroup (<= 1024 threads): n <= 4096 keys. */
 /*   gen(i)      -> the i-th key (recomputed in both passes, so no copy)     */
 /*   bucket(key) -> [0, NB), monotone non-decreasing in the sort order       */
 /*   less(a, b)  -> strict weak order (refines the bucket order)             */
