@@ -55,3 +55,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "ppp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/ppp_hip.h must compile as C (what cgo / a JNI stub / ctypesgen would see)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "ppp_hip.h"\nint main(void) { ppp_params p; ppp_config c; ppp_default_params(&p); ppp_default_config(&c); return 0; }\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
