@@ -100,38 +100,51 @@ def main():
         e.gen_path()
         w_all.append(e.get_path())
     # the batch is fixed, so is every rank's waypoint count: exchanged once; the engines write straight into the
-    # gatherer's send buffer, so a step's exchange is one collective and no copy
+    # gatherer's send buffer, so a step's exchange is one collective and no copy.  N > 1 uses TWO gatherers: the
+    # RCCL gather of step k-1 runs (on the framework's stream) while the planner works on step k (on its own stream).
     from polishpathplanning_amd.robot_path import RobotPathGatherer
-    gatherer = RobotPathGatherer(sum(w_all), dist if world > 1 else None, dev)
-    send = gatherer.send
-
+    pipelined = world > 1 or os.environ.get("PPP_BENCH_FORCE_PIPELINE") == "1"
+    gatherers = [RobotPathGatherer(sum(w_all), dist if world > 1 else None, dev) for _ in range(2 if pipelined else 1)]
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
+    w_step = int(sum(w_all))
 
-    def step():
+    def plan(k):
         # GenPath + getPath of every workpiece of this rank as ONE hipGraph launch (a branch per workpiece); every
-        # branch ends by copying its WayPointsList to its place in the gather buffer, so the host waits once.
-        # (Ordering the gather behind the planner on the GPU -- ppp_get_stream + torch wait_stream -- was measured:
-        # two event hand-offs through the framework cost more than this one host wait.)
-        engine.run_batch_async(engines, send.data_ptr(), offs, w_all)
-        engine.sync_batch(engines)
-        w = int(sum(w_all))
-        blocks = gatherer.gather()
-        return w, blocks
+        # branch ends by writing its WayPointsList to its place in the gather buffer
+        engine.run_batch_async(engines, gatherers[k % len(gatherers)].send.data_ptr(), offs, w_all)
+
+    def run_steps(count):
+        """`count` full steps: every step's robot path is planned and gathered on rank 0 before this returns"""
+        blocks = None
+        if not pipelined:
+            for k in range(count):
+                plan(k)
+                engine.sync_batch(engines)          # one host wait per step
+                blocks = gatherers[0].gather()
+            return blocks
+        for k in range(count):
+            plan(k)                                  # step k on the planner's stream ...
+            if k > 0:
+                blocks = gatherers[(k - 1) % 2].gather()   # ... while step k-1 is gathered
+            engine.sync_batch(engines)               # step k planned
+            torch.cuda.current_stream().synchronize()  # gather k-1 done: its send buffer is free for step k+1
+        if count > 0:
+            blocks = gatherers[(count - 1) % 2].gather()
+            torch.cuda.current_stream().synchronize()
+        return blocks
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    w_local = 0
-    for _ in range(args.steps):
-        w_local, blocks = step()
+    blocks = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    w_local = w_step
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ww = torch.tensor([float(w_local)], dtype=torch.float64, device=dev)

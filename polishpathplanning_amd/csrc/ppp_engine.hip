@@ -104,7 +104,9 @@ struct ppp_handle_s {
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
     hipStream_t pending_stream = nullptr; /* a batch graph launched on another handle's stream carries this handle's work */
-    struct BatchGraph *batch = nullptr;   /* cached batch graph (lead handle only) */
+    struct BatchGraph *batches[2] = {nullptr, nullptr}; /* cached batch graphs (lead handle only): two, so a caller can
+                                                           alternate between two destination buffers (double buffering) */
+    int batch_next = 0;                                 /* slot the next new graph replaces */
     bool timing = false;
     std::vector<KTimer> timers;
 
@@ -151,7 +153,10 @@ struct BatchGraph {
         for (auto e : join) if (e) (void)hipEventDestroy(e);
     }
 };
-void ppp_handle_s::drop_batch() { delete batch; batch = nullptr; }
+void ppp_handle_s::drop_batch()
+{
+    for (auto &b : batches) { delete b; b = nullptr; }
+}
 
 namespace {
 
@@ -928,14 +933,21 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         }
         return PPP_OK;
     }
-    BatchGraph *bg = lead->batch;
-    bool fresh = bg && bg->hs.size() == count && bg->dst == dst_dev;
-    for (size_t i = 0; fresh && i < count; ++i)
-        fresh = bg->hs[i] == hs[i] && bg->epochs[i] == hs[i]->epoch && (!dst_dev || (bg->off[i] == offset_rows[i] && bg->cap[i] == cap_rows[i]));
+    BatchGraph *bg = nullptr;
+    for (BatchGraph *cand : lead->batches) {
+        bool same = cand && cand->hs.size() == count && cand->dst == dst_dev;
+        for (size_t i = 0; same && i < count; ++i)
+            same = cand->hs[i] == hs[i] && cand->epochs[i] == hs[i]->epoch && (!dst_dev || (cand->off[i] == offset_rows[i] && cand->cap[i] == cap_rows[i]));
+        if (same) { bg = cand; break; }
+    }
+    const bool fresh = bg != nullptr;
+    int slot = -1;
     if (!fresh) {
-        lead->drop_batch();
+        slot = lead->batch_next;
+        lead->batch_next ^= 1;
+        delete lead->batches[slot];
         bg = new BatchGraph();
-        lead->batch = bg;
+        lead->batches[slot] = bg;
         bg->hs.assign(hs, hs + count);
         bg->dst = dst_dev;
         if (dst_dev) { bg->off.assign(offset_rows, offset_rows + count); bg->cap.assign(cap_rows, cap_rows + count); }
@@ -971,13 +983,13 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         hipError_t e2 = hipStreamEndCapture(lead->stream, &g);
         if (rc != PPP_OK || e != hipSuccess || e2 != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
-            lead->drop_batch();
+            delete lead->batches[slot]; lead->batches[slot] = nullptr;
             if (rc != PPP_OK) return rc;
             return fail(lead, PPP_ERR_HIP, std::string("batch capture (") + where + "): " + hipGetErrorString(e != hipSuccess ? e : e2));
         }
         bg->g = g;
         e = hipGraphInstantiate(&bg->ge, bg->g, nullptr, nullptr, 0);
-        if (e != hipSuccess) { lead->drop_batch(); return fail(lead, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { delete lead->batches[slot]; lead->batches[slot] = nullptr; return fail(lead, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         bg->epochs.resize(count);
         for (size_t i = 0; i < count; ++i) bg->epochs[i] = hs[i]->epoch;
     }

@@ -596,6 +596,12 @@ def test_run_batch_graph_matches_single_handles(engine_mod):
     assert got.tobytes() == np.concatenate(want).tobytes()
     for e, w in zip(engines, want):
         assert e.waypoints().tobytes() == w.tobytes()
+    # double buffering: two destinations in turn (each keeps its own cached graph)
+    buf2 = _DeviceBuffer(sum(ws) * 24)
+    for k in range(4):
+        engine_mod.run_batch_async(engines, (buf if k % 2 == 0 else buf2).ptr, offs, ws)
+        engine_mod.sync_batch(engines)
+    assert buf2.to_host(sum(ws) * 6).tobytes() == np.concatenate(want).tobytes()
     # a destination slot that is too small is that handle's error, not silent truncation
     caps = list(ws); caps[2] -= 1
     engine_mod.run_batch_async(engines, buf.ptr, offs, caps)
