@@ -650,3 +650,37 @@ def test_remove_outlier_matches_the_oracle(engine_mod, oracle_mod, name):
     assert n_e == n_o < len(pts) and abs(thr_e - thr_o) <= 1e-9 * thr_o
     assert np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(o.points()))
     assert_full_parity(engine_mod, e, o)
+
+
+def test_distinct_handles_from_concurrent_host_threads(engine_mod):
+    """thread-compatible -- distinct handles may be driven from different host threads at once
+    (own stream, own graph capture in thread-local mode, no globals)."""
+    import threading
+    kinds = [("small_40k", 11), ("tiny_5k", 12), ("small_40k", 13), ("tiny_5k", 14)]
+    clouds = [synth.make_config(n, seed=s)[0] for n, s in kinds]
+    want = []
+    for pts in clouds:
+        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path(); e.get_path()
+        want.append(e.waypoints().tobytes())
+    errors = []
+
+    def worker(i):
+        try:
+            e = engine_mod.Engine(0, tool_radius=6.0)
+            e.set_cloud(clouds[i])
+            for rep in range(8):
+                if rep % 2:
+                    e.run_async(); e.sync()
+                else:
+                    e.gen_path(); e.get_path()
+                if e.waypoints().tobytes() != want[i]:
+                    errors.append((i, rep, "list differs"))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(clouds))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
