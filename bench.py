@@ -102,7 +102,7 @@ def main():
     # the batch is fixed, so is every rank's waypoint count: exchanged once; the engines write straight into the
     # gatherer's send buffer, so a step's exchange is one collective and no copy.  N > 1 uses TWO gatherers: the
     # RCCL gather of step k-1 runs (on the framework's stream) while the planner works on step k (on its own stream).
-    from polishpathplanning_amd.robot_path import RobotPathGatherer
+    from polishpathplanning_amd.robot_path import RobotPathGatherer, run_pipelined_steps
     pipelined = world > 1 or os.environ.get("PPP_BENCH_FORCE_PIPELINE") == "1"
     gatherers = [RobotPathGatherer(sum(w_all), dist if world > 1 else None, dev) for _ in range(2 if pipelined else 1)]
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
@@ -122,16 +122,9 @@ def main():
                 engine.sync_batch(engines)          # one host wait per step
                 blocks = gatherers[0].gather()
             return blocks
-        for k in range(count):
-            plan(k)                                  # step k on the planner's stream ...
-            if k > 0:
-                blocks = gatherers[(k - 1) % 2].gather()   # ... while step k-1 is gathered
-            engine.sync_batch(engines)               # step k planned
-            torch.cuda.current_stream().synchronize()  # gather k-1 done: its send buffer is free for step k+1
-        if count > 0:
-            blocks = gatherers[(count - 1) % 2].gather()
-            torch.cuda.current_stream().synchronize()
-        return blocks
+        # step k on the planner's stream while step k-1 is gathered on the framework's stream
+        return run_pipelined_steps(count, plan, lambda: engine.sync_batch(engines), gatherers,
+                                   lambda: torch.cuda.current_stream().synchronize())
 
     def fence():
         if world > 1:

@@ -79,6 +79,34 @@ class RobotPathGatherer:
         return [self.recv[r * self.wmax: r * self.wmax + self.counts[r]] for r in range(self.world)]
 
 
+def run_pipelined_steps(count, plan, wait_planned, gatherers, wait_gathered, on_blocks=None):
+    """`count` plan+gather steps with the gather of step k-1 overlapping the planning of step k.
+
+    plan(k)          enqueues step k's planning; its lists land in gatherers[k % 2].send   (asynchronous)
+    wait_planned()   host waits until the last plan() has finished
+    wait_gathered()  host waits until the collectives enqueued so far have finished (their send buffer is free again)
+    on_blocks(k, b)  optional: called on every rank with step k's gathered blocks (None off rank 0)
+
+    Two gatherers = two send/receive buffer pairs, so step k+1 may overwrite the buffer of step k-1 only after
+    wait_gathered().  Every step is planned AND gathered before this returns.  Returns the last step's blocks."""
+    assert len(gatherers) == 2
+    blocks = None
+    for k in range(count):
+        plan(k)
+        if k > 0:
+            blocks = gatherers[(k - 1) % 2].gather()
+            if on_blocks:
+                on_blocks(k - 1, blocks)
+        wait_planned()
+        wait_gathered()
+    if count > 0:
+        blocks = gatherers[(count - 1) % 2].gather()
+        if on_blocks:
+            on_blocks(count - 1, blocks)
+        wait_gathered()
+    return blocks
+
+
 def slice_ranges(num_slices, world):
     """SURVEY.md 8e case (ii): GPU g plans the slices [g*S/world, (g+1)*S/world) of ONE cloud."""
     return [(g * num_slices // world, (g + 1) * num_slices // world) for g in range(world)]

@@ -144,6 +144,63 @@ def test_slice_range_gather_world2_gloo():
     assert np.array_equal(pre[:, 0], want) and pre.shape == (per_slice.sum(), 6)
 
 
+def _pipeline_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from polishpathplanning_amd.robot_path import RobotPathGatherer, run_pipelined_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = 4 + 5 * rank                                     # ragged: rank 0 has 4 waypoints, rank 1 has 9
+    gatherers = [RobotPathGatherer(w, dist, torch.device("cpu")) for _ in range(2)]
+    seen = []
+
+    def plan(k):                                         # "planner": step k's list = 100 k + 1000 rank + row
+        g = gatherers[k % 2]
+        g.send[:w] = (torch.arange(w, dtype=torch.float32)[:, None] + 100.0 * k + 1000.0 * rank).expand(w, 6)
+
+    def on_blocks(k, blocks):
+        if rank == 0:
+            seen.append((k, [b.clone() for b in blocks]))
+        else:
+            assert blocks is None
+
+    for count in (0, 1, 2, 5):
+        del seen[:]
+        last = run_pipelined_steps(count, plan, lambda: None, gatherers, lambda: None, on_blocks)
+        if rank == 0:
+            assert [k for k, _ in seen] == list(range(count))
+            for k, blocks in seen:
+                assert [b.shape[0] for b in blocks] == [4, 9]
+                for r, b in enumerate(blocks):
+                    want = (torch.arange(b.shape[0], dtype=torch.float32)[:, None] + 100.0 * k + 1000.0 * r).expand(-1, 6)
+                    assert torch.equal(b, want), (count, k, r)
+            assert (last is None) == (count == 0)
+        else:
+            assert last is None
+    if rank == 0:
+        q.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_steps_world2_gloo():
+    """bench.py's N > 1 loop: the gather of step k-1 overlaps the planning of step k over two buffer pairs; every
+    step's blocks arrive intact and in order, for 0, 1, 2 and 5 steps."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) == "ok"
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+
 def test_gather_without_process_group():
     import torch
     from polishpathplanning_amd.robot_path import gather_robot_path
