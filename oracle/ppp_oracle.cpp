@@ -302,9 +302,13 @@ void compute_roots(const float m[3][3], float roots[3])
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.f) q = 0.f;
     float rho = std::sqrt(-a_over_3);
-    float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
-    float cos_theta = std::cos(theta);
-    float sin_theta = std::sin(theta);
+    /* std::atan2 / std::cos / std::sin on floats (pcl/common/impl/eigen.hpp computeRoots).  Evaluated in double and
+       rounded: the correctly rounded float results, which any libm's float functions return or miss by one ulp; the
+       product does the same, so the eigen-decompositions (normals, principal curvatures) agree bit for bit and the
+       discontinuous decisions of the dynamic adjustment built on them do not flip between oracle and GPU. */
+    float theta = (float)std::atan2((double)std::sqrt(-q), (double)half_b) * s_inv3;
+    float cos_theta = (float)std::cos((double)theta);
+    float sin_theta = (float)std::sin((double)theta);
     roots[0] = c2_over_3 + 2.f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

@@ -382,9 +382,11 @@ __device__ inline void pcl_roots(const float m[3][3], float roots[3])
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.f) q = 0.f;
     float rho = sqrtf(-a_over_3);
-    float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-    float cos_theta = cosf(theta);
-    float sin_theta = sinf(theta);
+    /* correctly rounded float results through double (see the oracle's computeRoots): device and host libm float
+       functions differ by an ulp now and then, their double functions rounded to float do not */
+    float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+    float cos_theta = (float)cos((double)theta);
+    float sin_theta = (float)sin((double)theta);
     roots[0] = c2_over_3 + 2.f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

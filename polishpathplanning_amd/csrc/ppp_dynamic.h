@@ -152,13 +152,25 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
                         m2 = (i == 2 ? 1.f : 0.f) - n0[i] * n0[2];
             proj[i] = m0 * nn[0] + m1 * nn[1] + m2 * nn[2];
         }
-    float cen[3];
-    for (int i = 0; i < 3; ++i) cen[i] = wave_sum(proj[i]) / (float)kk;
+    /* centroid and covariance of the projected normals: summed neighbour by neighbour in rank order, as the reference's
+       loops do (a tree reduction gives other last bits, and the ellipse extremum below is a discontinuous function of
+       them) -- every lane runs the same sequential sums on values broadcast from lane r */
+    auto lane_value = [](float v, int r) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); }; /* r is wave-uniform */
+    /* lanes >= kk hold zeros: adding them is exact, so the loops run all 64 ranks without a branch */
+    float cen[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+        for (int i = 0; i < 3; ++i) cen[i] += lane_value(proj[i], r);
+    for (int i = 0; i < 3; ++i) cen[i] /= (float)kk;
     float d[3] = {0.f, 0.f, 0.f};
     if (lane < kk) for (int i = 0; i < 3; ++i) d[i] = proj[i] - cen[i];
-    float cov[9];
-    cov[0] = wave_sum(d[0] * d[0]); cov[1] = wave_sum(d[0] * d[1]); cov[2] = wave_sum(d[0] * d[2]);
-    cov[4] = wave_sum(d[1] * d[1]); cov[5] = wave_sum(d[1] * d[2]); cov[8] = wave_sum(d[2] * d[2]);
+    float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const float dx = lane_value(d[0], r), dy = lane_value(d[1], r), dz = lane_value(d[2], r);
+        cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
+        cov[4] += dy * dy; cov[5] += dy * dz; cov[8] += dz * dz;
+    }
     cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
     /* pcl::eigen33(mat, evals) + computeCorrespondingEigenVector(mat, evals[2]) */
     float scale = 0.f;

@@ -1233,57 +1233,95 @@ __device__ inline int nearest_in_slabs(const SlabView &V, float qx, float qy, fl
 
 /* pcl::NormalEstimation::computeFeature for one cloud point p:
    radius search, computeMeanAndCovarianceMatrix shifted by the nearest neighbour (p itself),
-   eigen33, flipNormalTowardsViewpoint. */
+   eigen33, flipNormalTowardsViewpoint.
+   The neighbours are summed in the order the radius search returns them -- ascending (distance, cloud index) -- so the
+   float covariance, and with it the normal, carries the same bits as the reference's; the principal curvatures of the
+   dynamic adjustment are built on this field and feed discontinuous decisions.  (k_pose's per-waypoint normals use
+   the faster slab-order sum of normal_at_point_group: they only feed continuous outputs.) */
+#define NRM_CAP 48
 __device__ inline void normal_at_point(const SlabView &V, const float4 p, float radius, const float vp[3], float out[4])
 {
     const int B = V.m->B;
     const float r2 = radius * radius;
-    float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int cpos[NRM_CAP], cidx[NRM_CAP];
+    float cd[NRM_CAP];
     int count = 0;
-    auto scan_slab = [&](int b) {
-        const int s0 = V.slab_start[b], s1 = V.slab_start[b + 1];
-        if (s0 >= s1) return;
-        const int q0 = lower_bound_y(V, s0, s1, p.y);
-        for (int i = q0; i < s1; ++i) {
-            const float4 c = V.at(i);
-            float dy = p.y - c.y;
-            if (dy * dy > r2) break;
-            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
-                float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
-                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
-                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
-                accu[6] += x; accu[7] += y; accu[8] += z;
-                count++;
+    /* visit(i, c, d) for every indexed point within the radius */
+    auto for_each_neighbour = [&](auto visit) {
+        auto scan_slab = [&](int b) {
+            const int s0 = V.slab_start[b], s1 = V.slab_start[b + 1];
+            if (s0 >= s1) return;
+            const int q0 = lower_bound_y(V, s0, s1, p.y);
+            for (int i = q0; i < s1; ++i) {
+                const float4 c = V.at(i);
+                const float dy = p.y - c.y;
+                if (dy * dy > r2) break;
+                const float d = dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z);
+                if (d <= r2) visit(i, c, d);
             }
+            for (int i = q0 - 1; i >= s0; --i) {
+                const float4 c = V.at(i);
+                const float dy = p.y - c.y;
+                if (dy * dy > r2) break;
+                const float d = dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z);
+                if (d <= r2) visit(i, c, d);
+            }
+        };
+        const int b = slab_of(V.m, p.x);
+        scan_slab(b);
+        for (int bb = b + 1; bb < B; ++bb) {
+            if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
+            const float dx = V.slab_xmin[bb] - p.x;
+            if (dx > 0.f && dx * dx > r2) break;
+            scan_slab(bb);
         }
-        for (int i = q0 - 1; i >= s0; --i) {
-            const float4 c = V.at(i);
-            float dy = p.y - c.y;
-            if (dy * dy > r2) break;
-            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
-                float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
-                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
-                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
-                accu[6] += x; accu[7] += y; accu[8] += z;
-                count++;
-            }
+        for (int bb = b - 1; bb >= 0; --bb) {
+            if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
+            const float dx = p.x - V.slab_xmax[bb];
+            if (dx > 0.f && dx * dx > r2) break;
+            scan_slab(bb);
         }
     };
-    const int b = slab_of(V.m, p.x);
-    scan_slab(b);
-    for (int bb = b + 1; bb < B; ++bb) {
-        if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
-        float dx = V.slab_xmin[bb] - p.x;
-        if (dx > 0.f && dx * dx > r2) break;
-        scan_slab(bb);
-    }
-    for (int bb = b - 1; bb >= 0; --bb) {
-        if (V.slab_start[bb] == V.slab_start[bb + 1]) continue;
-        float dx = p.x - V.slab_xmax[bb];
-        if (dx > 0.f && dx * dx > r2) break;
-        scan_slab(bb);
-    }
+    for_each_neighbour([&](int i, const float4 &c, float d) {
+        if (count < NRM_CAP) { cpos[count] = i; cidx[count] = idx_of(c); cd[count] = d; }
+        count++;
+    });
     if (count < 3) { out[0] = out[1] = out[2] = out[3] = NAN; return; }
+    float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](const float4 &c) {
+        const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
+        accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+        accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+        accu[6] += x; accu[7] += y; accu[8] += z;
+    };
+    if (count <= NRM_CAP) { /* the usual case: a few dozen neighbours, selected in order from the thread's own list */
+        for (int r = 0; r < count; ++r) {
+            int bj = 0;
+            float bd = INFINITY;
+            int bi = 0x7fffffff;
+            for (int j = 0; j < count; ++j) {
+                const float dj = cd[j];
+                if (dj < bd || (dj == bd && cidx[j] < bi)) { bd = dj; bi = cidx[j]; bj = j; }
+            }
+            add(V.at(cpos[bj]));
+            cd[bj] = INFINITY; cidx[bj] = 0x7fffffff; /* taken */
+        }
+    } else { /* a very dense neighbourhood: no list, the next neighbour in order is found by scanning again */
+        float ld = -1.f;
+        int li = -1;
+        for (int r = 0; r < count; ++r) {
+            float bd = INFINITY;
+            int bi = 0x7fffffff;
+            float4 bc = p;
+            for_each_neighbour([&](int, const float4 &c, float d) {
+                const int id = idx_of(c);
+                const bool after = d > ld || (d == ld && id > li);
+                if (after && (d < bd || (d == bd && id < bi))) { bd = d; bi = id; bc = c; }
+            });
+            add(bc);
+            ld = bd; li = bi;
+        }
+    }
     float cnt = (float)count;
     for (int i = 0; i < 9; ++i) accu[i] /= cnt;
     float cov[9];

@@ -378,6 +378,8 @@ def test_whole_cloud_normal_field(engine_mod, oracle_mod):
     e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
     n = e.estimate_normals(); on = o.estimate_normals()
     on[123] = np.nan  # the oracle leaves a dropped point's slot at zero; PCL gives NaN for it
+    keep = np.arange(len(n)) != 123
+    assert np.array_equal(n[keep].view(np.uint32), on[keep].view(np.uint32))   # same neighbour order, same rounding: same bits
     nan = np.isnan(on[:, 0])
     assert np.array_equal(np.isnan(n[:, 0]), nan) and nan.sum() >= 1
     ang = np.arctan2(np.linalg.norm(np.cross(n[~nan, :3], on[~nan, :3]), axis=1), np.sum(n[~nan, :3] * on[~nan, :3], axis=1))
@@ -452,12 +454,9 @@ def test_area2cloud_api(engine_mod, oracle_mod):
         want = np.stack([o.area2cloud(p, key) for p in q])
         nan = np.isnan(want[:, 0])
         assert np.array_equal(np.isnan(got[:, 0]), nan)
-        d = np.abs(got[~nan] - want[~nan])
-        # x (the extremum itself) agrees to float noise; y (and z through the surface slope) is the
-        # 0.5-degree sample that happens to be extreme, so a tiny rotation of the principal direction
-        # moves it by up to two samples (R sin 1 deg = 0.1 mm)
-        assert d[:, 0].max() < 2e-3 and d[:, 1].max() < 0.12 and d[:, 2].max() < 0.06
-        assert np.median(d) == 0.0   # and almost always nothing moves at all
+        # the normal field is bit-identical to the oracle's (distance-ordered covariance sums, correctly rounded trig in
+        # computeRoots), so the principal direction and with it the extreme 0.5-degree ellipse sample are the same
+        assert np.array_equal(got[~nan], want[~nan])
 
 
 @pytest.mark.parametrize("walk", [1, 2, 3])

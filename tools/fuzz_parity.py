@@ -28,7 +28,16 @@ def sharded_matches(one, pts, kw, S, world):
             continue
         g = engine.Engine(0, slice_begin=b, slice_end=e_, **kw)
         g.set_cloud(pts)
-        g.gen_path(); g.get_path()
+        try:
+            g.gen_path(); g.get_path()
+        except engine.PPPError as ex:
+            if "range_margin" not in str(ex):
+                return "sharded (%d ranges), range [%d, %d) of %d slices: %s (failed slice %d)" % (world, b, e_, S, ex, g.failed_slice())
+            # a waypoint far from the cloud (its nearest point cannot be proven inside the default 24 mm margin): the
+            # engine refuses instead of guessing; the caller's remedy is a wider margin
+            g = engine.Engine(0, slice_begin=b, slice_end=e_, range_margin=400.0, **kw)
+            g.set_cloud(pts)
+            g.gen_path(); g.get_path()
         off += g.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, buf.ptr + 24 * off, W - off)
         c = g.waypoint_counts()
         counts = c if counts is None else counts + c
@@ -44,7 +53,9 @@ def sharded_matches(one, pts, kw, S, world):
 
 def one_case(rng, i, only=None, verbose=False):
     kind = rng.choice(["dome", "wavy", "blade", "flat"])
-    nx = int(rng.integers(120, 420)); ny = int(rng.integers(40, 160))
+    big = os.environ.get("PPP_FUZZ_BIG") == "1"   # larger, denser clouds: LDS-overflow (arena) paths, many slabs
+    nx = int(rng.integers(600, 2400)) if big else int(rng.integers(120, 420))
+    ny = int(rng.integers(150, 700)) if big else int(rng.integers(40, 160))
     amp = float(rng.uniform(2.0, 40.0))
     R = float(rng.choice([4.0, 5.0, 6.0, 7.5, 9.0, 12.0, 15.0]))
     walk = int(rng.integers(0, 5))
