@@ -51,9 +51,10 @@ def sharded_matches(one, pts, kw, S, world):
     return None
 
 
-def one_case(rng, i, only=None, verbose=False):
+def one_case(rng, i, only=None, verbose=False, big=None):
     kind = rng.choice(["dome", "wavy", "blade", "flat"])
-    big = os.environ.get("PPP_FUZZ_BIG") == "1"   # larger, denser clouds: LDS-overflow (arena) paths, many slabs
+    if big is None:
+        big = os.environ.get("PPP_FUZZ_BIG") == "1"   # larger clouds: LDS-overflow (arena) paths, many slabs, long chains
     nx = int(rng.integers(600, 2400)) if big else int(rng.integers(120, 420))
     ny = int(rng.integers(150, 700)) if big else int(rng.integers(40, 160))
     amp = float(rng.uniform(2.0, 40.0))
