@@ -206,6 +206,15 @@ KTimer *timer_for(ppp_handle h, const char *name)
     return t;
 }
 
+/* synchronous copy on the handle's own stream.  Never hipMemcpy: that runs on the legacy stream, which HIP refuses
+   (and which poisons the other thread's capture) while ANY thread is capturing a graph -- distinct handles are driven
+   from concurrent host threads. */
+hipError_t copy_sync(ppp_handle h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    return e == hipSuccess ? hipStreamSynchronize(h->stream) : e;
+}
+
 /* launch helper: optional hipEvent bracket on the handle's stream */
 #define LAUNCH(h, name, kern, grid, block, shmem, ...)                                                \
     do {                                                                                              \
@@ -768,9 +777,9 @@ int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n)
     if (xyz && k) {
         std::vector<float> t(3 * k);
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipMemcpy(t.data(), h->X.p, 4 * k, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(t.data() + k, h->Y.p, 4 * k, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(t.data() + 2 * k, h->Z.p, 4 * k, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, t.data(), h->X.p, 4 * k, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, t.data() + k, h->Y.p, 4 * k, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, t.data() + 2 * k, h->Z.p, 4 * k, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; ++i) { xyz[3 * i] = t[i]; xyz[3 * i + 1] = t[k + i]; xyz[3 * i + 2] = t[2 * k + i]; }
     }
     return PPP_OK;
@@ -1067,7 +1076,7 @@ int ppp_get_waypoints(ppp_handle h, float *out6, size_t cap, size_t *W)
     if (W) *W = w;
     if (out6 && cap) {
         size_t k = std::min(cap, w);
-        if (k) HIPCHK(h, hipMemcpy(out6, h->wp_out.p, k * 24, hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, copy_sync(h, out6, h->wp_out.p, k * 24, hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }
@@ -1112,7 +1121,7 @@ int ppp_get_tail_index(ppp_handle h, int *tail, size_t cap, size_t *n)
     if (n) *n = nk;
     if (tail && cap) {
         size_t k = std::min(cap, nk);
-        if (k) HIPCHK(h, hipMemcpy(tail, h->tail.p, k * sizeof(int), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, copy_sync(h, tail, h->tail.p, k * sizeof(int), hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }
@@ -1127,7 +1136,7 @@ int ppp_get_waypoint_counts(ppp_handle h, int *counts, size_t cap, size_t *nkept
     if (nkept) *nkept = nk;
     if (counts && cap) {
         size_t k = std::min(cap, nk);
-        if (k) HIPCHK(h, hipMemcpy(counts, h->wp_cnt.p, k * sizeof(int), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, copy_sync(h, counts, h->wp_cnt.p, k * sizeof(int), hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }
@@ -1171,7 +1180,7 @@ int ppp_get_slice_positions(ppp_handle h, float *px, size_t cap, size_t *S)
     if (S) *S = s;
     if (px && cap) {
         size_t k = std::min(cap, s);
-        if (k) HIPCHK(h, hipMemcpy(px, h->px.p, k * sizeof(float), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, copy_sync(h, px, h->px.p, k * sizeof(float), hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }
@@ -1208,7 +1217,7 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
     if (n) *n = (size_t)h->hmeta.api_cnt;
     if (out && cap) {
         size_t k = std::min(cap, (size_t)h->hmeta.api_cnt);
-        if (k) HIPCHK(h, hipMemcpy(out, src, k * sizeof(int), hipMemcpyDeviceToHost));
+        if (k) HIPCHK(h, copy_sync(h, out, src, k * sizeof(int), hipMemcpyDeviceToHost));
     }
     return PPP_OK;
 }
@@ -1228,8 +1237,8 @@ int ppp_get_slice_indices(ppp_handle h, int s, int *out, size_t cap, size_t *n)
     if (rc) return rc;
     if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
     float lohi[2];
-    HIPCHK(h, hipMemcpy(&lohi[0], h->lo.p + s, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(&lohi[1], h->hi.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, &lohi[0], h->lo.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, &lohi[1], h->hi.p + s, 4, hipMemcpyDeviceToHost));
     return band_indices(h, lohi[0], lohi[1], out, cap, n);
 }
 
@@ -1240,17 +1249,17 @@ int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t c
     if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
     int st = 0, cnt = 0;
     float pxs = 0;
-    HIPCHK(h, hipMemcpy(&st, h->node_start.p + s, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(&cnt, h->node_cnt.p + s, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(&pxs, h->px.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, &st, h->node_start.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, &cnt, h->node_cnt.p + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, &pxs, h->px.p + s, 4, hipMemcpyDeviceToHost));
     if (m) *m = (size_t)cnt;
     size_t k = std::min(cap, (size_t)cnt);
     (void)pxs;
     if (k && (y || z || x)) {
         std::vector<float> fx(k), fy(k), fz(k);
-        HIPCHK(h, hipMemcpy(fx.data(), h->node_x.p + st, k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(fy.data(), h->node_y.p + st, k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(fz.data(), h->node_z.p + st, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, fx.data(), h->node_x.p + st, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, fy.data(), h->node_y.p + st, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, fz.data(), h->node_z.p + st, k * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; ++i) {
             if (y) y[i] = (double)fy[i];
             if (x) x[i] = (double)fx[i];
@@ -1305,8 +1314,8 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, 
     size_t k = std::min(cap, cnt);
     if (k) {
         std::vector<float> fy(k), fz(k);
-        HIPCHK(h, hipMemcpy(fy.data(), dy, k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, hipMemcpy(fz.data(), dz, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, fy.data(), dy, k * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, fz.data(), dz, k * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < k; ++i) {
             if (y) y[i] = (double)fy[i];
             if (x) x[i] = (double)plane_x;
@@ -1410,7 +1419,7 @@ int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *
     switch (stage) {
     case PPP_STAGE_WP_XYZ: {
         std::vector<float4> t4(W);
-        HIPCHK(h, hipMemcpy(t4.data(), h->wp_xyz.p, W * 16, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, t4.data(), h->wp_xyz.p, W * 16, hipMemcpyDeviceToHost));
         tmp.resize(3 * W);
         for (size_t i = 0; i < W; ++i) { tmp[3 * i] = t4[i].x; tmp[3 * i + 1] = t4[i].y; tmp[3 * i + 2] = t4[i].z; }
         memcpy(out, tmp.data(), std::min(cap_bytes, W * 12));
@@ -1422,7 +1431,7 @@ int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *
     case PPP_STAGE_WP_SMOOTHED: src = h->wp_smooth.p; elem = 24; break;
     default: return fail(h, PPP_ERR_ARG, "unknown stage");
     }
-    HIPCHK(h, hipMemcpy(out, src, std::min(cap_bytes, W * elem), hipMemcpyDeviceToHost));
+    HIPCHK(h, copy_sync(h, out, src, std::min(cap_bytes, W * elem), hipMemcpyDeviceToHost));
     return PPP_OK;
 }
 

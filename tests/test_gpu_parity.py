@@ -660,7 +660,7 @@ def test_distinct_handles_from_concurrent_host_threads(engine_mod):
     """thread-compatible -- distinct handles may be driven from different host threads at once
     (own stream, own graph capture in thread-local mode, no globals)."""
     import threading
-    kinds = [("small_40k", 11), ("tiny_5k", 12), ("small_40k", 13), ("tiny_5k", 14)]
+    kinds = [("small_40k", 11), ("tiny_5k", 12), ("small_40k", 13), ("tiny_5k", 14), ("small_40k", 15), ("tiny_5k", 16)]
     clouds = [synth.make_config(n, seed=s)[0] for n, s in kinds]
     want = []
     for pts in clouds:
@@ -672,13 +672,16 @@ def test_distinct_handles_from_concurrent_host_threads(engine_mod):
         try:
             e = engine_mod.Engine(0, tool_radius=6.0)
             e.set_cloud(clouds[i])
-            for rep in range(8):
-                if rep % 2:
+            for rep in range(10):
+                if rep % 3 == 1:
                     e.run_async(); e.sync()
+                elif rep % 3 == 2:       # a parameter change drops the graph: the next run_async captures again
+                    e.set_params(path_resolution=7.0); e.run_async(); e.sync()
                 else:
                     e.gen_path(); e.get_path()
                 if e.waypoints().tobytes() != want[i]:
                     errors.append((i, rep, "list differs"))
+                e.nodes(1); e.slice_indices(2); e.tail_index(); e.stage(engine_mod.STAGE_WP_NN)   # synchronous readers
         except Exception as ex:  # noqa: BLE001
             errors.append((i, repr(ex)))
 
