@@ -17,6 +17,7 @@ def _rt():
 
 class DeviceBuffer:
     def __init__(self, nbytes):
+        self.hip = _rt()
         p = C.c_void_p()
         rc = _rt().hipMalloc(C.byref(p), C.c_size_t(max(int(nbytes), 1)))
         if rc:

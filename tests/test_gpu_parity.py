@@ -691,3 +691,88 @@ def test_distinct_handles_from_concurrent_host_threads(engine_mod):
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors
+
+
+def test_one_handle_through_many_clouds_errors_and_modes(engine_mod, oracle_mod):
+    """Handle reuse: clouds of different sizes in turn, a cloud that fails in between, the dynamic adjustment switched
+    on and off, a device-resident cloud, outlier removal -- after each, the result equals a fresh handle's."""
+    from polishpathplanning_amd.hipbuf import DeviceBuffer
+    import ctypes as C
+
+    def fresh(pts, **kw):
+        f = engine_mod.Engine(0, **kw); f.set_cloud(pts); f.gen_path(); f.get_path()
+        return f.waypoints().tobytes()
+
+    big = synth.make_config("small_40k", seed=21)[0]
+    small = synth.make_config("tiny_5k", seed=22)[0]
+    flat = synth.make_plate(150, 40, kind="flat", seed=23)            # dynamic adjustment fails on a plane (no curvature)
+    one_sided = small.copy(); one_sided[:, 0] = np.float32(0.0405)    # every point on one plane x: no slice has two sides
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    for step, (pts, kw) in enumerate([(big, {}), (small, {}), (big, dict(dynamic_adjustment=1)), (flat, dict(dynamic_adjustment=1)),
+                                      (one_sided, dict(dynamic_adjustment=0)), (small, {}), (big, dict(path_resolution=5.0)),
+                                      (np.zeros((0, 3), np.float32), {}), (big, dict(path_resolution=7.0))]):
+        if kw:
+            e.set_params(**kw)
+        e.set_cloud(pts)
+        params = dict(tool_radius=6.0, dynamic_adjustment=e.params.dynamic_adjustment, path_resolution=e.params.path_resolution)
+        try:
+            e.gen_path(); e.get_path()
+            got = e.waypoints().tobytes()
+        except engine_mod.PPPError as ex:
+            got = ("error", ex.code)
+        try:
+            want = fresh(pts, **params)
+        except engine_mod.PPPError as ex:
+            want = ("error", ex.code)
+        assert got == want, (step, got if isinstance(got, tuple) else len(got), want if isinstance(want, tuple) else len(want))
+    # a cloud that already lives in device memory (stride 16, as a float4 array would be)
+    buf = DeviceBuffer(len(big) * 16)
+    host = np.zeros((len(big), 4), np.float32); host[:, :3] = big
+    assert buf.hip.hipMemcpy(C.c_void_p(buf.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) == 0
+    e.set_params(dynamic_adjustment=0, path_resolution=7.0)
+    e._chk(e.L.ppp_set_cloud_device(e.h, C.c_void_p(buf.ptr), len(big), 16, None))
+    e.gen_path(); e.get_path()
+    assert e.waypoints().tobytes() == fresh(big, tool_radius=6.0)
+    # outlier removal on the reused handle, then planning
+    n1, thr = e.remove_outlier(50, 1.0)
+    o = oracle_mod.Oracle(big, tool_radius=6.0); n2, thr2, _ = o.remove_outlier(50, 1.0)
+    assert n1 == n2
+    e.gen_path(); e.get_path(); o.gen_path(); o.get_path()
+    assert np.linalg.norm(e.waypoints()[:, :3] - o.waypoints()[:, :3], axis=1).max() <= TOL_M
+
+
+def test_batch_with_mixed_members_and_a_failing_one(engine_mod):
+    """One batch graph over a plain handle, a dynamic-adjustment handle, a brute-pairing handle and one whose cloud
+    makes the planner fail: the failure is that member's alone."""
+    big = synth.make_config("small_40k", seed=31)[0]
+    small = synth.make_config("tiny_5k", seed=32)[0]
+    bad = small.copy(); bad[:, 0] = np.float32(0.0405)
+    specs = [(big, dict()), (big, dict(dynamic_adjustment=1)), (small, dict(pairing=1, walk=3)), (bad, dict()), (small, dict(walk=2))]
+    want = []
+    for pts, kw in specs:
+        f = engine_mod.Engine(0, tool_radius=6.0, **kw); f.set_cloud(pts)
+        try:
+            f.gen_path(); f.get_path(); want.append(f.waypoints())
+        except engine_mod.PPPError as ex:
+            want.append(ex.code)
+    assert isinstance(want[3], int) and all(not isinstance(w, int) for i, w in enumerate(want) if i != 3)
+    engines = []
+    for pts, kw in specs:
+        e = engine_mod.Engine(0, tool_radius=6.0, **kw); e.set_cloud(pts); engines.append(e)
+    ws = [0 if isinstance(w, int) else len(w) for w in want]
+    offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
+    buf = _DeviceBuffer(max(sum(ws), 1) * 24)
+    for _ in range(2):
+        engine_mod.run_batch_async(engines, buf.ptr, offs, [max(w, 1) for w in ws])
+        with pytest.raises(engine_mod.PPPError) as ei:
+            engine_mod.sync_batch(engines)
+        assert "handle 3" in str(ei.value)
+        for i, e in enumerate(engines):
+            if i == 3:
+                with pytest.raises(engine_mod.PPPError):
+                    e.waypoints()
+            else:
+                e.sync()
+                assert e.waypoints().tobytes() == want[i].tobytes()
+    got = buf.to_host(sum(ws) * 6)
+    assert got.tobytes() == np.concatenate([w for w in want if not isinstance(w, int)]).tobytes()
