@@ -922,7 +922,7 @@ struct ppo_handle {
         float ab[3];
         area2cloud(node, key == 0 ? 1 : 0, ab);
         if (ab[1] < boundary.small_y || ab[1] > boundary.big_y) return;
-        if (!boundary.yx.in_domain((double)ab[1])) return; /* NaN y: GSL would abort; treated as overflow */
+        if (!boundary.yx.in_domain((double)ab[1])) return; /* (a NaN y passes this test and GSL's own: the spline then returns NaN) */
         double bpnt[3];
         boundary.point((double)ab[1], bpnt);
         double norm0 = (double)ab[0] - bpnt[0];
@@ -950,6 +950,11 @@ struct ppo_handle {
             origin.point(dy, node);
             bisection(node, boundary, 0, key);
             const float q[3] = {(float)node[0], (float)node[1], (float)node[2]};
+            /* B.14: a NaN Area2Cloud (negative curvature under a square root) makes the whole node NaN ("adjust path node
+               NAN" is printed, :258-261) and nearestKSearch is then handed a NaN point; what FLANN leaves in pointIdx is
+               the previous sample's result at best.  Defined behaviour here and in the product: such a sample adds no
+               knot. */
+            if (!std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) continue;
             int id = tree.nearest(q); /* nearestKSearch(point, 3): only pointIdx[0] is used */
             if (id < 0) return -1;
             const Pt &c = cloud[id];

@@ -467,8 +467,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     for (int itr = 0; itr <= 5; ++itr) {
         float ab[3];
         wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, node, c.key == 0 ? 1 : 0, ab, sc);
-        if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break;
-        if (!(ab[1] == ab[1])) break;
+        if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break; /* a NaN bound passes, as in the reference: the node turns NaN below */
         const int iv = gsl_bsearch(nb, (double)ab[1], BY);
         const double bpx = steffen_eval_at(iv, nb, (double)ab[1], BY, BX);
         const double norm0 = (double)ab[0] - bpx;
@@ -478,11 +477,15 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
         sc.mark(6);
     }
     sc.mark(7);
-    /* kdtree.nearestKSearch(point, 3): only pointIdx[0] is used (:291-294) */
+    /* kdtree.nearestKSearch(point, 3): only pointIdx[0] is used (:291-294).  B.14: a node that Area2Cloud turned NaN
+       ("adjust path node NAN", :258-261) adds no knot (the reference hands the NaN to FLANN and reads whatever
+       pointIdx holds afterwards) */
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
-    const int got = (qx == qx && qy == qy && qz == qz) ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
+    const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
+    const int got = finite ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
     if (lane == 0) {
-        if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
+        if (!finite) *dst = make_float4(0, 0, 0, 0);
+        else if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
         else { const float4 p = V.at(s_w[wv].sel[0]); *dst = make_float4(p.y, p.x, p.z, 1.f); }
     }
     sc.mark(8);

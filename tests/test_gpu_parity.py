@@ -629,6 +629,15 @@ def test_randomised_sweep_against_the_oracle(engine_mod, oracle_mod):
         res, desc = fz.one_case(rng, i)
         if res is not None and not res.startswith("both fail"):
             bad.append((desc, res))
+    os.environ["PPP_FUZZ_TINY"] = "1"     # 60 clouds of a few hundred points: one or two slices, empty sides, NaN ellipses
+    try:
+        rng = np.random.default_rng(51)
+        for i in range(60):
+            res, desc = fz.one_case(rng, i)
+            if res is not None and not res.startswith("both fail"):
+                bad.append((desc, res))
+    finally:
+        del os.environ["PPP_FUZZ_TINY"]
     rng = np.random.default_rng(31)   # and 8 clouds of 0.2 .. 1.5 M points (long dynamic chains, many slabs)
     for i in range(8):
         res, desc = fz.one_case(rng, i, big=True)

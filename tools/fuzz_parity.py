@@ -55,8 +55,9 @@ def one_case(rng, i, only=None, verbose=False, big=None):
     kind = rng.choice(["dome", "wavy", "blade", "flat"])
     if big is None:
         big = os.environ.get("PPP_FUZZ_BIG") == "1"   # larger clouds: LDS-overflow (arena) paths, many slabs, long chains
-    nx = int(rng.integers(600, 2400)) if big else int(rng.integers(120, 420))
-    ny = int(rng.integers(150, 700)) if big else int(rng.integers(40, 160))
+    tiny = os.environ.get("PPP_FUZZ_TINY") == "1" if big is not True else False   # few slices, few points per band
+    nx = int(rng.integers(600, 2400)) if big else (int(rng.integers(6, 70)) if tiny else int(rng.integers(120, 420)))
+    ny = int(rng.integers(150, 700)) if big else (int(rng.integers(6, 50)) if tiny else int(rng.integers(40, 160)))
     amp = float(rng.uniform(2.0, 40.0))
     R = float(rng.choice([4.0, 5.0, 6.0, 7.5, 9.0, 12.0, 15.0]))
     walk = int(rng.integers(0, 5))
