@@ -16,7 +16,7 @@ from oracle import ppo  # noqa: E402
 rng2 = np.random.default_rng(12345)  # choices that must not disturb the case stream
 
 
-def sharded_matches(one, pts, kw, S, world):
+def sharded_matches(one, pts, kw, S, world, viewpoint=None):
     """slice-range handles + ppp_finish_path_async against the single handle: must be byte-identical"""
     from polishpathplanning_amd.hipbuf import DeviceBuffer
     from polishpathplanning_amd.robot_path import slice_ranges
@@ -27,7 +27,7 @@ def sharded_matches(one, pts, kw, S, world):
         if b == e_:
             continue
         g = engine.Engine(0, slice_begin=b, slice_end=e_, **kw)
-        g.set_cloud(pts)
+        g.set_cloud(pts, viewpoint=viewpoint)
         try:
             g.gen_path(); g.get_path()
         except engine.PPPError as ex:
@@ -36,7 +36,7 @@ def sharded_matches(one, pts, kw, S, world):
             # a waypoint far from the cloud (its nearest point cannot be proven inside the default 24 mm margin): the
             # engine refuses instead of guessing; the caller's remedy is a wider margin
             g = engine.Engine(0, slice_begin=b, slice_end=e_, range_margin=400.0, **kw)
-            g.set_cloud(pts)
+            g.set_cloud(pts, viewpoint=viewpoint)
             g.gen_path(); g.get_path()
         off += g.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, buf.ptr + 24 * off, W - off)
         c = g.waypoint_counts()
@@ -75,6 +75,20 @@ def one_case(rng, i, only=None, verbose=False, big=None):
               trim=float(rng.choice([5.0, 10.0])), smooth=int(rng.random() < 0.8))
     if walk == 3 and dyn:
         kw.update(curvature_k=10, depth=0.005)
+    # secondary knobs, drawn from their own stream so the seeded cases above stay what they were
+    viewpoint = None
+    if rng2.random() < 0.5:
+        kw["ee_length"] = float(rng2.uniform(0.05, 0.5))
+        kw["normal_radius"] = float(rng2.choice([2.5, 3.0, 4.0]))
+        if rng2.random() < 0.5:
+            kw["handeye"] = [float(v) for v in rng2.uniform(-1.0, 1.0, 3)] + [float(v) for v in rng2.uniform(-3.1, 3.1, 3)]
+        if rng2.random() < 0.4:
+            viewpoint = [0.0, 0.0, 3000.0]                # the VIEWPOINT is not scaled with the cloud: above z = 1500 mm every normal flips
+        if dyn:
+            kw["adjust_threshold"] = float(rng2.choice([0.5, 1.0, 2.0]))
+            kw["depth"] = float(rng2.choice([0.005, 0.01, 0.02]))
+            kw["toolthickness"] = float(rng2.choice([5.0, 10.0]))
+    sor = rng2.random() < 0.1
     desc = "case %d: %s %dx%d amp %.1f R %.1f walk %d pairing %d dyn %d res %.1f rpy %.0f trim %.0f smooth %d n %d" % (
         i, kind, nx, ny, amp, R, walk, pairing, dyn, kw["path_resolution"], kw["rpy_resolution"], kw["trim"], kw["smooth"], len(pts))
     if only is not None and i != only:
@@ -82,15 +96,35 @@ def one_case(rng, i, only=None, verbose=False, big=None):
     if verbose:
         np.save("gpurun_out/fuzz_case_%d.npy" % i, pts)
         print(kw)
-    o = ppo.Oracle(pts, **kw)
-    So = o.gen_path()
+    okw = dict(kw)
+    if viewpoint is not None:
+        okw["viewpoint"] = viewpoint
+    o = ppo.Oracle(pts, **okw)
     e = engine.Engine(0, **kw)
-    e.set_cloud(pts)
+    e.set_cloud(pts, viewpoint=viewpoint)
+    if sor:                                                # RemoveOutlier = true first
+        n_o = o.remove_outlier(50, 1.0)[0]
+        try:
+            n_e = e.remove_outlier(50, 1.0)[0]
+        except engine.PPPError as ex:
+            n_e = -1
+        if n_o != n_e:
+            return "remove_outlier kept %d, oracle %d" % (n_e, n_o), desc
+        if n_o < 0:
+            return None, desc
+        if not np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(o.points())):
+            return "remove_outlier: filtered clouds differ", desc
+    So = o.gen_path()
     try:
         S = e.gen_path()
     except engine.PPPError as ex:
         if So < 0 and e.failed_slice() == -(So + 1):
             return "both fail at slice %d" % e.failed_slice(), desc
+        if So < 0 and dyn and walk == 1:
+            # the centre-out planner adjusts its left and right chains side by side (two threads in the reference, two
+            # chains per launch here, one after the other in the oracle): when both chains fail, which slice is named
+            # first is an artefact of that order
+            return "both fail (slice %d here, %d in the oracle's chain order)" % (e.failed_slice(), -(So + 1)), desc
         return "GPU error %s (oracle S=%d)" % (ex, So), desc
     if So < 0:
         return "oracle fails at slice %d, GPU S=%d" % (-(So + 1), S), desc
@@ -135,8 +169,8 @@ def one_case(rng, i, only=None, verbose=False, big=None):
             return "angles differ by %.3e rad" % r, desc
         if not np.array_equal(e.tail_index(), o.tail_index()):
             return "TailIndex differs", desc
-        if not dyn:
-            res = sharded_matches(e, pts, kw, S, int(rng2.integers(2, 6)))
+        if not dyn and not sor:
+            res = sharded_matches(e, pts, kw, S, int(rng2.integers(2, 6)), viewpoint)
             if res:
                 return res, desc
     return None, desc
