@@ -89,6 +89,13 @@ def one_case(rng, i, only=None, verbose=False, big=None):
             kw["depth"] = float(rng2.choice([0.005, 0.01, 0.02]))
             kw["toolthickness"] = float(rng2.choice([5.0, 10.0]))
     sor = rng2.random() < 0.1
+    unit = 1.0
+    if rng2.random() < 0.1:                               # ChangeRange = false: the file is already in millimetres
+        pts = pts * np.float32(1000.0)
+        kw["change_range"] = 0
+        unit = 1000.0
+        if viewpoint is not None:
+            viewpoint = [0.0, 0.0, 3000.0]
     desc = "case %d: %s %dx%d amp %.1f R %.1f walk %d pairing %d dyn %d res %.1f rpy %.0f trim %.0f smooth %d n %d" % (
         i, kind, nx, ny, amp, R, walk, pairing, dyn, kw["path_resolution"], kw["rpy_resolution"], kw["trim"], kw["smooth"], len(pts))
     if only is not None and i != only:
@@ -162,8 +169,8 @@ def one_case(rng, i, only=None, verbose=False, big=None):
             ang = np.arctan2(np.linalg.norm(np.cross(n_g[:, :3], n_o[:, :3]), axis=1), np.sum(n_g[:, :3] * n_o[:, :3], axis=1))
             print("normal angle max", ang.max(), "at", ang.argmax(), n_g[ang.argmax()], n_o[ang.argmax()])
             print("rpy g", e.waypoints()[dv.argmax()], "o", o.waypoints()[dv.argmax()])
-        if not d <= 1e-4:
-            return "waypoints differ by %.3e m" % d, desc
+        if not d <= 1e-4 * unit:
+            return "waypoints differ by %.3e m" % (d / unit), desc
         r = np.abs(e.waypoints()[:, 3:] - o.waypoints()[:, 3:]); r = np.minimum(r, np.abs(r - 2 * np.pi)).max()
         if not r <= 2e-3:
             return "angles differ by %.3e rad" % r, desc
