@@ -365,6 +365,11 @@ __device__ inline void pcl_roots2(float b, float c, float roots[3])
     roots[2] = 0.5f * (b + sd);
     roots[1] = 0.5f * (b - sd);
 }
+/* EXACT_TRIG: atan2 / cos / sin through double, rounded (the correctly rounded float, as the oracle computes it) -- for
+   the normal FIELD and the principal curvatures, whose last bits feed the dynamic adjustment's discontinuous
+   decisions.  Otherwise the device's float functions: k_pose's per-waypoint normals feed continuous outputs only, and
+   the double versions cost its hot loop 10-20 %. */
+template <bool EXACT_TRIG = true>
 __device__ inline void pcl_roots(const float m[3][3], float roots[3])
 {
     float c0 = m[0][0] * m[1][1] * m[2][2] + 2.f * m[0][1] * m[0][2] * m[1][2] -
@@ -384,9 +389,16 @@ __device__ inline void pcl_roots(const float m[3][3], float roots[3])
     float rho = sqrtf(-a_over_3);
     /* correctly rounded float results through double (see the oracle's computeRoots): device and host libm float
        functions differ by an ulp now and then, their double functions rounded to float do not */
-    float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
-    float cos_theta = (float)cos((double)theta);
-    float sin_theta = (float)sin((double)theta);
+    float theta, cos_theta, sin_theta;
+    if (EXACT_TRIG) {
+        theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+        cos_theta = (float)cos((double)theta);
+        sin_theta = (float)sin((double)theta);
+    } else {
+        theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+        cos_theta = cosf(theta);
+        sin_theta = sinf(theta);
+    }
     roots[0] = c2_over_3 + 2.f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
@@ -404,6 +416,7 @@ __device__ inline void cross3f(const float a[3], const float b[3], float o[3])
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
 }
+template <bool EXACT_TRIG = true>
 __device__ inline void pcl_eigen33_smallest(const float cov[9], float *eigenvalue, float ev[3])
 {
     float scale = 0.f;
@@ -413,7 +426,7 @@ __device__ inline void pcl_eigen33_smallest(const float cov[9], float *eigenvalu
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) m[i][j] = cov[3 * i + j] / scale;
     float roots[3];
-    pcl_roots(m, roots);
+    pcl_roots<EXACT_TRIG>(m, roots);
     *eigenvalue = roots[0] * scale;
     m[0][0] -= roots[0]; m[1][1] -= roots[0]; m[2][2] -= roots[0];
     float cp[3][3];

@@ -1486,7 +1486,7 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
     cov[8] = accu[5] - accu[8] * accu[8];
     cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
     float ev, n[3];
-    pcl_eigen33_smallest(cov, &ev, n);
+    pcl_eigen33_smallest<false>(cov, &ev, n); /* continuous outputs only: the device float trig is enough */
     float eig_sum = cov[0] + cov[4] + cov[8];
     float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
     float vx = vp[0] - p.x, vy = vp[1] - p.y, vz = vp[2] - p.z;
