@@ -1855,7 +1855,7 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
             double acc[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[j] = (double)cur[j][rs - 1 - base];
-            for (int i = rs; i < a; ++i) { /* (hoisting all reads in front of a predicated, unrolled chain measured slower) */
+            for (int i = rs; i < a; ++i) { /* (hoisting the reads -- all of them, or four steps at a time -- measured no faster) */
                 const int l = i - base;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[j] = s_c[j][l] + weight_smooth * acc[j];
@@ -1863,12 +1863,18 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
             for (int i = a; i < e; ++i) {
                 const int l = i - base;
                 const bool owned = i >= t0 && i < t1;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    acc[j] = s_c[j][l] + weight_smooth * acc[j];
-                    nxt[j][l] = (float)acc[j];
-                    if (owned) change += fabs(acc[j] - (double)cur[j][l]);
-                }
+                /* all six LDS operands first, then the arithmetic; `owned` selects instead of branching (the compiler
+                   otherwise emits three guarded read-wait sequences) */
+                const double c0 = s_c[0][l], c1 = s_c[1][l], c2 = s_c[2][l];
+                const float y0 = cur[0][l], y1 = cur[1][l], y2 = cur[2][l];
+                acc[0] = c0 + weight_smooth * acc[0];
+                acc[1] = c1 + weight_smooth * acc[1];
+                acc[2] = c2 + weight_smooth * acc[2];
+                nxt[0][l] = (float)acc[0]; nxt[1][l] = (float)acc[1]; nxt[2][l] = (float)acc[2];
+                const double d0 = fabs(acc[0] - (double)y0), d1 = fabs(acc[1] - (double)y1), d2 = fabs(acc[2] - (double)y2);
+                change += owned ? d0 : 0.0;
+                change += owned ? d1 : 0.0;
+                change += owned ? d2 : 0.0;
             }
         }
         s_chg[k - 1][threadIdx.x] = change; /* reduced once, after the last sweep (a block reduction per
