@@ -1377,23 +1377,31 @@ __device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, flo
                     const float dx = so > 0 ? V.slab_xmin[bb] - qx : (so < 0 ? qx - V.slab_xmax[bb] : 0.f);
                     if (dx > 0.f && dx * dx > best) { if (so > 0) rc = 1; else lc = 1; }
                     else {
-                        const int p = lower_bound_y(V, s0, s1, qy);
-                        for (int i = p; i < s1; ++i) {
-                            const float4 c = V.at(i);
-                            const float dy = qy - c.y;
-                            if (dy * dy > best) break;
-                            const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
-                            const int id = idx_of(c);
-                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
-                        }
-                        for (int i = p - 1; i >= s0; --i) {
-                            const float4 c = V.at(i);
-                            const float dy = qy - c.y;
-                            if (dy * dy > best) break;
-                            const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
-                            const int id = idx_of(c);
-                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
-                        }
+                        /* the staged window covers this slab almost always: then every read is an LDS read and the
+                           per-access "LDS or global?" test of SlabView::at leaves the loops */
+                        auto scan = [&](auto at) {
+                            int lo = s0, hi = s1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < qy) lo = mid + 1; else hi = mid; }
+                            const int p = lo;
+                            for (int i = p; i < s1; ++i) {
+                                const float4 c = at(i);
+                                const float dy = qy - c.y;
+                                if (dy * dy > best) break;
+                                const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
+                                const int id = idx_of(c);
+                                if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                            }
+                            for (int i = p - 1; i >= s0; --i) {
+                                const float4 c = at(i);
+                                const float dy = qy - c.y;
+                                if (dy * dy > best) break;
+                                const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
+                                const int id = idx_of(c);
+                                if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                            }
+                        };
+                        if (s0 >= V.lds_lo && s1 <= V.lds_hi) { const float4 *L = V.lds - V.lds_lo; scan([&](int i) { return L[i]; }); }
+                        else scan([&](int i) { return V.at(i); });
                     }
                 }
             }
@@ -1438,31 +1446,37 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
                     const float dx = so > 0 ? V.slab_xmin[bb] - p.x : (so < 0 ? p.x - V.slab_xmax[bb] : 0.f);
                     if (dx > 0.f && dx * dx > r2) { if (so > 0) rc = 1; else lc = 1; }
                     else {
-                        const int q0 = lower_bound_y(V, s0, s1, p.y);
-                        for (int i = q0; i < s1; ++i) {
-                            const float4 c = V.at(i);
-                            const float dy = p.y - c.y;
-                            if (dy * dy > r2) break;
-                            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
-                                const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
-                                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
-                                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
-                                accu[6] += x; accu[7] += y; accu[8] += z;
-                                count++;
+                        auto scan = [&](auto at) { /* LDS-only reads when the staged window covers the slab (see the NN scan) */
+                            int lo = s0, hi = s1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < p.y) lo = mid + 1; else hi = mid; }
+                            const int q0 = lo;
+                            for (int i = q0; i < s1; ++i) {
+                                const float4 c = at(i);
+                                const float dy = p.y - c.y;
+                                if (dy * dy > r2) break;
+                                if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
+                                    const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
+                                    accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+                                    accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+                                    accu[6] += x; accu[7] += y; accu[8] += z;
+                                    count++;
+                                }
                             }
-                        }
-                        for (int i = q0 - 1; i >= s0; --i) {
-                            const float4 c = V.at(i);
-                            const float dy = p.y - c.y;
-                            if (dy * dy > r2) break;
-                            if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
-                                const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
-                                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
-                                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
-                                accu[6] += x; accu[7] += y; accu[8] += z;
-                                count++;
+                            for (int i = q0 - 1; i >= s0; --i) {
+                                const float4 c = at(i);
+                                const float dy = p.y - c.y;
+                                if (dy * dy > r2) break;
+                                if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
+                                    const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
+                                    accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+                                    accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+                                    accu[6] += x; accu[7] += y; accu[8] += z;
+                                    count++;
+                                }
                             }
-                        }
+                        };
+                        if (s0 >= V.lds_lo && s1 <= V.lds_hi) { const float4 *L = V.lds - V.lds_lo; scan([&](int i) { return L[i]; }); }
+                        else scan([&](int i) { return V.at(i); });
                     }
                 }
             }
