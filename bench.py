@@ -192,6 +192,14 @@ def main():
                    "sample": "1 full pass of %s (GenPath + getPath), single thread, reference-complexity "
                              "mode: per-slice O(N) PassThrough scans, whole-cloud normal estimation twice" % args.config,
                    "seconds": t_cpu, "host_cores_available": os.cpu_count()}
+            try:   # the host the baseline ran on
+                info = open("/proc/cpuinfo").read()
+                models = [ln.split(":", 1)[1].strip() for ln in info.splitlines() if ln.startswith("model name")]
+                sockets = {ln.split(":", 1)[1].strip() for ln in info.splitlines() if ln.startswith("physical id")}
+                cpu["cpu_model"] = models[0] if models else None
+                cpu["sockets"] = len(sockets) or None
+            except OSError:
+                pass
             # context only: the same pass with OpenMP over the slices and over the points of the normal
             # estimation; the kd-tree builds stay serial, as FLANN's are in the reference
             try:
