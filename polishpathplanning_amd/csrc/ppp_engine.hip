@@ -91,7 +91,7 @@ struct ppp_handle_s {
     DevBuf<char> arena;                /* their global scratch, allocated on first need */
     bool big_path = false;             /* launch the fallback kernels (set by the plan or after an overflow) */
     DevBuf<double> sm_part, sm_chist;
-    int mm_grid = 1, sm_tiles = 1;
+    int mm_grid = 1, mm_grid_used = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
 
     DevMeta hmeta;
@@ -402,10 +402,15 @@ int enqueue_index(ppp_handle h)
     const float slab_x0 = h->h_mn[0];
     const float xr = h->h_mx[0] - h->h_mn[0];
     const float slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f;
-    LAUNCH(h, "k_minmax", k_minmax<false>, h->mm_grid, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, 0.f, 0.f, 0, (int *)nullptr);
-    int gh = std::max(1, std::min((n / 4 + 256 * 8 - 1) / (256 * 8), 512));
-    LAUNCH(h, "k_slab_hist", k_slab_hist, gh, 256, hist_lds, h->X.p, n, slab_x0, slab_invw, h->B, h->slab_cnt.p, h->incl_lo, h->incl_hi);
-    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
+    {   /* a2 and the slab histogram in ONE pass over the cloud (the slab grid comes from the bounds cached with the
+           cloud).  At most 256 workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
+           that flush, not the streaming, is what grows with the grid. */
+        const int gf = std::max(1, std::min(h->mm_grid, 256));
+        LAUNCH(h, "k_minmax", k_minmax<true>, gf, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
+               h->incl_lo, h->incl_hi);
+        h->mm_grid_used = gf;
+    }
+    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
            h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
@@ -567,7 +572,7 @@ int refresh_bounds_and_plan(ppp_handle h)
         HIPCHK(h, h->mm_part.ensure(g));
         (void)hipGetLastError();
         hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
-                           (int *)nullptr);
+                           (int *)nullptr, 0.f, 0.f);
         HIPCHK(h, hipGetLastError());
         std::vector<MinMaxPart> parts(g);
         HIPCHK(h, hipMemcpyAsync(parts.data(), h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));
@@ -645,7 +650,7 @@ int ppp_create(int device_id, ppp_handle *out)
     /* kernels with > 64 KiB of dynamic LDS opt in explicitly */
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_slice_kd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_slab_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_minmax<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
     (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);

@@ -99,7 +99,7 @@ __device__ inline int slab_of_grid(float x, float x0, float invw, int B)
 template <bool HIST>
 __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
                                                 const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
-                                                int B, int *slab_cnt)
+                                                int B, int *slab_cnt, float xlo, float xhi)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     if (HIST) {
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
                 mn[1] = fminf(mn[1], ys[k]); mx[1] = fmaxf(mx[1], ys[k]);
                 mn[2] = fminf(mn[2], zs[k]); mx[2] = fmaxf(mx[2], zs[k]);
                 cnt++;
-                if (HIST) atomicAdd(&s_hist[slab_of_grid(xs[k], x0, invw, B)], 1);
+                if (HIST && xs[k] >= xlo && xs[k] <= xhi) atomicAdd(&s_hist[slab_of_grid(xs[k], x0, invw, B)], 1);
             }
         }
     }
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
             cnt++;
-            if (HIST) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
+            if (HIST && x >= xlo && x <= xhi) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
         }
     }
     if (HIST) {
@@ -341,35 +341,6 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
 /* Slice binning, generalised: every point goes to one x-slab (the      */
 /* replacement for kdtree.setInputCloud + the S PassThrough scans).     */
 /* ------------------------------------------------------------------ */
-/* x-slab histogram: LDS-privatised, few workgroups (every workgroup flushes one global atomic per
-   non-empty slab, so the grid stays small while each thread streams many points). */
-__global__ void __launch_bounds__(256) k_slab_hist(const float *__restrict__ X, int n, float x0, float invw, int B, int *slab_cnt,
-                                                   float xlo, float xhi)
-{
-    extern __shared__ __attribute__((aligned(16))) int s_hist[];
-    for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
-    __syncthreads();
-    const int n4 = n >> 2;
-    const float4 *X4 = (const float4 *)X;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-        float4 x = X4[i];
-        /* NaN fails both comparisons; a whole-cloud handle passes -inf / +inf */
-        if (x.x >= xlo && x.x <= xhi) atomicAdd(&s_hist[slab_of_grid(x.x, x0, invw, B)], 1);
-        if (x.y >= xlo && x.y <= xhi) atomicAdd(&s_hist[slab_of_grid(x.y, x0, invw, B)], 1);
-        if (x.z >= xlo && x.z <= xhi) atomicAdd(&s_hist[slab_of_grid(x.z, x0, invw, B)], 1);
-        if (x.w >= xlo && x.w <= xhi) atomicAdd(&s_hist[slab_of_grid(x.w, x0, invw, B)], 1);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        float x = X[(n4 << 2) + threadIdx.x];
-        if (x >= xlo && x <= xhi) atomicAdd(&s_hist[slab_of_grid(x, x0, invw, B)], 1);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        int c = s_hist[b];
-        if (c) atomicAdd(&slab_cnt[b], c);
-    }
-}
-
 #ifndef SCAT_T
 #define SCAT_T 1024
 #endif
