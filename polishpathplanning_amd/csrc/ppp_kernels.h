@@ -931,14 +931,16 @@ __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restric
         int base = atomicAdd(&m->node_cursor, tot);
         if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
         s_base = base;
+        s_plane = tot; /* (s_plane is free again: the knot count, for the workgroup, without re-reading node_cnt from memory) */
         node_start[s] = base;
         node_cnt[s] = tot;
         if (tot < 3) set_err(m, DERR_SLICE, s);
     }
     __syncthreads();
-    if (node_cnt[s] == 0) return;
+    const int nknots = s_plane;
+    if (nknots == 0) return;
     float *oy = node_y + s_base, *oz = node_z + s_base;
-    for (int i = threadIdx.x; i < node_cnt[s]; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
+    for (int i = threadIdx.x; i < nknots; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
     for (int base = 0; base < nEl; base += blockDim.x) {
         int j = base + threadIdx.x;
         int keep = 0;
