@@ -108,7 +108,7 @@ extern "C" {
 
 void ppp_free(void *p) { free(p); }
 
-int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
+static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoint[7])
 {
     if (!path || !xyz || !n) return PPP_ERR_ARG;
     *xyz = nullptr; *n = 0;
@@ -208,7 +208,7 @@ int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
     return PPP_OK;
 }
 
-int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
+static int save_pcd_impl(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
 {
     if (!path || (!xyz && n) || stride_floats < 3) return PPP_ERR_ARG;
     FILE *f = fopen(path, "wb");
@@ -247,7 +247,7 @@ void ppp_default_config(ppp_config *c)
     c->smooth_cloud = 0; c->remove_outlier = 0; c->alignment = 0; c->dynamic_adjustment = 1;
 }
 
-int ppp_read_config(const char *path, ppp_config *c)
+static int read_config_impl(const char *path, ppp_config *c)
 {
     if (!path || !c) return PPP_ERR_ARG;
     std::ifstream cFile(path);
@@ -284,7 +284,7 @@ int ppp_read_config(const char *path, ppp_config *c)
     return PPP_OK;
 }
 
-int ppp_write_path_file(const char *path, const float *wp6, size_t W)
+static int write_path_file_impl(const char *path, const float *wp6, size_t W)
 {
     if (!path || (!wp6 && W)) return PPP_ERR_ARG;
     std::ofstream outputFile(path);
@@ -300,4 +300,22 @@ int ppp_write_path_file(const char *path, const float *wp6, size_t W)
     return PPP_OK;
 }
 
+
+/* The boundary never lets a C++ exception (std::bad_alloc on a header that promises 10^12 points, ...) escape. */
+int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
+{
+    try { return load_pcd_impl(path, xyz, n, viewpoint); } catch (...) { if (xyz) *xyz = nullptr; if (n) *n = 0; return PPP_ERR_IO; }
+}
+int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
+{
+    try { return save_pcd_impl(path, xyz, n, stride_floats, viewpoint, binary); } catch (...) { return PPP_ERR_IO; }
+}
+int ppp_read_config(const char *path, ppp_config *c)
+{
+    try { return read_config_impl(path, c); } catch (...) { return PPP_ERR_IO; }
+}
+int ppp_write_path_file(const char *path, const float *wp6, size_t W)
+{
+    try { return write_path_file_impl(path, wp6, W); } catch (...) { return PPP_ERR_IO; }
+}
 } /* extern "C" */

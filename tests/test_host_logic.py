@@ -292,6 +292,20 @@ def test_pcd_errors(engine_mod, tmp_path):
     assert ei.value.code == engine_mod.ERR_UNSUPPORTED
 
 
+def test_hostile_pcd_header_is_an_error_not_a_crash(engine_mod, tmp_path):
+    """A header that promises more points than memory holds must come back as an error through the C ABI."""
+    p = tmp_path / "huge.pcd"
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 900000000000\nHEIGHT 1\nPOINTS 900000000000\nDATA binary\n")
+    with pytest.raises(engine_mod.PPPError) as ei:
+        engine_mod.load_pcd(str(p))
+    assert ei.value.code == engine_mod.ERR_IO
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 5\nHEIGHT 1\nPOINTS 5\nDATA binary_compressed\n")
+    with open(p, "ab") as f:
+        f.write(b"\xff\xff\xff\x7f\x3c\x00\x00\x00" + b"\x00" * 16)      # claims a 2 GiB stream
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.load_pcd(str(p))
+
+
 def test_read_config_follows_the_reference_parser(engine_mod, tmp_path):
     ref = "/root/reference/config.txt"
     if os.path.exists(ref):  # only in the build container; the same text is restated below
