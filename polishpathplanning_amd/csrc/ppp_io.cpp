@@ -138,6 +138,12 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     }
     if (!have_points) points = width * height;
     if (fields.empty() || data_kind.empty()) return PPP_ERR_IO;
+    /* bytes left after the header: sizes the header (or a compressed block) claims beyond that are refused before
+       anything is allocated for them */
+    const std::streamoff data_pos = f.tellg();
+    f.seekg(0, std::ios::end);
+    const size_t remaining = (size_t)std::max<std::streamoff>(0, f.tellg() - data_pos);
+    f.seekg(data_pos);
     int off = 0, ix = -1, iy = -1, iz = -1;
     for (size_t i = 0; i < fields.size(); ++i) {
         fields[i].offset = off;
@@ -147,6 +153,9 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
         if (fields[i].name == "z") iz = (int)i;
     }
     if (ix < 0 || iy < 0 || iz < 0) return PPP_ERR_IO;
+    if (data_kind == "binary" && (points > remaining || (size_t)off * points > remaining)) return PPP_ERR_IO;
+    if (data_kind == "ascii" && points > remaining) return PPP_ERR_IO; /* a point takes at least one byte */
+    if (data_kind == "binary_compressed" && points > (size_t)1 << 40) return PPP_ERR_IO;
     float *out = (float *)malloc(sizeof(float) * 3 * std::max<size_t>(points, 1));
     if (!out) return PPP_ERR_IO;
     if (data_kind == "ascii") {
@@ -187,7 +196,7 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
         if (f.gcount() != 8) { free(out); return PPP_ERR_IO; }
         uint32_t csize, usize;
         memcpy(&csize, hdr, 4); memcpy(&usize, hdr + 4, 4);
-        if ((size_t)usize != (size_t)off * points) { free(out); return PPP_ERR_IO; }
+        if ((size_t)usize != (size_t)off * points || (size_t)csize + 8 > remaining) { free(out); return PPP_ERR_IO; }
         std::vector<unsigned char> comp(csize), raw(usize);
         f.read((char *)comp.data(), (std::streamsize)csize);
         if ((size_t)f.gcount() != (size_t)csize) { free(out); return PPP_ERR_IO; }
