@@ -67,7 +67,7 @@ typedef struct ppp_params {
     float  handeye[6];        /* HANDEYEx..rz (Path_Generate_Algorithm.h:43-48)               */
     float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
     int    smooth_max_sweeps; /* cap of the smoothing loop                   */
-    int    alignment;         /* Alignment / Smooth / RemoveOutlier: must be 0 (next rows)    */
+    int    alignment;         /* Alignment / Smooth: must be 0 (next rows); RemoveOutlier is ppp_remove_outlier */
     int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306 for the connect /
                                  connect1 walks, Path_Generation.cpp:362-634 for PPP_WALK_V1_CONTACT            */
     double depth;             /* depth            (config.txt:5)                              */
@@ -121,17 +121,18 @@ int ppp_gen_path_async(ppp_handle h);
  * reduceRPY, TransFlangeposition); the list stays in HBM. */
 int ppp_get_path_async(ppp_handle h);
 /* GenPath() followed by getPath() as ONE enqueue: the kernel sequence is captured into a hipGraph
- * the first time and replayed afterwards (one host call per workpiece instead of ~15 launches;
+ * the first time and replayed afterwards (one host call per workpiece instead of ~10 launches;
  * this is what keeps a batch of small workpieces from being host-launch-bound).  Falls back to
  * the two plain calls while kernel timing is enabled. */
 int ppp_run_async(ppp_handle h);
 /* Batched form (SURVEY.md 8b / BASELINE config 3: many small workpieces on ONE GPU): GenPath + getPath of
  * `count` handles of the same device as ONE hipGraph whose branches (one per handle) run side by side --
- * one host call per batch instead of one per workpiece.  When dst_dev is not NULL every branch ends by
- * copying its WayPointsList to dst_dev + 6 * offset_rows[i] (at most cap_rows[i] rows; a longer list is an
- * error of that handle), so the batch lands in one caller-owned device buffer (the RCCL send buffer)
- * without a host round trip.  The graph is cached in hs[0] and rebuilt when the handle list, a handle's
- * plan or the destination changes.  Follow with ppp_sync_batch (or any per-handle call, which waits). */
+ * one host call per batch instead of one per workpiece.  When dst_dev is not NULL every branch's last
+ * kernel also writes its WayPointsList to dst_dev + 6 * offset_rows[i] (at most cap_rows[i] rows; a longer
+ * list is an error of that handle), so the batch lands in one caller-owned device buffer (the RCCL send
+ * buffer) without a host round trip.  Graphs are cached in hs[0] (two: a caller may alternate between two
+ * destinations) and rebuilt when the handle list, a handle's plan or the destination changes.  Follow with
+ * ppp_sync_batch (or any per-handle call, which waits). */
 int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows);
 /* waits for the batch, returns the first handle's error (index in *failed when not NULL) */
 int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed);
