@@ -324,11 +324,14 @@ int make_plan(ppp_handle h)
             h->n_range = range > 0 ? (int)std::min((double)h->h_nvalid, std::max(0.0, part / range) * h->h_nvalid * 1.05 + 64) : h->h_nvalid;
         }
     }
-    /* x-slabs: ~640 points each so a slab sorts as 1024 keys; the histogram must fit LDS.  A slice-range handle
+    /* x-slabs: the histogram must fit LDS.  A slice-range handle
        keeps the WHOLE cloud's slab grid and just leaves the slabs outside its interval empty: its slabs then hold
        the same points in the same order as a whole-cloud handle's, so every sum over neighbours (normals) adds
        in the same order and the sharded list is bit-identical to the unsharded one. */
-    int B = (h->h_nvalid + 639) / 640;
+    /* 832 points per slab on average (measured: 640 .. 960 within 5 %, best here; from 1024 on the sort needs the
+       larger LDS block and loses occupancy) -- a slab 2.4 times denser than the mean still sorts in LDS */
+    const int SLAB_PTS = 832;
+    int B = (h->h_nvalid + SLAB_PTS - 1) / SLAB_PTS;
     B = std::max(1, std::min(B, 8192));
     h->B = B;
     {
