@@ -836,13 +836,13 @@ int ppp_gen_path_async(ppp_handle h)
 /* getPath's second half: postion_smooth, reduceRPY, TransFlangeposition (path_translation_alg.cpp:212-214) */
 int enqueue_finish(ppp_handle h, const DevParams &D)
 {
-    const int gw = std::max(1, (h->W_cap + 63) / 64);
+    const int gw = std::max(1, (h->W_cap + FIN_T - 1) / FIN_T);
     /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
     const int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
     for (int b = 0; b <= nb; ++b)
         LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
                h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
-    LAUNCH(h, "k_finish", k_finish, gw, 64, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p, h->out2, h->out2_cap);
+    LAUNCH(h, "k_finish", k_finish, gw, FIN_T, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p, h->out2, h->out2_cap);
     return enqueue_meta_copy(h);
 }
 

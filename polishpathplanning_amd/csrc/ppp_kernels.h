@@ -1488,8 +1488,12 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
    in LDS, so the binary searches and window scans are LDS reads instead of dependent HBM/L2
    round trips; anything outside the staged window falls back to the global copy (exactness
    never depends on the window). */
+#ifndef POSE_STAGE_CAP
 #define POSE_STAGE_CAP 5120
+#endif
+#ifndef POSE_PAD
 #define POSE_PAD 8.0f
+#endif
 __host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 12; }
 
 #ifndef POSE_T
@@ -1705,7 +1709,9 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* either continues from the last snapshot or emits the snapshot of the  */
 /* stop sweep.                                                           */
 /* ------------------------------------------------------------------ */
+#ifndef SM_K
 #define SM_K 16
+#endif
 #ifndef SM_D
 #define SM_D 8
 #endif
@@ -1998,7 +2004,10 @@ __device__ inline void finish_waypoints(const DevMeta *m, const DevParams &P, co
 /* The launch: finish_waypoints, then (batched form) the list's copy into the caller's buffer -- the pass ends without a
    separate copy-out launch.  (Also publishing the meta block from the last workgroup to retire, instead of the
    device-to-host blit that follows, was measured and is slower: ~400 same-address tickets + stores across PCIe.) */
-__global__ void __launch_bounds__(64) k_finish(DevMeta *m, DevParams P, const int *__restrict__ tail, const float *__restrict__ src,
+#ifndef FIN_T
+#define FIN_T 64
+#endif
+__global__ void __launch_bounds__(FIN_T) k_finish(DevMeta *m, DevParams P, const int *__restrict__ tail, const float *__restrict__ src,
                                                float *out, float *dst2, int cap2)
 {
     finish_waypoints(m, P, tail, src, out);
