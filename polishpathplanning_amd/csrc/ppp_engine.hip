@@ -69,7 +69,8 @@ struct ppp_handle_s {
 
     DevBuf<float> X, Y, Z;
     DevBuf<float4> unsorted4, sorted4;
-    DevBuf<int> slab_cnt, slab_start, slab_cursor;
+    DevBuf<int> slab_cnt, slab_start, slab_cursor, coarse_cursor;
+    bool two_pass_scatter = false; /* large clouds: coarse bins first (see k_slab_scatter) */
     DevBuf<float> slab_xmin, slab_xmax;
     DevBuf<DevMeta> meta;
     DevBuf<float> px, lo, hi;
@@ -122,7 +123,7 @@ struct ppp_handle_s {
     {
         (void)hipSetDevice(device);
         X.release(); Y.release(); Z.release(); unsorted4.release(); sorted4.release();
-        slab_cnt.release(); slab_start.release(); slab_cursor.release(); slab_xmin.release(); slab_xmax.release();
+        slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_xmin.release(); slab_xmax.release();
         meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
         normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
@@ -367,6 +368,9 @@ int make_plan(ppp_handle h)
 
     HIPCHK(h, h->unsorted4.ensure(n)); HIPCHK(h, h->sorted4.ensure(n));
     HIPCHK(h, h->slab_cnt.ensure(B)); HIPCHK(h, h->slab_start.ensure(B + 1)); HIPCHK(h, h->slab_cursor.ensure(B));
+    HIPCHK(h, h->coarse_cursor.ensure((B >> SCAT_COARSE_SHIFT) + 2));
+    /* one scatter pass leaves runs of chunk / B points: below ~4 points per run the second pass pays for itself */
+    h->two_pass_scatter = B >= 4096 && h->n_range >= 3000000;
     HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream)); /* every run leaves it cleared again */
     HIPCHK(h, h->slab_xmin.ensure(B)); HIPCHK(h, h->slab_xmax.ensure(B));
     HIPCHK(h, h->px.ensure(h->S_cap)); HIPCHK(h, h->lo.ensure(h->S_cap)); HIPCHK(h, h->hi.ensure(h->S_cap));
@@ -414,14 +418,29 @@ int enqueue_index(ppp_handle h)
         h->mm_grid_used = gf;
     }
     LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
-           h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p);
+           h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p, h->coarse_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
-    int chunk = SCAT_CHUNK;
-    while (chunk < 32768 && (n + chunk - 1) / chunk > 768) chunk <<= 1;
-    int gs = std::max(1, (n + chunk - 1) / chunk);
-    LAUNCH(h, "k_slab_scatter", k_slab_scatter, gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, chunk, h->meta.p,
-           h->slab_cursor.p, h->unsorted4.p);
+    /* points per scatter workgroup: every workgroup reserves its share of each slab with one global atomic per
+       non-empty (workgroup, slab) pair, so larger clouds use 8 instead of 4 points per thread */
+    const bool ppt8 = n > 1500000;
+    const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
+    const int gs = std::max(1, (n + chunk - 1) / chunk);
+    if (!h->two_pass_scatter) {
+        if (ppt8)
+            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 8>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
+                   h->slab_cursor.p, h->unsorted4.p);
+        else
+            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 4>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
+                   h->slab_cursor.p, h->unsorted4.p);
+    } else {
+        /* coarse bins into sorted4 (free until k_slab_sort writes it), then from there into the slabs */
+        LAUNCH(h, "k_slab_scatter", (k_slab_scatter<1, 8>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
+               h->coarse_cursor.p, h->sorted4.p);
+        const int gs2 = std::max(1, (n + 4 * SCAT_T - 1) / (4 * SCAT_T));
+        LAUNCH(h, "k_slab_scatter2", (k_slab_scatter<2, 4>), gs2, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)h->sorted4.p, n,
+               h->meta.p, h->slab_cursor.p, h->unsorted4.p);
+    }
     size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
     LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
            h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
@@ -654,7 +673,10 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_slice_kd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_minmax<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-    (void)hipFuncSetAttribute((const void *)k_slab_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
     (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -45,6 +45,7 @@ struct DevParams {
     float nn_hint2; /* (a few mean point spacings)^2: first search bound of the waypoints' 1-NN queries */
 };
 
+#define SCAT_COARSE_SHIFT 6 /* two-pass scatter of large clouds: 64 neighbouring slabs form a coarse bin */
 enum { DERR_NONE = 0, DERR_SLICE = 1, DERR_CAPACITY = 2, DERR_DOMAIN = 3, DERR_QUERY = 4, DERR_MARGIN = 5 };
 
 __device__ inline void set_err(DevMeta *m, int code, int slice)
@@ -237,7 +238,7 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
 __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
                                                float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
-                                               float slab_invw, int *slab_start, int *slab_cursor)
+                                               float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
 {
     __shared__ int s_scan[17];
     __shared__ float s_mn[3][4], s_mx[3][4];
@@ -271,6 +272,7 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
             if (b0 + k < B) {
                 int c = slab_cnt[b0 + k];
                 slab_start[b0 + k] = pre; slab_cursor[b0 + k] = pre;
+                if (coarse_cursor && ((b0 + k) & ((1 << SCAT_COARSE_SHIFT) - 1)) == 0) coarse_cursor[(b0 + k) >> SCAT_COARSE_SHIFT] = pre;
                 pre += c;
                 slab_cnt[b0 + k] = 0;
             }
@@ -344,41 +346,57 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
 #ifndef SCAT_T
 #define SCAT_T 1024
 #endif
-#ifndef SCAT_CHUNK
-#define SCAT_CHUNK 4096
-#endif
+/* LEVEL 0: the cloud straight into its slabs (one pass; the writes of a workgroup are runs of chunk / B points).
+   Large clouds have thousands of slabs and those runs shrink to a point or two -- 16-byte writes scattered over the
+   whole array.  They go in two passes instead: LEVEL 1 bins into COARSE groups of 64 neighbouring slabs (runs of
+   hundreds of points, written to `out4` = the sorted4 buffer used as scratch), LEVEL 2 reads that -- each chunk now
+   touches a few dozen slabs -- and bins into the slabs proper.  Same result as LEVEL 0 up to the order inside a slab,
+   which k_slab_sort fixes anyway. */
+/* Every thread keeps its PPT points in registers between the counting and the writing pass: the input is read once. */
+template <int LEVEL, int PPT>
 __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
-                                                      const float *__restrict__ Z, int n, int chunk, const DevMeta *m,
-                                                      int *slab_cursor, float4 *unsorted4)
+                                                      const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
+                                                      const DevMeta *m, int *cursor, float4 *out4)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
-    const int B = m->B;
+    const int B = LEVEL == 1 ? ((m->B + (1 << SCAT_COARSE_SHIFT) - 1) >> SCAT_COARSE_SHIFT) : m->B;
     const float xlo = m->incl_lo, xhi = m->incl_hi;
+    if (LEVEL == 2) n = m->n_sorted; /* the scratch holds the kept points only */
+    auto bin = [&](float x) { return LEVEL == 1 ? (slab_of(m, x) >> SCAT_COARSE_SHIFT) : slab_of(m, x); };
     STAMP_BEGIN();
+    /* this thread's points: i0 + threadIdx.x + k * blockDim.x (coalesced), requested before anything else */
+    const int i0 = blockIdx.x * (PPT * (int)blockDim.x);
+    float4 p[PPT];
+    int pb[PPT]; /* bin, or -1: not mine / dropped */
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = i0 + threadIdx.x + k * (int)blockDim.x;
+        pb[k] = -1;
+        if (i < n) {
+            if (LEVEL == 2) p[k] = in4[i];
+            else p[k] = make_float4(X[i], Y[i], Z[i], __int_as_float(i));
+        } else p[k] = make_float4(NAN, 0.f, 0.f, 0.f);
+    }
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
     STAMP(2, 0); /* zero */
-    const int i0 = blockIdx.x * chunk;
-    const int i1 = min(n, i0 + chunk);
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        float x = X[i];
-        if (x >= xlo && x <= xhi) atomicAdd(&s_hist[slab_of(m, x)], 1);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const float x = p[k].x;
+        const bool keep = LEVEL == 2 ? (i0 + (int)threadIdx.x + k * (int)blockDim.x < n) : (x >= xlo && x <= xhi); /* NaN fails both */
+        if (keep) { pb[k] = bin(x); atomicAdd(&s_hist[pb[k]], 1); }
     }
     __syncthreads();
     STAMP(2, 1); /* count */
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         int c = s_hist[b];
-        if (c) s_hist[b] = atomicAdd(&slab_cursor[b], c);
+        if (c) s_hist[b] = atomicAdd(&cursor[b], c);
     }
     __syncthreads();
     STAMP(2, 2); /* reserve (global atomics) */
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        float x = X[i];
-        if (x >= xlo && x <= xhi) {
-            int pos = atomicAdd(&s_hist[slab_of(m, x)], 1);
-            unsorted4[pos] = make_float4(x, Y[i], Z[i], __int_as_float(i));
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (pb[k] >= 0) out4[atomicAdd(&s_hist[pb[k]], 1)] = p[k];
     STAMP(2, 3); /* scatter */
 }
 
