@@ -442,10 +442,10 @@ int enqueue_index(ppp_handle h)
                h->meta.p, h->slab_cursor.p, h->unsorted4.p);
     }
     size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
-    LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, 256, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+    LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, SORT_T, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
            h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
     if (h->big_path)
-        LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, 256, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+        LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, SORT_T, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
                h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
     h->index_built = true;
     return PPP_OK;

@@ -404,13 +404,16 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict
    the cloud's y range --, then the exact x bounds of the slab.  ARENA = false: keys and histogram
    in LDS, slabs larger than `cap` are appended to a work list; ARENA = true: second pass over that
    list with the same code on a bump-allocated global arena (any slab size, slower). */
+#ifndef SORT_T
+#define SORT_T 512
+#endif
 template <bool ARENA>
-__global__ void __launch_bounds__(256) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
+__global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                    float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
                                                    int *big_list, char *arena, unsigned long long arena_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    __shared__ float s_mn[4], s_mx[4];
+    __shared__ float s_mn[SORT_T / 64], s_mx[SORT_T / 64];
     __shared__ int s_scr[17];
     __shared__ unsigned long long s_off;
     int b = blockIdx.x;
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(256) k_slab_sort(const float4 *__restrict__ un
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        for (int w = 1; w < SORT_T / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
         slab_xmin[b] = mn; slab_xmax[b] = mx;
     }
 }
