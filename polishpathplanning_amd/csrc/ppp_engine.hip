@@ -417,7 +417,7 @@ int enqueue_index(ppp_handle h)
                h->incl_lo, h->incl_hi);
         h->mm_grid_used = gf;
     }
-    LAUNCH(h, "k_setup", k_setup, 1, 256, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
+    LAUNCH(h, "k_setup", k_setup, 1, SETUP_T, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
            h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p, h->coarse_cursor.p);
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */

@@ -236,13 +236,14 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
 
 /* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
-__global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
+#define SETUP_T 1024
+__global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
                                                float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
                                                float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
 {
     __shared__ int s_scan[17];
-    __shared__ float s_mn[3][4], s_mx[3][4];
-    __shared__ int s_cnt[4];
+    __shared__ float s_mn[3][SETUP_T / 64], s_mx[3][SETUP_T / 64];
+    __shared__ int s_cnt[SETUP_T / 64];
     __shared__ int s_S, s_total, s_nfront, s_c;
     __shared__ float s_mid;
     __shared__ float s_front[4096];
@@ -283,11 +284,11 @@ __global__ void __launch_bounds__(256) k_setup(DevMeta *m, DevParams P, const Mi
     STAMP(5, 1); /* slab scan */
     if (threadIdx.x == 0) {
         int c = 0;
-        for (int w = 0; w < 4; ++w) c += s_cnt[w];
+        for (int w = 0; w < SETUP_T / 64; ++w) c += s_cnt[w];
         DevMeta r; /* built in registers, stored once: no dependent global round trips */
         for (int d = 0; d < 3; ++d) {
             float a = INFINITY, b = -INFINITY;
-            for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            for (int w = 0; w < SETUP_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
             /* getMinMax3D starts from +-FLT_MAX */
             r.mn[d] = c ? a : 3.402823466e+38f;
             r.mx[d] = c ? b : -3.402823466e+38f;
