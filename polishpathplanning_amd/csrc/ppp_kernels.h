@@ -236,7 +236,9 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
 
 /* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
+#ifndef SETUP_T
 #define SETUP_T 1024
+#endif
 __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
                                                float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
                                                float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
