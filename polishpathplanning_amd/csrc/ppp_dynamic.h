@@ -13,7 +13,9 @@
 #include "ppp_kernels.h"
 
 #define DYN_KNN_CAP 448   /* candidates a wave keeps while growing the search radius */
-#define DYN_WAVES 4       /* waves (= Area2Cloud evaluations) per workgroup          */
+#ifndef DYN_WAVES
+#define DYN_WAVES 4       /* waves (= Area2Cloud evaluations) per workgroup; 1, 2, 4 measure the same, 8 slower */
+#endif
 #define DYN_ELL 721       /* for (float angle = 0; angle <= 360; angle += 0.5)       */
 
 struct DynParams {

@@ -12,6 +12,10 @@ from polishpathplanning_amd import engine, synth  # noqa: E402
 
 
 def main():
+    if "--lib" in sys.argv:
+        i = sys.argv.index("--lib")
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     name = args[0] if args else "cfg2_1m_s256"
     walk = int(args[1]) if len(args) > 1 else 1
