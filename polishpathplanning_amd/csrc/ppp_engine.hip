@@ -55,6 +55,7 @@ struct ppp_handle_s {
     size_t n = 0;
     bool have_cloud = false, planned = false, index_built = false, gen_done = false, path_done = false;
     int max_lds = 65536;
+    int num_cus = 256;
 
     /* plan */
     int B = 1, slab_cap = 4096, S_cap = 1, capb = 2048, W_cap = 1, node_cap = 1;
@@ -667,8 +668,10 @@ int ppp_create(int device_id, ppp_handle *out)
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) h->max_lds = lds;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
-        h->max_lds = std::max(h->max_lds, 160 * 1024); /* CDNA4: one workgroup may own the CU's whole LDS */
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) h->max_lds = std::max(h->max_lds, 160 * 1024); /* CDNA4: one workgroup may own the CU's whole LDS */
+        if (prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+    }
     /* kernels with > 64 KiB of dynamic LDS opt in explicitly */
     (void)hipFuncSetAttribute((const void *)k_slice, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_slice_kd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
@@ -677,7 +680,8 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-    (void)hipFuncSetAttribute((const void *)k_smooth_batch, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void *)k_smooth_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(0));
+    (void)hipFuncSetAttribute((const void *)k_smooth_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(1));
     (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -861,9 +865,15 @@ int enqueue_finish(ppp_handle h, const DevParams &D)
     const int gw = std::max(1, (h->W_cap + FIN_T - 1) / FIN_T);
     /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
     const int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
-    for (int b = 0; b <= nb; ++b)
-        LAUNCH(h, "k_smooth_batch", k_smooth_batch, h->sm_tiles, SM_T, SM_LDS_BYTES, h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-               h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+    const bool wave_partials = h->sm_tiles > h->num_cus; /* more tiles than CUs: the small-LDS variant runs several per CU */
+    for (int b = 0; b <= nb; ++b) {
+        if (wave_partials)
+            LAUNCH(h, "k_smooth_batch", k_smooth_batch<true>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(1), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
+                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+        else
+            LAUNCH(h, "k_smooth_batch", k_smooth_batch<false>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(0), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
+                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+    }
     LAUNCH(h, "k_finish", k_finish, gw, FIN_T, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p, h->out2, h->out2_cap);
     return enqueue_meta_copy(h);
 }

@@ -1747,7 +1747,9 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 #define SM_HB ((SM_D + 1) * SM_K + 1)
 #define SM_OWN (SM_M - SM_HB - SM_K)
 #define SM_MAXS 512
-#define SM_LDS_BYTES (3 * SM_M * (8 + 4 + 4 + 4) + SM_K * SM_T * 8)
+/* LDS of a tile; WP (wave partials) keeps one |delta| sum per wave and sweep instead of one per thread */
+#define SM_LDS_BYTES_OF(WP) (3 * SM_M * (8 + 4 + 4 + 4) + SM_K * ((WP) ? SM_T / 64 : SM_T) * 8)
+#define SM_LDS_BYTES SM_LDS_BYTES_OF(0)
 
 __host__ __device__ inline int smooth_tiles(int W) { return W > 2 ? (W - 2 + SM_OWN - 1) / SM_OWN : 1; }
 /* snapshot set q (0/1), level k (1..SM_K), coordinate j: float[W_cap] */
@@ -1756,6 +1758,11 @@ __host__ __device__ inline size_t smooth_snap_off(int q, int k, int j, int W_cap
     return ((size_t)(q * SM_K + (k - 1)) * 3 + j) * (size_t)W_cap;
 }
 
+/* WP = false: every thread parks its |delta| sum of every sweep in LDS and the sums are reduced once per launch -- the
+   fastest sweep, but 64 KB of LDS: one workgroup per CU.  WP = true: a shuffle tree per sweep leaves one partial per
+   wave -- 0.3 us more per sweep, but 32 KB: lists with more tiles than the GPU has CUs run two to four tiles per CU
+   (10 M points: 112 -> 86 us).  The host picks by the tile count. */
+template <bool WP>
 __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, int b, int ntiles_cap, int W_cap,
                                                        const float *__restrict__ sx, float *snap, double *part, double *chist,
                                                        const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out)
@@ -1765,7 +1772,8 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
     float (*s_x)[SM_M] = (float (*)[SM_M])(s_raw + 3 * SM_M * 8);
     float (*s_a)[SM_M] = s_x + 3;
     float (*s_b)[SM_M] = s_a + 3;
-    double (*s_chg)[SM_T] = (double (*)[SM_T])(s_b + 3); /* per-thread |delta| sums of every sweep of the batch */
+    constexpr int CHW = WP ? SM_T / 64 : SM_T;
+    double (*s_chg)[CHW] = (double (*)[CHW])(s_b + 3); /* per-thread (or per-wave) |delta| sums of every sweep of the batch */
     __shared__ double s_change[SM_MAXS + 1];
     __shared__ int s_kstar;
     const int W = m->W;
@@ -1894,8 +1902,12 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
                 change += owned ? d2 : 0.0;
             }
         }
-        s_chg[k - 1][threadIdx.x] = change; /* reduced once, after the last sweep (a block reduction per
-                                               sweep cost more than the sweep itself) */
+        /* one partial per wave and sweep (a shuffle tree, no barrier; a block-wide reduction per sweep cost more than
+           the sweep itself, and one partial per THREAD made the tile too large for a second workgroup on the CU) */
+        if (WP) {
+            change = wave_sum(change);
+            if ((threadIdx.x & 63) == 0) s_chg[k - 1][threadIdx.x >> 6] = change;
+        } else s_chg[k - 1][threadIdx.x] = change;
         lds_barrier(); /* publishes nxt; the snapshot stores below stay in flight */
         STAMP(6, 2); /* run-up + own element */
         float (*t)[SM_M] = cur; cur = nxt; nxt = t;
@@ -1909,11 +1921,19 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
     /* per-sweep sums of this tile, fixed summation order: one wave per sweep */
     {
         const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int k = 1 + wid; k <= SM_K; k += nw) {
-            double c = 0;
-            for (int q = lane; q < SM_T; q += 64) c += s_chg[k - 1][q];
-            c = wave_sum(c);
-            if (lane == 0) part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
+        if (WP) {
+            for (int k = 1 + (int)threadIdx.x; k <= SM_K; k += blockDim.x) { /* the waves' partials in wave order */
+                double c = 0;
+                for (int w = 0; w < CHW; ++w) c += s_chg[k - 1][w];
+                part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
+            }
+        } else {
+            for (int k = 1 + wid; k <= SM_K; k += nw) { /* one wave per sweep */
+                double c = 0;
+                for (int q = lane; q < CHW; q += 64) c += s_chg[k - 1][q];
+                c = wave_sum(c);
+                if (lane == 0) part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
+            }
         }
     }
     STAMP(6, 4); /* per-sweep sums */
