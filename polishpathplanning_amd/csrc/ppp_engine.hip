@@ -414,7 +414,7 @@ int enqueue_index(ppp_handle h)
            cloud).  At most 256 workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
            that flush, not the streaming, is what grows with the grid. */
         const int gf = std::max(1, std::min(h->mm_grid, 256));
-        LAUNCH(h, "k_minmax", k_minmax<true>, gf, 256, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
+        LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
                h->incl_lo, h->incl_hi);
         h->mm_grid_used = gf;
     }
@@ -594,7 +594,7 @@ int refresh_bounds_and_plan(ppp_handle h)
         int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
         HIPCHK(h, h->mm_part.ensure(g));
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(256), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
+        hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
                            (int *)nullptr, 0.f, 0.f);
         HIPCHK(h, hipGetLastError());
         std::vector<MinMaxPart> parts(g);

@@ -97,8 +97,11 @@ __device__ inline int slab_of_grid(float x, float x0, float invw, int B)
     b = b < 0 ? 0 : b;
     return b >= B ? B - 1 : b;
 }
+#ifndef MM_T
+#define MM_T 512
+#endif
 template <bool HIST>
-__global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
+__global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
                                                 const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
                                                 int B, int *slab_cnt, float xlo, float xhi)
 {
@@ -143,8 +146,8 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
             if (c) atomicAdd(&slab_cnt[b], c);
         }
     }
-    __shared__ float s_mn[3][4], s_mx[3][4];
-    __shared__ int s_cnt[4];
+    __shared__ float s_mn[3][MM_T / 64], s_mx[3][MM_T / 64];
+    __shared__ int s_cnt[MM_T / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
     cnt = wave_sum(cnt);
@@ -153,10 +156,10 @@ __global__ void __launch_bounds__(256) k_minmax(const float *__restrict__ X, con
     if (threadIdx.x == 0) {
         MinMaxPart r;
         r.cnt = 0; r.pad = 0;
-        for (int w = 0; w < 4; ++w) r.cnt += s_cnt[w];
+        for (int w = 0; w < MM_T / 64; ++w) r.cnt += s_cnt[w];
         for (int d = 0; d < 3; ++d) {
             float a = INFINITY, b = -INFINITY;
-            for (int w = 0; w < 4; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            for (int w = 0; w < MM_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
             r.mn[d] = a; r.mx[d] = b;
         }
         part[blockIdx.x] = r;
