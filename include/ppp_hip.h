@@ -136,6 +136,14 @@ int ppp_run_async(ppp_handle h);
 int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows);
 /* waits for the batch, returns the first handle's error (index in *failed when not NULL) */
 int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed);
+/* Multi-GPU exchange of the finished lists: variable-length gather to `root` over RCCL.  Rank r
+ * contributes the counts_rows[r] rows of its WayPointsList; on root, recv_dev (device memory, sum(counts) x 6 floats)
+ * receives the blocks back to back in rank order.  One ncclGroup of direct ncclSend / ncclRecv pairs -- point to point
+ * over xGMI, no ring -- on the handle's stream (asynchronous; ppp_sync afterwards).  nccl_comm is the caller's
+ * ncclComm_t (one rank per process / GPU); librccl is looked up at the first call (dlopen), the engine itself does not
+ * link it.  Frameworks that own the communicator (torch.distributed) use their own collective on the list's device
+ * pointer instead -- polishpathplanning_amd/robot_path.py. */
+int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, int root, const size_t *counts_rows, float *recv_dev);
 /* the handle's HIP stream (hipStream_t), so a framework can order its own work after the planner's on the GPU
  * (e.g. torch.cuda.ExternalStream + wait_stream before the RCCL gather) instead of waiting on the host */
 int ppp_get_stream(ppp_handle h, void **stream);

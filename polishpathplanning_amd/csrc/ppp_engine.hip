@@ -11,6 +11,7 @@
 #include "ppp_preproc.h"
 #include "../../include/ppp_hip.h"
 
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -1050,6 +1051,68 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         h->meta_in_flight = true;
         h->pending_stream = (i == 0) ? nullptr : lead->stream;
     }
+    return PPP_OK;
+}
+
+extern "C++" {
+namespace {
+/* librccl, looked up on first use: the engine does not link it (a process that already carries a framework's RCCL
+   gets that one back from dlopen) */
+struct Rccl {
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    bool ok = false;
+};
+const Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return x;
+        x.group_start = (int (*)())dlsym(lib, "ncclGroupStart");
+        x.group_end = (int (*)())dlsym(lib, "ncclGroupEnd");
+        x.send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclSend");
+        x.recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclRecv");
+        x.ok = x.group_start && x.group_end && x.send && x.recv;
+        return x;
+    }();
+    return r;
+}
+} // namespace
+} // extern "C++"
+
+int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, int root, const size_t *counts_rows, float *recv_dev)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks || !counts_rows) return fail(h, PPP_ERR_ARG, "bad rank / root / counts");
+    if (!h->path_done || !h->list_final) return fail(h, PPP_ERR_ARG, "no finished list on this handle (call ppp_get_path_async / ppp_run_async first)");
+    if (counts_rows[rank] > (size_t)h->W_cap) return fail(h, PPP_ERR_CAPACITY, "counts_rows[rank] exceeds this handle's list capacity");
+    if (rank == root && !recv_dev) return fail(h, PPP_ERR_ARG, "the root needs a receive buffer");
+    const int kFloat = 7; /* ncclFloat32 */
+    if (nranks == 1) { /* nothing to exchange: the list goes to the receive buffer */
+        if (counts_rows[0]) HIPCHK(h, hipMemcpyAsync(recv_dev, h->wp_out.p, counts_rows[0] * 24, hipMemcpyDeviceToDevice, h->stream));
+        return PPP_OK;
+    }
+    if (!nccl_comm) return fail(h, PPP_ERR_ARG, "nccl_comm is NULL");
+    const Rccl &R = rccl();
+    if (!R.ok) return fail(h, PPP_ERR_UNSUPPORTED, "librccl.so not found (ncclGroupStart / ncclSend / ncclRecv)");
+    int e = R.group_start();
+    if (e) return fail(h, PPP_ERR_HIP, "ncclGroupStart failed");
+    if (rank == root) {
+        size_t off = 0;
+        for (int r = 0; r < nranks && !e; ++r) {
+            if (r == root) { if (counts_rows[r]) HIPCHK(h, hipMemcpyAsync(recv_dev + 6 * off, h->wp_out.p, counts_rows[r] * 24, hipMemcpyDeviceToDevice, h->stream)); }
+            else if (counts_rows[r]) e = R.recv(recv_dev + 6 * off, counts_rows[r] * 6, kFloat, r, nccl_comm, h->stream);
+            off += counts_rows[r];
+        }
+    } else if (counts_rows[rank]) e = R.send(h->wp_out.p, counts_rows[rank] * 6, kFloat, root, nccl_comm, h->stream);
+    const int e2 = R.group_end();
+    if (e || e2) return fail(h, PPP_ERR_HIP, "RCCL send / recv failed (ncclResult " + std::to_string(e ? e : e2) + ")");
     return PPP_OK;
 }
 

@@ -77,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_get_cloud", "ppp_remove_outlier", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -130,6 +130,7 @@ def lib():
         L.ppp_run_batch_async.argtypes = [C.POINTER(vp), sz, vp, szp, szp]
         L.ppp_sync_batch.argtypes = [C.POINTER(vp), sz, szp]
         L.ppp_get_stream.argtypes = [vp, C.POINTER(vp)]
+        L.ppp_gather_waypoints.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, szp, vp]
         L.ppp_get_cloud.argtypes = [vp, fp, sz, szp]
         L.ppp_remove_outlier.argtypes = [vp, C.c_int, C.c_double, szp, C.POINTER(C.c_double)]
         L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
@@ -373,6 +374,11 @@ class Engine:
         thr = C.c_double()
         self._chk(self.L.ppp_remove_outlier(self.h, int(mean_k), float(stddev_mul), C.byref(n), C.byref(thr)))
         return n.value, thr.value
+
+    def gather_waypoints(self, comm_ptr, rank, nranks, root, counts, recv_ptr):
+        """ppp_gather_waypoints: the finished lists of all ranks to `root` over RCCL (comm_ptr = ncclComm_t)."""
+        c = (C.c_size_t * nranks)(*[int(x) for x in counts])
+        self._chk(self.L.ppp_gather_waypoints(self.h, C.c_void_p(comm_ptr), rank, nranks, root, c, C.c_void_p(recv_ptr)))
 
     def stream_ptr(self):
         """hipStream_t of this handle as an integer (torch.cuda.ExternalStream(ptr) orders framework work behind it)."""

@@ -785,3 +785,21 @@ def test_batch_with_mixed_members_and_a_failing_one(engine_mod):
                 assert e.waypoints().tobytes() == want[i].tobytes()
     got = buf.to_host(sum(ws) * 6)
     assert got.tobytes() == np.concatenate([w for w in want if not isinstance(w, int)]).tobytes()
+
+
+def test_gather_waypoints_single_rank_and_argument_checks(engine_mod):
+    """ppp_gather_waypoints with one rank is a device copy of the list into the receive buffer (the send/recv path
+    needs several GPUs and is the driver's to run); bad arguments come back as errors."""
+    pts, cfg = synth.make_config("small_40k")
+    e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path(); W = e.get_path()
+    buf = _DeviceBuffer(W * 24)
+    e.gather_waypoints(0, 0, 1, 0, [W], buf.ptr)
+    e.sync()
+    assert buf.to_host(W * 6).tobytes() == e.waypoints().tobytes()
+    with pytest.raises(engine_mod.PPPError):
+        e.gather_waypoints(0, 1, 2, 0, [W, W], buf.ptr)      # two ranks but no communicator
+    with pytest.raises(engine_mod.PPPError):
+        e.gather_waypoints(0, 0, 1, 0, [10 ** 9], buf.ptr)   # more rows than the list can hold
+    r = engine_mod.Engine(0, tool_radius=6.0, slice_begin=2, slice_end=5); r.set_cloud(pts); r.gen_path(); r.get_path()
+    with pytest.raises(engine_mod.PPPError):
+        r.gather_waypoints(0, 0, 1, 0, [1], buf.ptr)         # a slice-range handle has no finished list
