@@ -89,6 +89,16 @@ def one_case(rng, i, only=None, verbose=False, big=None):
             kw["depth"] = float(rng2.choice([0.005, 0.01, 0.02]))
             kw["toolthickness"] = float(rng2.choice([5.0, 10.0]))
     sor = rng2.random() < 0.1
+    if os.environ.get("PPP_FUZZ_ODD") == "1":             # unusual but legal parameters
+        kw["tool_radius"] = float(rng2.choice([1.0, 1.5, 2.0, 2.6, 3.3, 25.0, 40.0]))   # steps of 2 .. 6 mm: the 4 mm bands overlap
+        kw["path_resolution"] = float(rng2.choice([0.5, 1.0, 2.5, 11.0, 30.0]))
+        kw["rpy_resolution"] = float(rng2.choice([0.0, 1.0, 2.0, 2.5, 3.0, 15.0]))
+        kw["trim"] = float(rng2.choice([0.0, 1.0, 5.0, 10.0, 20.0]))
+        kw["smooth_max_sweeps"] = int(rng2.choice([1, 2, 16, 17, 32, 33, 64]))
+        desc = "odd R %.1f res %.1f rpy %.1f trim %.0f sweeps %d | " % (kw["tool_radius"], kw["path_resolution"], kw["rpy_resolution"], kw["trim"],
+                                                                      kw["smooth_max_sweeps"])
+    else:
+        desc = ""
     unit = 1.0
     if rng2.random() < 0.1:                               # ChangeRange = false: the file is already in millimetres
         pts = pts * np.float32(1000.0)
@@ -96,13 +106,14 @@ def one_case(rng, i, only=None, verbose=False, big=None):
         unit = 1000.0
         if viewpoint is not None:
             viewpoint = [0.0, 0.0, 3000.0]
-    desc = "case %d: %s %dx%d amp %.1f R %.1f walk %d pairing %d dyn %d res %.1f rpy %.0f trim %.0f smooth %d n %d" % (
+    desc0 = "case %d: %s %dx%d amp %.1f R %.1f walk %d pairing %d dyn %d res %.1f rpy %.0f trim %.0f smooth %d n %d" % (
         i, kind, nx, ny, amp, R, walk, pairing, dyn, kw["path_resolution"], kw["rpy_resolution"], kw["trim"], kw["smooth"], len(pts))
     if only is not None and i != only:
         return None, "skipped"
     if verbose:
         np.save("gpurun_out/fuzz_case_%d.npy" % i, pts)
         print(kw)
+    desc = desc + desc0
     okw = dict(kw)
     if viewpoint is not None:
         okw["viewpoint"] = viewpoint
