@@ -28,7 +28,7 @@ public:
     ~path_generater() {}
 
     void show() { planner.show_notice(); }
-    void voxel_down(const float, const float, const float) { note("voxel_down"); }
+    void voxel_down(const float x, const float y, const float z) { planner.voxel_down(x, y, z); } /* Path_Generation.cpp:53-59 */
     void trans2center() { note("trans2center"); }
     void smooth() { note("smooth"); }
     void Set_kdtree() {}

@@ -111,6 +111,17 @@ int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n);
  * new indices), the plan is rebuilt.  n_kept / threshold (mean + mul * stddev of the per-point mean neighbour
  * distances) are optional outputs.  mean_k <= 63. */
 int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_kept, double *threshold);
+/* path_generater::voxel_down(x, y, z) (Path_Generation.cpp:53-59): pcl::VoxelGrid, setLeafSize(x, y, z), sor.filter(*cloud)
+ * with the class defaults: one point per occupied voxel (float centroid of its points), in ascending voxel id; replaces
+ * the resident cloud, the plan is rebuilt.  Leaf sizes in the cloud's units (mm after ChangeRange).  *overflow = 1 and
+ * the cloud is left as it is where PCL warns "Leaf size is too small ... Integer indices would overflow". */
+int ppp_voxel_down(ppp_handle h, float leaf_x, float leaf_y, float leaf_z, size_t *n_out, int *overflow);
+/* SectPath::smooth() (path_slicing_alg.cpp:111-139; v1 Path_Generation.cpp:340-360): pcl::MovingLeastSquares with
+ * setPolynomialOrder(order = 3), setSearchRadius(search_radius = 15), SIMPLE projection, no upsampling; the projected
+ * points replace the resident cloud (points with fewer than 3 neighbours in the radius, and non-finite points, are
+ * not in the output), the plan is rebuilt.  Radius in the cloud's units (mm after ChangeRange); order 0..3 (0 and 1:
+ * projection on the local plane only).  The "smooth_<name>" PCD side file of the reference is the caller's to write. */
+int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out);
 
 /* ---- whole hot path, asynchronous on the handle's stream ---- */
 /* GenPath(): getMinMax3D + slice walk + rangedX_index + insert_point + Spline for every

@@ -87,6 +87,14 @@ public:
         int rc = ppp_remove_outlier(h_, mean_k, stddev_mul, &n, nullptr);
         return rc == PPP_OK ? true : report(rc);
     }
+    bool voxel_down(float lx, float ly, float lz)
+    {
+        if (!ok()) return false;
+        int overflow = 0;
+        int rc = ppp_voxel_down(h_, lx, ly, lz, nullptr, &overflow);
+        if (rc == PPP_OK && overflow) std::fprintf(stderr, "[pcl::VoxelGrid::applyFilter] Leaf size is too small for the input dataset. Integer indices would overflow.\n");
+        return rc == PPP_OK ? true : report(rc);
+    }
     bool apply_params()
     {
         int rc = ppp_set_params(h_, &cfg_.params);

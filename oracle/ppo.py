@@ -71,6 +71,8 @@ def lib():
         L.ppo_num_points.argtypes = [vp]
         L.ppo_get_points.argtypes = [vp, fp]
         L.ppo_remove_outlier.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_double), fp]
+        L.ppo_voxel_down.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int)]
+        L.ppo_smooth_mls.argtypes = [vp, C.c_double, C.c_int]
         L.ppo_minmax.argtypes = [vp, fp, fp]
         L.ppo_slice_positions.argtypes = [vp, fp, C.c_int]
         L.ppo_ranged_x_index.argtypes = [vp, C.c_int, ip, C.c_int]
@@ -279,6 +281,21 @@ class Oracle:
         if rc >= 0:
             self.n = rc
         return rc, thr.value, dist[:n0]
+
+    def voxel_down(self, lx, ly, lz):
+        """path_generater::voxel_down; returns (new size, overflow flag)"""
+        ov = C.c_int()
+        rc = self.L.ppo_voxel_down(self.h, float(lx), float(ly), float(lz), C.byref(ov))
+        if rc >= 0:
+            self.n = rc
+        return rc, bool(ov.value)
+
+    def smooth_mls(self, radius=15.0, order=3):
+        """SectPath::smooth (pcl::MovingLeastSquares); returns the new size"""
+        rc = self.L.ppo_smooth_mls(self.h, float(radius), int(order))
+        if rc >= 0:
+            self.n = rc
+        return rc
 
     def knn(self, q, k):
         q = np.ascontiguousarray(q, np.float32)

@@ -32,6 +32,8 @@
 
 #include <algorithm>
 #include <array>
+#include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -347,6 +349,71 @@ void eigen33_smallest(const float cov[9], float *eigenvalue, float ev[3])
     float len[3];
     for (int i = 0; i < 3; ++i) len[i] = std::sqrt(cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1] + cp[i][2] * cp[i][2]);
     int idx = 0; /* maxCoeff: first maximum */
+    if (len[1] > len[idx]) idx = 1;
+    if (len[2] > len[idx]) idx = 2;
+    for (int d = 0; d < 3; ++d) ev[d] = cp[idx][d] / len[idx];
+}
+
+/* the same pcl::eigen33 path with Scalar = double (pcl::MLSResult::computeMLSSurface calls it on a Matrix3d) */
+void compute_roots2_d(double b, double c, double roots[3])
+{
+    roots[0] = 0.0;
+    double d = b * b - 4.0 * c;
+    if (d < 0.0) d = 0.0;
+    double sd = std::sqrt(d);
+    roots[2] = 0.5 * (b + sd);
+    roots[1] = 0.5 * (b - sd);
+}
+void compute_roots_d(const double m[3][3], double roots[3])
+{
+    double c0 = m[0][0] * m[1][1] * m[2][2] + 2.0 * m[0][1] * m[0][2] * m[1][2] -
+                m[0][0] * m[1][2] * m[1][2] - m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+    double c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] +
+                m[1][1] * m[2][2] - m[1][2] * m[1][2];
+    double c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::abs(c0) < std::numeric_limits<double>::epsilon()) { compute_roots2_d(c2, c1, roots); return; }
+    const double s_inv3 = 1.0 / 3.0, s_sqrt3 = std::sqrt(3.0);
+    double c2_over_3 = c2 * s_inv3;
+    double a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0) a_over_3 = 0.0;
+    double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+    double q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0) q = 0.0;
+    double rho = std::sqrt(-a_over_3);
+    double theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
+    double cos_theta = std::cos(theta), sin_theta = std::sin(theta);
+    roots[0] = c2_over_3 + 2.0 * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    if (roots[1] >= roots[2]) {
+        std::swap(roots[1], roots[2]);
+        if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    }
+    if (roots[0] <= 0) compute_roots2_d(c2, c1, roots);
+}
+void eigen33_smallest_d(const double cov[9], double *eigenvalue, double ev[3])
+{
+    double scale = 0.0;
+    for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(cov[i]));
+    if (scale <= std::numeric_limits<double>::min()) scale = 1.0;
+    double m[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = cov[3 * i + j] / scale;
+    double roots[3];
+    compute_roots_d(m, roots);
+    *eigenvalue = roots[0] * scale;
+    m[0][0] -= roots[0]; m[1][1] -= roots[0]; m[2][2] -= roots[0];
+    double cp[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const double *a = m[k == 2 ? 1 : 0], *b = m[k == 0 ? 1 : 2];
+        cp[k][0] = a[1] * b[2] - a[2] * b[1];
+        cp[k][1] = a[2] * b[0] - a[0] * b[2];
+        cp[k][2] = a[0] * b[1] - a[1] * b[0];
+    }
+    double len[3];
+    for (int i = 0; i < 3; ++i) len[i] = std::sqrt(cp[i][0] * cp[i][0] + cp[i][1] * cp[i][1] + cp[i][2] * cp[i][2]);
+    int idx = 0;
     if (len[1] > len[idx]) idx = 1;
     if (len[2] > len[idx]) idx = 2;
     for (int d = 0; d < 3; ++d) ev[d] = cp[idx][d] / len[idx];
@@ -1051,6 +1118,201 @@ struct ppo_handle {
     double sor_threshold = 0;
     std::vector<float> sor_distances;
 
+    /* path_generater::voxel_down (Path_Generation.cpp:53-59): pcl::VoxelGrid<pcl::PointXYZRGB>, setLeafSize(x, y, z),
+       filter(*cloud) -- PCL filters/impl/voxel_grid.hpp applyFilter with the class defaults (no filter field,
+       downsample_all_data_ = true -> CentroidPoint, min_points_per_voxel_ = 0).  PCL orders the (voxel id, point index)
+       pairs by id alone with an unstable sort (std::sort in 1.10, boost integer_sort from 1.11), so the order of the float
+       additions inside a voxel is an artefact of that sort; this restatement adds in ascending point index.
+       Returns the new size; *overflow = 1 and the cloud unchanged where PCL warns that the indices would overflow. */
+    int voxel_down(float lx, float ly, float lz, int *overflow)
+    {
+        *overflow = 0;
+        const float inv[3] = {1.0f / lx, 1.0f / ly, 1.0f / lz}; /* inverse_leaf_size_ = Array4f::Ones() / leaf_size_ */
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        size_t finite = 0;
+        for (const Pt &p : cloud) { /* getMinMax3D, skipping non-finite points */
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            const float c[3] = {p.x, p.y, p.z};
+            for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
+            ++finite;
+        }
+        if (cloud.empty()) return 0;
+        if (!finite) { cloud.clear(); invalidate(); return 0; }
+        long long dxyz = 1, cells = 1;
+        int min_b[3], div_b[3];
+        for (int d = 0; d < 3; ++d) {
+            dxyz *= static_cast<long long>((mx[d] - mn[d]) * inv[d]) + 1;
+            min_b[d] = static_cast<int>(std::floor(mn[d] * inv[d]));
+            const int max_b = static_cast<int>(std::floor(mx[d] * inv[d]));
+            div_b[d] = max_b - min_b[d] + 1;
+            cells *= div_b[d];
+            /* PCL tests dx*dy*dz only; div_b can be one larger per axis, and its product is what the int id is built from */
+            if (dxyz > INT_MAX || cells > INT_MAX || dxyz <= 0 || cells <= 0) { *overflow = 1; return (int)cloud.size(); }
+        }
+        const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};
+        std::vector<std::pair<unsigned, unsigned>> iv;
+        iv.reserve(finite);
+        for (size_t i = 0; i < cloud.size(); ++i) {
+            const Pt &p = cloud[i];
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            const int i0 = static_cast<int>(std::floor(p.x * inv[0]) - static_cast<float>(min_b[0]));
+            const int i1 = static_cast<int>(std::floor(p.y * inv[1]) - static_cast<float>(min_b[1]));
+            const int i2 = static_cast<int>(std::floor(p.z * inv[2]) - static_cast<float>(min_b[2]));
+            iv.emplace_back(static_cast<unsigned>(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]), (unsigned)i);
+        }
+        std::stable_sort(iv.begin(), iv.end(), [](const std::pair<unsigned, unsigned> &a, const std::pair<unsigned, unsigned> &b) { return a.first < b.first; });
+        std::vector<Pt> out;
+        for (size_t a = 0; a < iv.size();) {
+            size_t b = a;
+            float sx = 0.f, sy = 0.f, sz = 0.f; /* AccumulatorXYZ: Eigen::Vector3f xyz += point; get: xyz / n */
+            while (b < iv.size() && iv[b].first == iv[a].first) { const Pt &p = cloud[iv[b].second]; sx += p.x; sy += p.y; sz += p.z; ++b; }
+            const float c = static_cast<float>(b - a);
+            Pt q = cloud[iv[a].second];
+            q.x = sx / c; q.y = sy / c; q.z = sz / c;
+            out.push_back(q);
+            a = b;
+        }
+        cloud.swap(out);
+        invalidate();
+        return (int)cloud.size();
+    }
+    /* SectPath::smooth (path_slicing_alg.cpp:111-139; v1 Path_Generation.cpp:340-360): pcl::MovingLeastSquares with
+       setPolynomialOrder(3), setSearchRadius(15), the default SIMPLE projection and no upsampling; the result replaces
+       the cloud (copyPointCloud).  PCL surface/include/pcl/surface/impl/mls.hpp (1.10 - 1.12): process ->
+       performProcessing -> computeMLSPointNormal -> MLSResult::computeMLSSurface + projectQueryPoint(SIMPLE).
+       Points with fewer than 3 neighbours in the radius (and non-finite points, whose search returns nothing) are not
+       in the output.  All arithmetic in double on the float coordinates.  Returns the new size. */
+    int smooth_mls(double search_radius, int order)
+    {
+        rebuild_tree();
+        const int nr_coeff = (order + 1) * (order + 2) / 2;
+        const double sqr_gauss = search_radius * search_radius;
+        std::vector<Pt> out;
+        out.reserve(cloud.size());
+        std::vector<std::pair<float, int>> nb;
+        std::vector<double> P, A, wv, fv;
+        for (size_t i = 0; i < cloud.size(); ++i) {
+            const Pt &qp = cloud[i];
+            if (!std::isfinite(qp.x) || !std::isfinite(qp.y) || !std::isfinite(qp.z)) continue;
+            tree.radius(&qp.x, (float)search_radius, nb); /* sorted by distance; the point itself first */
+            if (nb.size() < 3) continue;
+            const int nn = (int)nb.size();
+            /* computeMeanAndCovarianceMatrix<PointT, double> (PCL 1.12: shifted by the first neighbour) */
+            const Pt &K0 = cloud[nb[0].second];
+            const double K[3] = {K0.x, K0.y, K0.z};
+            double accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (auto &e : nb) {
+                const Pt &c = cloud[e.second];
+                const double x = c.x - K[0], y = c.y - K[1], z = c.z - K[2];
+                accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
+                accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
+                accu[6] += x; accu[7] += y; accu[8] += z;
+            }
+            for (int k = 0; k < 9; ++k) accu[k] /= (double)nn;
+            const double centroid[3] = {accu[6] + K[0], accu[7] + K[1], accu[8] + K[2]};
+            double cov[9];
+            cov[0] = accu[0] - accu[6] * accu[6];
+            cov[1] = accu[1] - accu[6] * accu[7];
+            cov[2] = accu[2] - accu[6] * accu[8];
+            cov[4] = accu[3] - accu[7] * accu[7];
+            cov[5] = accu[4] - accu[7] * accu[8];
+            cov[8] = accu[5] - accu[8] * accu[8];
+            cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+            double ev, n[3];
+            eigen33_smallest_d(cov, &ev, n);
+            const double q[3] = {qp.x, qp.y, qp.z};
+            Pt o = qp;
+            if (!std::isfinite(n[0]) || !std::isfinite(n[1]) || !std::isfinite(n[2])) { out.push_back(o); continue; } /* mean = query_point */
+            const double d4 = -1 * (n[0] * centroid[0] + n[1] * centroid[1] + n[2] * centroid[2]);
+            const double distance = (q[0] * n[0] + q[1] * n[1] + q[2] * n[2]) + d4;
+            const double mean[3] = {q[0] - distance * n[0], q[1] - distance * n[1], q[2] - distance * n[2]};
+            double res[3] = {mean[0], mean[1], mean[2]};
+            if (order > 1 && nn >= nr_coeff) {
+                /* v_axis = plane_normal.unitOrthogonal(); u_axis = plane_normal.cross(v_axis)  (Eigen OrthoMethods.h) */
+                double va[3], ua[3];
+                const double prec = 1e-12; /* NumTraits<double>::dummy_precision() */
+                if (!(std::abs(n[0]) <= std::abs(n[2]) * prec) || !(std::abs(n[1]) <= std::abs(n[2]) * prec)) {
+                    const double invnm = 1.0 / std::sqrt(n[0] * n[0] + n[1] * n[1]);
+                    va[0] = -n[1] * invnm; va[1] = n[0] * invnm; va[2] = 0;
+                } else {
+                    const double invnm = 1.0 / std::sqrt(n[1] * n[1] + n[2] * n[2]);
+                    va[0] = 0; va[1] = -n[2] * invnm; va[2] = n[1] * invnm;
+                }
+                ua[0] = n[1] * va[2] - n[2] * va[1];
+                ua[1] = n[2] * va[0] - n[0] * va[2];
+                ua[2] = n[0] * va[1] - n[1] * va[0];
+                P.assign((size_t)nr_coeff * nn, 0.0); wv.assign(nn, 0.0); fv.assign(nn, 0.0);
+                for (int ni = 0; ni < nn; ++ni) {
+                    const Pt &c = cloud[nb[ni].second];
+                    const double dm[3] = {c.x - mean[0], c.y - mean[1], c.z - mean[2]};
+                    wv[ni] = std::exp(-(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]) / sqr_gauss); /* computeMLSWeight */
+                    const double u_coord = dm[0] * ua[0] + dm[1] * ua[1] + dm[2] * ua[2];
+                    const double v_coord = dm[0] * va[0] + dm[1] * va[1] + dm[2] * va[2];
+                    fv[ni] = dm[0] * n[0] + dm[1] * n[1] + dm[2] * n[2];
+                    int j = 0;
+                    double u_pow = 1;
+                    for (int ui = 0; ui <= order; ++ui) {
+                        double v_pow = 1;
+                        for (int vi = 0; vi <= order - ui; ++vi) { P[(size_t)(j++) * nn + ni] = u_pow * v_pow; v_pow *= v_coord; }
+                        u_pow *= u_coord;
+                    }
+                }
+                /* P_weight = P * w.asDiagonal(); P_weight_Pt = P_weight * P^T; c_vec = P_weight * f_vec
+                   (Eigen's blocked products group the additions differently: last-bit differences in double) */
+                A.assign((size_t)nr_coeff * nr_coeff, 0.0);
+                std::vector<double> c(nr_coeff, 0.0);
+                for (int a = 0; a < nr_coeff; ++a) {
+                    for (int b = 0; b < nr_coeff; ++b) {
+                        double sum = 0;
+                        for (int ni = 0; ni < nn; ++ni) sum += (P[(size_t)a * nn + ni] * wv[ni]) * P[(size_t)b * nn + ni];
+                        A[(size_t)a * nr_coeff + b] = sum;
+                    }
+                    double sum = 0;
+                    for (int ni = 0; ni < nn; ++ni) sum += (P[(size_t)a * nn + ni] * wv[ni]) * fv[ni];
+                    c[a] = sum;
+                }
+                /* P_weight_Pt.llt().solveInPlace(c_vec): Eigen's unblocked LLT (size < 32) on the lower triangle; on a
+                   non-positive pivot it stops and the solve runs on what is there (Eigen does not check info()) */
+                const int N = nr_coeff;
+                for (int k = 0; k < N; ++k) {
+                    double x = A[(size_t)k * N + k];
+                    for (int j = 0; j < k; ++j) x -= A[(size_t)k * N + j] * A[(size_t)k * N + j];
+                    if (x <= 0.0) break;
+                    A[(size_t)k * N + k] = x = std::sqrt(x);
+                    for (int r = k + 1; r < N; ++r) {
+                        double t = A[(size_t)r * N + k];
+                        for (int j = 0; j < k; ++j) t -= A[(size_t)r * N + j] * A[(size_t)k * N + j];
+                        A[(size_t)r * N + k] = t / x;
+                    }
+                }
+                for (int r = 0; r < N; ++r) { /* L y = c */
+                    double t = c[r];
+                    for (int j = 0; j < r; ++j) t -= A[(size_t)r * N + j] * c[j];
+                    c[r] = t / A[(size_t)r * N + r];
+                }
+                for (int r = N - 1; r >= 0; --r) { /* L^T x = y */
+                    double t = c[r];
+                    for (int j = r + 1; j < N; ++j) t -= A[(size_t)j * N + r] * c[j];
+                    c[r] = t / A[(size_t)r * N + r];
+                }
+                if (std::isfinite(c[0])) { /* projectQueryPoint, SIMPLE: mean + c_vec[0] * plane_normal */
+                    res[0] = mean[0] + c[0] * n[0]; res[1] = mean[1] + c[0] * n[1]; res[2] = mean[2] + c[0] * n[2];
+                }
+            }
+            o.x = static_cast<float>(res[0]); o.y = static_cast<float>(res[1]); o.z = static_cast<float>(res[2]);
+            out.push_back(o);
+        }
+        cloud.swap(out);
+        invalidate();
+        return (int)cloud.size();
+    }
+    void invalidate()
+    {
+        tree_built = false;
+        normals.clear(); normal_done.clear();
+        path_set.clear(); slice_idx.clear();
+    }
+
     int gen_path()
     {
         path_set.clear();
@@ -1269,6 +1531,9 @@ int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *thresh
     return rc;
 }
 
+int ppo_voxel_down(ppo_handle *h, float lx, float ly, float lz, int *overflow) { return h->voxel_down(lx, ly, lz, overflow); }
+
+int ppo_smooth_mls(ppo_handle *h, double radius, int order) { return h->smooth_mls(radius, order); }
 int ppo_knn(ppo_handle *h, const float q[3], int k, int *out)
 {
     h->ensure_tree();

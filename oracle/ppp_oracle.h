@@ -109,6 +109,10 @@ void ppo_normal_at(ppo_handle *h, int idx, float n4[4]);
 /* SectPath::remove_outlier (path_slicing_alg.cpp:101-108; pcl::StatisticalOutlierRemoval): replaces the cloud, returns
    the new size (or -1); threshold / distances (one float per ORIGINAL point) are optional outputs for the tests */
 int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *threshold, float *distances);
+/* path_generater::voxel_down (Path_Generation.cpp:53-59; pcl::VoxelGrid): replaces the cloud, returns the new size */
+int ppo_voxel_down(ppo_handle *h, float lx, float ly, float lz, int *overflow);
+/* SectPath::smooth (path_slicing_alg.cpp:111-139; pcl::MovingLeastSquares, order 3, radius 15): replaces the cloud */
+int ppo_smooth_mls(ppo_handle *h, double radius, int order);
 /* dynamic adjustment building blocks (for the cross-check tests) */
 /* kdtree.nearestKSearch(q, k): ascending distance; returns the count */
 int ppo_knn(ppo_handle *h, const float q[3], int k, int *out);

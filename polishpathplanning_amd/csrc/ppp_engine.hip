@@ -9,6 +9,7 @@
  */
 #include "ppp_kernels.h"
 #include "ppp_preproc.h"
+#include "ppp_sort.h"
 #include "../../include/ppp_hip.h"
 
 #include <dlfcn.h>
@@ -796,6 +797,152 @@ int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_ke
     h->n = (size_t)hst.n_kept;
     if (n_kept) *n_kept = h->n;
     if (threshold) *threshold = hst.threshold;
+    cleanup();
+    h->drop_graph();
+    return refresh_bounds_and_plan(h);
+}
+
+int ppp_voxel_down(ppp_handle h, float lx, float ly, float lz, size_t *n_out, int *overflow)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (!(lx > 0.f) || !(ly > 0.f) || !(lz > 0.f) || !std::isfinite(lx) || !std::isfinite(ly) || !std::isfinite(lz))
+        return fail(h, PPP_ERR_ARG, "leaf sizes must be positive and finite");
+    if (overflow) *overflow = 0;
+    if (n_out) *n_out = h->n;
+    const int n = (int)h->n;
+    if (n == 0) return PPP_OK;
+    /* voxel_grid.hpp applyFilter: inverse_leaf_size_ = 1 / leaf_size_ (float), the index-overflow test on the float extents,
+       min_b_ / max_b_ / div_b_ / divb_mul_ */
+    const float inv[3] = {1.0f / lx, 1.0f / ly, 1.0f / lz};
+    VoxGrid g;
+    long long cells = 1, dxyz = 1;
+    int div_b[3];
+    if (h->h_nvalid > 0) {
+        for (int d = 0; d < 3; ++d) {
+            dxyz *= (long long)((h->h_mx[d] - h->h_mn[d]) * inv[d]) + 1;
+            const int min_b = (int)std::floor(h->h_mn[d] * inv[d]), max_b = (int)std::floor(h->h_mx[d] * inv[d]);
+            div_b[d] = max_b - min_b + 1;
+            cells *= div_b[d];
+            g.inv[d] = inv[d];
+            g.min_b[d] = (float)min_b;
+            if (dxyz > 0x7fffffffLL || cells > 0x7fffffffLL || dxyz <= 0 || cells <= 0) {
+                /* "Leaf size is too small for the input dataset. Integer indices would overflow.": output = input */
+                if (overflow) *overflow = 1;
+                return PPP_OK;
+            }
+        }
+        g.mul[0] = 1; g.mul[1] = div_b[0]; g.mul[2] = div_b[0] * div_b[1];
+    } else {
+        for (int d = 0; d < 3; ++d) { g.inv[d] = inv[d]; g.min_b[d] = 0.f; g.mul[d] = 0; }
+    }
+    g.none = (unsigned)cells;
+    int end_bit = 1;
+    while (end_bit < 32 && (cells >> end_bit)) ++end_bit;
+    const int nblocks = (n + VOX_CHUNK - 1) / VOX_CHUNK;
+    DevBuf<unsigned> key, key2;
+    DevBuf<int> idx, idx2, bcnt;
+    DevBuf<char> tmp;
+    DevBuf<float4> pts;
+    DevBuf<float> X2, Y2, Z2;
+    DevBuf<VoxStats> st;
+    auto cleanup = [&]() { key.release(); key2.release(); idx.release(); idx2.release(); bcnt.release(); tmp.release(); pts.release();
+                           X2.release(); Y2.release(); Z2.release(); st.release(); };
+    size_t tmp_bytes = 0;
+    hipError_t e = ppp_sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, end_bit, h->stream);
+    if (e == hipSuccess) e = key.ensure(n);
+    if (e == hipSuccess) e = key2.ensure(n);
+    if (e == hipSuccess) e = idx.ensure(n);
+    if (e == hipSuccess) e = idx2.ensure(n);
+    if (e == hipSuccess) e = bcnt.ensure(nblocks);
+    if (e == hipSuccess) e = tmp.ensure(tmp_bytes);
+    if (e == hipSuccess) e = pts.ensure(n);
+    if (e == hipSuccess) e = X2.ensure(n);
+    if (e == hipSuccess) e = Y2.ensure(n);
+    if (e == hipSuccess) e = Z2.ensure(n);
+    if (e == hipSuccess) e = st.ensure(1);
+    if (e != hipSuccess) { cleanup(); return fail(h, PPP_ERR_HIP, std::string("voxel_down buffers: ") + hipGetErrorString(e)); }
+    VoxStats hst{0};
+    auto run = [&]() -> int {
+        const unsigned gb = (unsigned)((n + 255) / 256);
+        LAUNCH(h, "k_vox_key", k_vox_key, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, g, key.p, idx.p);
+        HIPCHK(h, ppp_sort_pairs_u32(tmp.p, &tmp_bytes, key.p, key2.p, idx.p, idx2.p, (size_t)n, end_bit, h->stream));
+        LAUNCH(h, "k_vox_count", k_vox_count, nblocks, 256, 0, key2.p, n, g.none, bcnt.p);
+        LAUNCH(h, "k_vox_scan", k_vox_scan, 1, 1024, 0, bcnt.p, nblocks, st.p);
+        LAUNCH(h, "k_vox_gather", k_vox_gather, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, idx2.p, n, pts.p);
+        LAUNCH(h, "k_vox_reduce", k_vox_reduce, nblocks, 256, 0, key2.p, pts.p, n, g.none, bcnt.p, X2.p, Y2.p, Z2.p);
+        HIPCHK(h, hipMemcpyAsync(&hst, st.p, sizeof(VoxStats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    int rc = run();
+    if (rc != PPP_OK) { cleanup(); return rc; }
+    std::swap(h->X, X2); std::swap(h->Y, Y2); std::swap(h->Z, Z2);
+    h->n = (size_t)hst.n_out;
+    if (n_out) *n_out = h->n;
+    cleanup();
+    h->drop_graph();
+    return refresh_bounds_and_plan(h);
+}
+
+int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (!(search_radius > 0) || !std::isfinite(search_radius)) return fail(h, PPP_ERR_ARG, "search radius must be positive"); /* mls.hpp: "Invalid search radius" */
+    if (order < 0 || order > 3) return fail(h, PPP_ERR_ARG, "polynomial order must be in [0, 3]");
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    if (overflowed_fast_path(h)) { h->big_path = true; h->drop_graph(); HIPCHK(h, h->arena.ensure((size_t)64 * std::max<size_t>(h->n, 1) + (1u << 20))); rc = enqueue_index(h); if (rc) return rc; rc = fetch_meta(h); if (rc) return rc; }
+    rc = map_dev_err(h);
+    if (rc) return rc;
+    const int n = (int)h->n, ns = h->hmeta.n_sorted;
+    if (n_out) *n_out = h->n;
+    if (n == 0) return PPP_OK;
+    const int nblocks = (n + VOX_CHUNK - 1) / VOX_CHUNK;
+    DevBuf<float4> rec;
+    DevBuf<float> X2, Y2, Z2;
+    DevBuf<int> bcnt;
+    DevBuf<VoxStats> st;
+    auto cleanup = [&]() { rec.release(); X2.release(); Y2.release(); Z2.release(); bcnt.release(); st.release(); };
+    hipError_t e = rec.ensure(n);
+    if (e == hipSuccess) e = X2.ensure(n);
+    if (e == hipSuccess) e = Y2.ensure(n);
+    if (e == hipSuccess) e = Z2.ensure(n);
+    if (e == hipSuccess) e = bcnt.ensure(nblocks);
+    if (e == hipSuccess) e = st.ensure(1);
+    if (e != hipSuccess) { cleanup(); return fail(h, PPP_ERR_HIP, std::string("smooth buffers: ") + hipGetErrorString(e)); }
+    VoxStats hst{0};
+    auto run = [&]() -> int {
+        HIPCHK(h, hipMemsetAsync(rec.p, 0, sizeof(float4) * (size_t)n, h->stream));
+        const unsigned gb = (unsigned)((std::max(ns, 1) + 255) / 256);
+        const float rf = (float)search_radius;
+        const double sq = search_radius * search_radius;
+        if (order == 3) LAUNCH(h, "k_mls<3>", k_mls<3>, gb, 256, 0, h->meta.p, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, rf, sq, rec.p);
+        else if (order == 2) LAUNCH(h, "k_mls<2>", k_mls<2>, gb, 256, 0, h->meta.p, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, rf, sq, rec.p);
+        else LAUNCH(h, "k_mls<1>", k_mls<1>, gb, 256, 0, h->meta.p, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, rf, sq, rec.p);
+        LAUNCH(h, "k_flag_count", k_flag_count, nblocks, 256, 0, rec.p, n, bcnt.p);
+        LAUNCH(h, "k_vox_scan", k_vox_scan, 1, 1024, 0, bcnt.p, nblocks, st.p);
+        LAUNCH(h, "k_flag_compact", k_flag_compact, nblocks, 256, 0, rec.p, n, bcnt.p, X2.p, Y2.p, Z2.p);
+        HIPCHK(h, hipMemcpyAsync(&hst, st.p, sizeof(VoxStats), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    rc = run();
+    if (rc == PPP_OK) { h->meta_in_flight = false; rc = fetch_meta(h); }
+    if (rc == PPP_OK) rc = map_dev_err(h);
+    if (rc != PPP_OK) { cleanup(); return rc; }
+    std::swap(h->X, X2); std::swap(h->Y, Y2); std::swap(h->Z, Z2);
+    h->n = (size_t)hst.n_out;
+    if (n_out) *n_out = h->n;
     cleanup();
     h->drop_graph();
     return refresh_bounds_and_plan(h);

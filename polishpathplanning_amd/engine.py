@@ -77,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -133,6 +133,8 @@ def lib():
         L.ppp_gather_waypoints.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, szp, vp]
         L.ppp_get_cloud.argtypes = [vp, fp, sz, szp]
         L.ppp_remove_outlier.argtypes = [vp, C.c_int, C.c_double, szp, C.POINTER(C.c_double)]
+        L.ppp_voxel_down.argtypes = [vp, C.c_float, C.c_float, C.c_float, szp, C.POINTER(C.c_int)]
+        L.ppp_smooth_mls.argtypes = [vp, C.c_double, C.c_int, szp]
         L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_finish_path_async.argtypes = [vp, vp, sz, ip, sz]
         L.ppp_minmax.argtypes = [vp, fp, fp]
@@ -374,6 +376,19 @@ class Engine:
         thr = C.c_double()
         self._chk(self.L.ppp_remove_outlier(self.h, int(mean_k), float(stddev_mul), C.byref(n), C.byref(thr)))
         return n.value, thr.value
+
+    def voxel_down(self, lx, ly, lz):
+        """path_generater::voxel_down (pcl::VoxelGrid) on the resident cloud; returns (new size, overflow flag)."""
+        n = C.c_size_t()
+        ov = C.c_int()
+        self._chk(self.L.ppp_voxel_down(self.h, float(lx), float(ly), float(lz), C.byref(n), C.byref(ov)))
+        return n.value, bool(ov.value)
+
+    def smooth_mls(self, radius=15.0, order=3):
+        """SectPath::smooth (pcl::MovingLeastSquares) on the resident cloud; returns the new size."""
+        n = C.c_size_t()
+        self._chk(self.L.ppp_smooth_mls(self.h, float(radius), int(order), C.byref(n)))
+        return n.value
 
     def gather_waypoints(self, comm_ptr, rank, nranks, root, counts, recv_ptr):
         """ppp_gather_waypoints: the finished lists of all ranks to `root` over RCCL (comm_ptr = ncclComm_t)."""

@@ -665,6 +665,57 @@ def test_remove_outlier_matches_the_oracle(engine_mod, oracle_mod, name):
     assert_full_parity(engine_mod, e, o)
 
 
+@pytest.mark.parametrize("leaf", [(0.1, 1.0, 1.0), (3.0, 3.0, 3.0), (7.5, 2.0, 50.0), (1e-3, 1e-3, 1e-3)])
+def test_voxel_down_matches_the_oracle(engine_mod, oracle_mod, leaf):
+    """path_generater::voxel_down (pcl::VoxelGrid): same voxels in the same order, bit-identical centroids (both sides add
+    in ascending point index), same behaviour on index overflow, same path afterwards."""
+    pts, cfg = synth.make_config("small_40k")
+    pts = pts.copy()
+    pts[7] = np.nan
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    n_o, ov_o = o.voxel_down(*leaf)
+    n_e, ov_e = e.voxel_down(*leaf)
+    assert (n_e, ov_e) == (n_o, ov_o)
+    assert ov_o == (leaf[0] < 0.01)
+    assert np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(o.points()))
+    if leaf == (0.1, 1.0, 1.0):      # main.cpp:25's leaf: the plan still has points in every band
+        assert_full_parity(engine_mod, e, o)
+
+
+@pytest.mark.parametrize("order", [3, 2, 1])
+def test_mls_smooth_matches_the_oracle(engine_mod, oracle_mod, order):
+    """SectPath::smooth (Smooth = true; pcl::MovingLeastSquares order 3 radius 15): the same points survive, coordinates
+    equal to the last float bit but for rare 1-ulp cases (f64 sums grouped differently), and the plan on the smoothed
+    cloud agrees within the waypoint tolerance."""
+    pts, cfg = synth.make_config("small_40k")
+    rng = np.random.default_rng(8)
+    pts = pts.copy()
+    pts[:, 2] += rng.normal(0, 0.2e-3, len(pts)).astype(np.float32)
+    pts[9] = np.nan
+    far = pts[:3].copy(); far[:, 2] += 0.5                    # three isolated points, 0.5 m above: fewer than 3 neighbours
+    far[:, 0] += np.array([0.0, 0.2, 0.4], np.float32)
+    pts = np.concatenate([pts, far])
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    n_o = o.smooth_mls(15.0, order)
+    n_e = e.smooth_mls(15.0, order)
+    assert n_e == n_o == len(pts) - 4
+    A, Bc = e.cloud(), o.points()
+    diff = np.abs(A.astype(np.float64) - Bc.astype(np.float64))
+    assert diff.max() <= 1.3e-4                                # one float ulp at |x| < 1024 mm
+    assert (A != Bc).any(axis=1).mean() < 1e-3
+    if order == 3:
+        So = o.gen_path(); S = e.gen_path()
+        assert S == So
+        o.get_path(); e.get_path()
+        wo, we = o.waypoints(), e.waypoints()
+        assert we.shape == wo.shape
+        assert np.abs(we[:, :3] - wo[:, :3]).max() < 1e-4
+
+
 def test_distinct_handles_from_concurrent_host_threads(engine_mod):
     """thread-compatible -- distinct handles may be driven from different host threads at once
     (own stream, own graph capture in thread-local mode, no globals)."""

@@ -181,6 +181,75 @@ def test_remove_outlier_matches_a_scipy_restatement(oracle_mod):
     assert o.gen_path() > 5                                            # and the planner runs on the filtered cloud
 
 
+def test_voxel_down_matches_a_numpy_restatement(oracle_mod):
+    """pcl::VoxelGrid (path_generater::voxel_down): one centroid per occupied voxel in ascending voxel id, non-finite points
+    dropped; an index space beyond INT_MAX leaves the cloud as it is."""
+    from polishpathplanning_amd import synth
+    pts = synth.make_plate(150, 60, kind="wavy", amp=10, seed=5)
+    pts[11] = np.nan
+    for leaf in [(0.1, 1.0, 1.0), (3.0, 3.0, 3.0), (7.5, 2.0, 50.0)]:   # main.cpp:25 passes (0.1, 1, 1)
+        o = oracle_mod.Oracle(pts, tool_radius=6.0)
+        P = o.points()
+        n2, ov = o.voxel_down(*leaf)
+        fin = np.isfinite(P).all(axis=1)
+        Q = P[fin]
+        inv = (np.float32(1.0) / np.asarray(leaf, np.float32)).astype(np.float32)
+        mnb = np.floor(Q.min(axis=0) * inv).astype(np.int64)
+        mxb = np.floor(Q.max(axis=0) * inv).astype(np.int64)
+        div = mxb - mnb + 1
+        ijk = (np.floor(Q * inv) - mnb.astype(np.float32)).astype(np.int64)
+        vid = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+        ids, invmap, cnt = np.unique(vid, return_inverse=True, return_counts=True)
+        cen = np.zeros((len(ids), 3))
+        np.add.at(cen, invmap, Q.astype(np.float64))
+        cen /= cnt[:, None]
+        assert not ov and n2 == len(ids)
+        assert np.abs(o.points().astype(np.float64) - cen).max() < 2e-3   # float sums of mm coordinates
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    n2, ov = o.voxel_down(0.001, 0.001, 0.001)
+    assert ov and n2 == len(pts) and np.array_equal(np.nan_to_num(o.points()), np.nan_to_num(P))
+
+
+def test_mls_smooth_matches_a_numpy_restatement(oracle_mod):
+    """pcl::MovingLeastSquares (SectPath::smooth), order 3, radius 15, SIMPLE projection: plane of the neighbourhood from
+    numpy's eigh, weighted cubic fit in the plane's frame from lstsq, the query point moved to mean + c0 * normal.
+    The fit is frame independent (a full cubic basis), so any orthonormal (u, v) gives the same c0."""
+    from polishpathplanning_amd import synth
+    pts = synth.make_plate(90, 70, kind="wavy", amp=10, seed=9)
+    rng = np.random.default_rng(2)
+    clean = pts.copy()
+    pts[:, 2] += rng.normal(0, 0.3e-3, len(pts)).astype(np.float32)     # 0.3 mm of noise (metres in the file)
+    pts[3] = np.nan
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    P = o.points().astype(np.float64)
+    n2 = o.smooth_mls(15.0, 3)
+    S = o.points().astype(np.float64)
+    fin = np.isfinite(P).all(axis=1)
+    assert n2 == fin.sum()                   # every finite point has >= 3 neighbours here; the NaN point is gone
+    Pf = P[fin]
+    tree = cKDTree(Pf)
+    for i in rng.integers(0, len(Pf), 60):
+        nb = tree.query_ball_point(Pf[i], 15.0)
+        Q = Pf[nb]
+        cen = Q.mean(axis=0)
+        w_, v_ = np.linalg.eigh(np.cov((Q - cen).T, bias=True))
+        nrm = v_[:, 0]
+        mean = Pf[i] - ((Pf[i] - cen) @ nrm) * nrm
+        dm = Q - mean
+        wgt = np.exp(-(dm ** 2).sum(axis=1) / 225.0)
+        u_ax = v_[:, 1]; v_ax = np.cross(nrm, u_ax)
+        u = dm @ u_ax; v = dm @ v_ax; f = dm @ nrm
+        cols = [u ** a * v ** b for a in range(4) for b in range(4 - a)]
+        Amat = np.stack(cols, axis=1) * np.sqrt(wgt)[:, None]
+        c = np.linalg.lstsq(Amat, f * np.sqrt(wgt), rcond=None)[0]
+        want = mean + c[0] * nrm
+        j = i                                 # index among the finite points == index in the output
+        assert np.abs(S[j] - want).max() < 2e-4, (i, S[j], want)
+    # and it does smooth: closer to the noise-free sheet than the input was (z in mm)
+    cz = clean[fin][:, 2].astype(np.float64) * 1000.0
+    assert np.abs(S[:, 2] - cz).std() < 0.5 * np.abs(Pf[:, 2] - cz).std()
+
+
 # ---------------- A.4: normals vs numpy eigh -----------------
 def test_normals_match_eigh(small):
     pts, o = small
