@@ -30,7 +30,7 @@ public:
     void show() { planner.show_notice(); }
     void voxel_down(const float x, const float y, const float z) { planner.voxel_down(x, y, z); } /* Path_Generation.cpp:53-59 */
     void trans2center() { note("trans2center"); }
-    void smooth() { note("smooth"); }
+    void smooth() { planner.smooth_mls(15, 3, file_name, true); } /* Path_Generation.cpp:340-360 */
     void Set_kdtree() {}
     void estimate_normal() {}
     void get_coverage() { note("get_coverage"); }

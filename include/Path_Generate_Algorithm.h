@@ -5,8 +5,9 @@
  * MI355X through include/ppp_hip.h.  Differences a caller can observe:
  *   - show() prints a notice instead of opening a PCL viewer (visualisation is out of scope);
  *   - Dynamic_adjustment = true runs the curvature-driven re-spacing (path_dynamic_alg.cpp:77-306)
- *     on the GPU, RemoveOutlier = true the statistical outlier removal (path_slicing_alg.cpp:101-108);
- *     Alignment / Smooth = true are reported and ignored;
+ *     on the GPU, RemoveOutlier = true the statistical outlier removal (path_slicing_alg.cpp:101-108),
+ *     Smooth = true the moving-least-squares smoothing (path_slicing_alg.cpp:111-139);
+ *     Alignment = true is reported and ignored;
  *   - conditions on which the reference aborts (GSL / FLANN) are reported on stderr instead.
  * Build connect1's single-direction walk with -DPPP_SDIR (it links dynamic_alg_sdir.cpp in the
  * reference, CMakeLists.txt:38-47).
@@ -35,9 +36,13 @@ public:
         planner.config().params.walk = PPP_WALK_SECTPATH;
         init_common();
         planner.open(cloud_name);
+        if (ifSmooth) smooth();         /* path_slicing_alg.cpp:27 */
         if (ifRemove) remove_outlier(); /* path_slicing_alg.cpp:29 */
     }
     virtual ~SectPath() {}
+
+    /* path_slicing_alg.cpp:111-139: pcl::MovingLeastSquares, order 3, radius 15, and the smooth_<name> side file */
+    void smooth() { planner.smooth_mls(15, 3, cloud_name, ifChangeRange); }
 
     /* path_slicing_alg.cpp:101-108: pcl::StatisticalOutlierRemoval, 50 neighbours, 1 sigma, on the resident cloud */
     void remove_outlier() { planner.remove_outlier(50, 1.0); }
@@ -71,8 +76,8 @@ protected:
         toolRadius = c.params.tool_radius; PathResolution = c.params.path_resolution; RPYres = c.params.rpy_resolution;
         EElen = c.params.ee_length; ifChangeRange = c.params.change_range; ifAlign = c.alignment; ifSmooth = c.smooth_cloud;
         ifRemove = c.remove_outlier; pathFile = c.path_file;
-        if (ifAlign || ifSmooth)
-            fprintf(stderr, "ppp: Alignment / Smooth are outside the accelerated path and are ignored (SURVEY.md 8f rank 3)\n");
+        if (ifAlign)
+            fprintf(stderr, "ppp: Alignment is outside the accelerated path and is ignored (SURVEY.md 8f rank 3)\n");
     }
     void init_common()
     {
@@ -116,6 +121,7 @@ public:
 #endif
         init_common();
         planner.open(cloud_name);
+        if (ifSmooth) smooth();         /* path_dynamic_alg.cpp:29 */
         if (ifRemove) remove_outlier(); /* path_dynamic_alg.cpp:32 */
     }
     void GenPath() override

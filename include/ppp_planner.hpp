@@ -95,6 +95,24 @@ public:
         if (rc == PPP_OK && overflow) std::fprintf(stderr, "[pcl::VoxelGrid::applyFilter] Leaf size is too small for the input dataset. Integer indices would overflow.\n");
         return rc == PPP_OK ? true : report(rc);
     }
+    /* SectPath::smooth: MLS on the resident cloud, then the "smooth_<name>" ascii PCD the reference leaves behind
+       (path_slicing_alg.cpp:126-138; coordinates back in metres when ChangeRange).  A name with a directory part makes
+       an unwritable "smooth_dir/..." path there (pcl::io throws); here the file is skipped with a note. */
+    bool smooth_mls(double radius, int order, const std::string &cloud_name, bool scale_back)
+    {
+        if (!ok()) return false;
+        size_t n = 0;
+        int rc = ppp_smooth_mls(h_, radius, order, &n);
+        if (rc != PPP_OK) return report(rc);
+        std::vector<float> xyz(3 * (n ? n : 1));
+        rc = ppp_get_cloud(h_, xyz.data(), n, &n);
+        if (rc != PPP_OK) return report(rc);
+        if (scale_back) for (size_t i = 0; i < 3 * n; ++i) xyz[i] /= 1000;
+        const float vp[7] = {0, 0, 0, 1, 0, 0, 0};
+        const std::string side = "smooth_" + cloud_name;
+        if (ppp_save_pcd(side.c_str(), xyz.data(), n, 3, vp, 0) != PPP_OK) std::fprintf(stderr, "ppp: could not write %s\n", side.c_str());
+        return true;
+    }
     bool apply_params()
     {
         int rc = ppp_set_params(h_, &cfg_.params);

@@ -290,10 +290,11 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize("dynamic,remove", [(0, 0), (1, 0), (0, 1)])
-def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remove):
+@pytest.mark.parametrize("dynamic,remove,smooth", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 1, 1)])
+def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remove, smooth):
     """The drop-in C++ classes (include/Path_Generate_Algorithm.h) driven like src/connect.cpp:
-    PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13) and RemoveOutlier (config.txt:11)."""
+    PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13), RemoveOutlier (config.txt:11) and
+    Smooth (config.txt:9, with its smooth_<name> side file)."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "connect1", "main"], stdout=subprocess.DEVNULL)
@@ -308,18 +309,24 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
     out = str(tmp_path / "WayPoints.txt")
     conf = tmp_path / "config.txt"
     conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
-                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = %s\nDynamic_adjustment = %s\n"
+                    "Smooth = %s\nAlignment = false\nChangeRange = true\nRemoveOutlier = %s\nDynamic_adjustment = %s\n"
                     "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n"
-                    % (out, "true" if remove else "false", "true" if dynamic else "false"))
+                    % (out, "true" if smooth else "false", "true" if remove else "false", "true" if dynamic else "false"))
     env = dict(os.environ, PPP_CONFIG=str(conf))
+    if smooth:
+        pcd = "workpiece.pcd"               # "smooth_" + name must be a writable path: run in the directory
     for exe, walk in (("connect", 1), ("connect1", 2)):
         if os.path.exists(out):
             os.remove(out)
-        r = subprocess.run([os.path.join(root, "examples", exe), pcd], env=env, capture_output=True, text=True, timeout=120)
+        r = subprocess.run([os.path.join(root, "examples", exe), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
         assert r.returncode == 0, r.stderr
         assert "!!!!! GOT PATH !!!!!" in r.stdout
         got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
         o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=walk, dynamic_adjustment=dynamic)
+        if smooth:                          # ctor order: smooth, (align,) remove (path_slicing_alg.cpp:27-29)
+            assert len(pts) - 30 <= o.smooth_mls(15.0, 3) <= len(pts)   # flyers more than 15 mm from the sheet have no neighbours
+            side = engine_mod.load_pcd(str(tmp_path / "smooth_workpiece.pcd"))[0]
+            assert np.abs(side * 1000.0 - o.points()).max() < 2e-3      # ascii, metres
         if remove:
             assert o.remove_outlier(50, 1.0)[0] < len(pts)
         o.gen_path(); o.get_path()
