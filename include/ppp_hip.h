@@ -67,7 +67,7 @@ typedef struct ppp_params {
     float  handeye[6];        /* HANDEYEx..rz (Path_Generate_Algorithm.h:43-48)               */
     float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
     int    smooth_max_sweeps; /* cap of the smoothing loop                   */
-    int    alignment;         /* Alignment / Smooth: must be 0 (next rows); RemoveOutlier is ppp_remove_outlier */
+    int    alignment;         /* must be 0: Alignment / Smooth / RemoveOutlier are the ppp_trans2center / ppp_smooth_mls / ppp_remove_outlier calls */
     int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306 for the connect /
                                  connect1 walks, Path_Generation.cpp:362-634 for PPP_WALK_V1_CONTACT            */
     double depth;             /* depth            (config.txt:5)                              */
@@ -116,6 +116,14 @@ int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_ke
  * the resident cloud, the plan is rebuilt.  Leaf sizes in the cloud's units (mm after ChangeRange).  *overflow = 1 and
  * the cloud is left as it is where PCL warns "Leaf size is too small ... Integer indices would overflow". */
 int ppp_voxel_down(ppp_handle h, float leaf_x, float leaf_y, float leaf_z, size_t *n_out, int *overflow);
+/* SectPath::trans2center() (path_slicing_alg.cpp:82-99; v1 Path_Generation.cpp:60-92): centroid and covariance as
+ * pcl::compute3DCentroid / pcl::computeCovarianceMatrix accumulate them (float, point after point -- reproduced bit for
+ * bit on the device), Eigen::EigenSolver<Matrix3f> eigenvectors (unsorted, as they come), TransAlign = [V^T | -V^T c],
+ * pcl::transformPointCloud on the resident cloud.  From then on ppp_get_path applies invTransAlign to the sampled
+ * points and looks up the nearest point and its normal in the cloud carried back by the inverse
+ * (path_translation_alg.cpp:146-174), until ppp_set_cloud.  Optional outputs: TransAlign (row-major 4 x 4), the
+ * centroid, the 3 x 3 accumulated covariance.  PPP_ERR_DOMAIN when the float Schur form keeps a complex pair. */
+int ppp_trans2center(ppp_handle h, float *trans_align16, float *centroid3, float *covariance9);
 /* SectPath::smooth() (path_slicing_alg.cpp:111-139; v1 Path_Generation.cpp:340-360): pcl::MovingLeastSquares with
  * setPolynomialOrder(order = 3), setSearchRadius(search_radius = 15), SIMPLE projection, no upsampling; the projected
  * points replace the resident cloud (points with fewer than 3 neighbours in the radius, and non-finite points, are

@@ -54,6 +54,15 @@ def build(force=False):
 _lib = None
 
 
+def eigensolver3f(A):
+    """Eigen::EigenSolver<Matrix3f> restatement: (rc, eigenvalues, eigenvectors in columns)"""
+    L = lib()
+    A = np.ascontiguousarray(A, np.float32).reshape(9)
+    ev = np.zeros(3, np.float32); V = np.zeros(9, np.float32)
+    rc = L.ppo_eigensolver3f(_f(A), _f(ev), _f(V))
+    return rc, ev, V.reshape(3, 3)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -73,6 +82,8 @@ def lib():
         L.ppo_remove_outlier.argtypes = [vp, C.c_int, C.c_double, C.POINTER(C.c_double), fp]
         L.ppo_voxel_down.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int)]
         L.ppo_smooth_mls.argtypes = [vp, C.c_double, C.c_int]
+        L.ppo_trans2center.argtypes = [vp, fp, fp, fp]
+        L.ppo_eigensolver3f.argtypes = [fp, fp, fp]
         L.ppo_minmax.argtypes = [vp, fp, fp]
         L.ppo_slice_positions.argtypes = [vp, fp, C.c_int]
         L.ppo_ranged_x_index.argtypes = [vp, C.c_int, ip, C.c_int]
@@ -296,6 +307,12 @@ class Oracle:
         if rc >= 0:
             self.n = rc
         return rc
+
+    def trans2center(self):
+        """SectPath::trans2center; returns (rc, TransAlign 4x4, centroid, covariance 3x3)"""
+        T = np.zeros(16, np.float32); c = np.zeros(3, np.float32); cov = np.zeros(9, np.float32)
+        rc = self.L.ppo_trans2center(self.h, _f(T), _f(c), _f(cov))
+        return rc, T.reshape(4, 4), c, cov.reshape(3, 3)
 
     def knn(self, q, k):
         q = np.ascontiguousarray(q, np.float32)

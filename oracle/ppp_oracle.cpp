@@ -354,6 +354,295 @@ void eigen33_smallest(const float cov[9], float *eigenvalue, float ev[3])
     for (int d = 0; d < 3; ++d) ev[d] = cp[idx][d] / len[idx];
 }
 
+/* ------------------------------------------------------------------ */
+/* Eigen::EigenSolver<Matrix3f> (trans2center, path_slicing_alg.cpp:92-94)                    */
+/* Restated from Eigen 3.3 / 3.4: RealSchur::compute (scaling by the largest |entry|, HessenbergDecomposition,     */
+/* computeFromHessenberg with Francis double-shift steps), EigenSolver::compute + doComputeEigenvectors (back       */
+/* substitution on T, back transformation by U) and eigenvectors() (columns normalised).  The order and the signs   */
+/* of the eigenvectors are whatever this iteration leaves on T's diagonal -- the reference takes them as they come. */
+/* Real eigenvalues only (a symmetric input); a complex pair (a numerically degenerate covariance) is reported.     */
+/* Matrices are row-major m[r][c] here.                                                                              */
+/* ------------------------------------------------------------------ */
+struct EigenSolver3f {
+    float T[3][3], U[3][3];
+    float ev[3];
+    bool complex_pair = false, converged = true;
+
+    /* MatrixBase::makeHouseholder: v[0..n-1] -> essential part (n-1), tau, beta */
+    static void make_householder(const float *v, int n, float *ess, float &tau, float &beta)
+    {
+        float tail_sq = 0.f;
+        for (int i = 1; i < n; ++i) tail_sq = (i == 1) ? v[i] * v[i] : tail_sq + v[i] * v[i];
+        const float c0 = v[0];
+        if (tail_sq <= std::numeric_limits<float>::min()) {
+            tau = 0.f; beta = c0;
+            for (int i = 0; i < n - 1; ++i) ess[i] = 0.f;
+        } else {
+            beta = std::sqrt(c0 * c0 + tail_sq);
+            if (c0 >= 0.f) beta = -beta;
+            for (int i = 0; i < n - 1; ++i) ess[i] = v[i + 1] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+    }
+    /* MatrixBase::applyHouseholderOnTheLeft on the block rows r0..r0+nr-1, cols c0..c0+nc-1 */
+    static void apply_left(float M[3][3], int r0, int nr, int c0, int nc, const float *ess, float tau)
+    {
+        if (nr == 1) { for (int j = 0; j < nc; ++j) M[r0][c0 + j] *= 1.f - tau; return; }
+        if (tau == 0.f) return;
+        for (int j = 0; j < nc; ++j) {
+            float tmp = ess[0] * M[r0 + 1][c0 + j];
+            for (int i = 2; i < nr; ++i) tmp += ess[i - 1] * M[r0 + i][c0 + j];
+            tmp += M[r0][c0 + j];
+            M[r0][c0 + j] -= tau * tmp;
+            for (int i = 1; i < nr; ++i) M[r0 + i][c0 + j] -= tmp * (tau * ess[i - 1]);
+        }
+    }
+    static void apply_right(float M[3][3], int r0, int nr, int c0, int nc, const float *ess, float tau)
+    {
+        if (nc == 1) { for (int i = 0; i < nr; ++i) M[r0 + i][c0] *= 1.f - tau; return; }
+        if (tau == 0.f) return;
+        for (int i = 0; i < nr; ++i) {
+            float tmp = M[r0 + i][c0 + 1] * ess[0];
+            for (int j = 2; j < nc; ++j) tmp += M[r0 + i][c0 + j] * ess[j - 1];
+            tmp += M[r0 + i][c0];
+            M[r0 + i][c0] -= tau * tmp;
+            for (int j = 1; j < nc; ++j) M[r0 + i][c0 + j] -= ess[j - 1] * (tau * tmp);
+        }
+    }
+    /* JacobiRotation::makeGivens (real) */
+    static void make_givens(float p, float q, float &c, float &s)
+    {
+        if (q == 0.f) { c = p < 0.f ? -1.f : 1.f; s = 0.f; }
+        else if (p == 0.f) { c = 0.f; s = q < 0.f ? 1.f : -1.f; }
+        else if (std::abs(p) > std::abs(q)) {
+            float t = q / p, u = std::sqrt(1.f + t * t);
+            if (p < 0.f) u = -u;
+            c = 1.f / u; s = -t * c;
+        } else {
+            float t = p / q, u = std::sqrt(1.f + t * t);
+            if (q < 0.f) u = -u;
+            s = -1.f / u; c = -t * s;
+        }
+    }
+
+    void compute(const float A[3][3])
+    {
+        const float eps = std::numeric_limits<float>::epsilon();
+        /* RealSchur::compute */
+        float scale = 0.f;
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) scale = std::max(scale, std::abs(A[i][j]));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { T[i][j] = 0.f; U[i][j] = i == j ? 1.f : 0.f; }
+        if (scale < std::numeric_limits<float>::min()) { finish(); return; }
+        float H[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[i][j] = A[i][j] / scale;
+        /* HessenbergDecomposition::_compute, n = 3: one reflector on (H10, H20); the second (length 1) has tau = 0 */
+        float v2[2] = {H[1][0], H[2][0]}, ess0, h0, beta;
+        make_householder(v2, 2, &ess0, h0, beta);
+        H[2][0] = ess0; H[1][0] = beta;
+        apply_left(H, 1, 2, 1, 2, &ess0, h0);
+        apply_right(H, 0, 3, 1, 2, &ess0, h0);
+        /* i = 1: tau = 0, beta = H21; the 1 x 1 / 1-column applications multiply by (1 - 0) */
+        /* matrixQ().evalTo(U): identity, then the reflector on its bottom-right 2 x 2 corner */
+        apply_left(U, 1, 2, 1, 2, &ess0, h0);
+        /* matrixH() */
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i][j] = H[i][j];
+        T[2][0] = 0.f;
+        /* computeFromHessenberg */
+        const int size = 3, max_iters = 40 * 3;
+        int iu = size - 1, iter = 0, total_iter = 0;
+        float exshift = 0.f, norm = 0.f;
+        for (int j = 0; j < size; ++j) { /* computeNormOfT */
+            float cs = std::abs(T[0][j]);
+            for (int i = 1; i < std::min(size, j + 2); ++i) cs += std::abs(T[i][j]);
+            norm += cs;
+        }
+        const float consider_as_zero = std::max(norm * (eps * eps), std::numeric_limits<float>::min());
+        if (norm != 0.f) {
+            while (iu >= 0) {
+                int il = iu; /* findSmallSubdiagEntry */
+                while (il > 0) {
+                    float s = std::abs(T[il - 1][il - 1]) + std::abs(T[il][il]);
+                    s = std::max(s * eps, consider_as_zero);
+                    if (std::abs(T[il][il - 1]) <= s) break;
+                    il--;
+                }
+                if (il == iu) { /* one root */
+                    T[iu][iu] = T[iu][iu] + exshift;
+                    if (iu > 0) T[iu][iu - 1] = 0.f;
+                    iu--; iter = 0;
+                } else if (il == iu - 1) { /* two roots: splitOffTwoRows */
+                    float p = 0.5f * (T[iu - 1][iu - 1] - T[iu][iu]);
+                    float q = p * p + T[iu][iu - 1] * T[iu - 1][iu];
+                    T[iu][iu] += exshift;
+                    T[iu - 1][iu - 1] += exshift;
+                    if (q >= 0.f) {
+                        float z = std::sqrt(std::abs(q)), c, s;
+                        if (p >= 0.f) make_givens(p + z, T[iu][iu - 1], c, s);
+                        else make_givens(p - z, T[iu][iu - 1], c, s);
+                        for (int j = iu - 1; j < size; ++j) { /* rightCols(size-iu+1).applyOnTheLeft(iu-1, iu, rot.adjoint()) */
+                            float x = T[iu - 1][j], y = T[iu][j];
+                            T[iu - 1][j] = c * x - s * y;
+                            T[iu][j] = s * x + c * y;
+                        }
+                        for (int i = 0; i <= iu; ++i) { /* topRows(iu+1).applyOnTheRight(iu-1, iu, rot) */
+                            float x = T[i][iu - 1], y = T[i][iu];
+                            T[i][iu - 1] = c * x - s * y;
+                            T[i][iu] = s * x + c * y;
+                        }
+                        T[iu][iu - 1] = 0.f;
+                        for (int i = 0; i < size; ++i) {
+                            float x = U[i][iu - 1], y = U[i][iu];
+                            U[i][iu - 1] = c * x - s * y;
+                            U[i][iu] = s * x + c * y;
+                        }
+                    } else complex_pair = true;
+                    if (iu > 1) T[iu - 1][iu - 2] = 0.f;
+                    iu -= 2; iter = 0;
+                } else { /* Francis QR step on rows il..iu (here il = 0, iu = 2) */
+                    float shift[3] = {T[iu][iu], T[iu - 1][iu - 1], T[iu][iu - 1] * T[iu - 1][iu]}; /* computeShift */
+                    if (iter == 10) {
+                        exshift += shift[0];
+                        for (int i = 0; i <= iu; ++i) T[i][i] -= shift[0];
+                        float s = std::abs(T[iu][iu - 1]) + std::abs(T[iu - 1][iu - 2]);
+                        shift[0] = 0.75f * s; shift[1] = 0.75f * s; shift[2] = -0.4375f * s * s;
+                    }
+                    if (iter == 30) {
+                        float s = (shift[1] - shift[0]) / 2.0f;
+                        s = s * s + shift[2];
+                        if (s > 0.f) {
+                            s = std::sqrt(s);
+                            if (shift[1] < shift[0]) s = -s;
+                            s = s + (shift[1] - shift[0]) / 2.0f;
+                            s = shift[0] - shift[2] / s;
+                            exshift += s;
+                            for (int i = 0; i <= iu; ++i) T[i][i] -= s;
+                            shift[0] = shift[1] = shift[2] = 0.964f;
+                        }
+                    }
+                    iter++; total_iter++;
+                    if (total_iter > max_iters) { converged = false; break; }
+                    int im; /* initFrancisQRStep */
+                    float fv[3] = {0.f, 0.f, 0.f};
+                    for (im = iu - 2; im >= il; --im) {
+                        const float Tmm = T[im][im], r = shift[0] - Tmm, s = shift[1] - Tmm;
+                        fv[0] = (r * s - shift[2]) / T[im + 1][im] + T[im][im + 1];
+                        fv[1] = T[im + 1][im + 1] - Tmm - r - s;
+                        fv[2] = T[im + 2][im + 1];
+                        if (im == il) break;
+                        const float lhs = T[im][im - 1] * (std::abs(fv[1]) + std::abs(fv[2]));
+                        const float rhs = fv[0] * (std::abs(T[im - 1][im - 1]) + std::abs(Tmm) + std::abs(T[im + 1][im + 1]));
+                        if (std::abs(lhs) < eps * rhs) break;
+                    }
+                    for (int k = im; k <= iu - 2; ++k) { /* performFrancisQRStep */
+                        const bool first = (k == im);
+                        float v[3];
+                        if (first) { v[0] = fv[0]; v[1] = fv[1]; v[2] = fv[2]; }
+                        else { v[0] = T[k][k - 1]; v[1] = T[k + 1][k - 1]; v[2] = T[k + 2][k - 1]; }
+                        float ess[2], tau, bt;
+                        make_householder(v, 3, ess, tau, bt);
+                        if (bt != 0.f) {
+                            if (first && k > il) T[k][k - 1] = -T[k][k - 1];
+                            else if (!first) T[k][k - 1] = bt;
+                            apply_left(T, k, 3, k, size - k, ess, tau);
+                            apply_right(T, 0, std::min(iu, k + 3) + 1, k, 3, ess, tau);
+                            apply_right(U, 0, size, k, 3, ess, tau);
+                        }
+                    }
+                    {
+                        float v[2] = {T[iu - 1][iu - 2], T[iu][iu - 2]}, ess, tau, bt;
+                        make_householder(v, 2, &ess, tau, bt);
+                        if (bt != 0.f) {
+                            T[iu - 1][iu - 2] = bt;
+                            apply_left(T, iu - 1, 2, iu - 1, size - iu + 1, &ess, tau);
+                            apply_right(T, 0, iu + 1, iu - 1, 2, &ess, tau);
+                            apply_right(U, 0, size, iu - 1, 2, &ess, tau);
+                        }
+                    }
+                    for (int i = im + 2; i <= iu; ++i) { /* clean up pollution due to round-off errors */
+                        T[i][i - 2] = 0.f;
+                        if (i > im + 2) T[i][i - 3] = 0.f;
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i][j] *= scale; /* m_matT *= scale */
+        finish();
+    }
+
+    /* EigenSolver::compute after the Schur form: eigenvalues off T, doComputeEigenvectors, eigenvectors() */
+    void finish()
+    {
+        const float eps = std::numeric_limits<float>::epsilon();
+        const int size = 3;
+        for (int i = 0; i < size; ++i) ev[i] = T[i][i];
+        for (int i = 0; i + 1 < size; ++i) if (T[i + 1][i] != 0.f) complex_pair = true;
+        if (complex_pair || !converged) return;
+        float norm = 0.f;
+        for (int j = 0; j < size; ++j) {
+            const int a = std::max(j - 1, 0);
+            float rs = std::abs(T[j][a]);
+            for (int k = a + 1; k < size; ++k) rs += std::abs(T[j][k]);
+            norm += rs;
+        }
+        if (norm != 0.f) {
+            for (int n = size - 1; n >= 0; n--) {
+                const float p = ev[n];
+                int l = n;
+                T[n][n] = 1.f;
+                for (int i = n - 1; i >= 0; i--) {
+                    const float w = T[i][i] - p;
+                    float r = T[i][l] * T[l][n];
+                    for (int k = l + 1; k <= n; ++k) r += T[i][k] * T[k][n];
+                    l = i;
+                    if (w != 0.f) T[i][n] = -r / w;
+                    else T[i][n] = -r / (eps * norm);
+                    const float t = std::abs(T[i][n]);
+                    if ((eps * t) * t > 1.f) for (int k = i; k < size; ++k) T[k][n] /= t;
+                }
+            }
+            for (int j = size - 1; j >= 0; j--) { /* back transformation */
+                float tmp[3];
+                for (int i = 0; i < size; ++i) {
+                    float a = U[i][0] * T[0][j];
+                    for (int k = 1; k <= j; ++k) a += U[i][k] * T[k][j];
+                    tmp[i] = a;
+                }
+                for (int i = 0; i < size; ++i) U[i][j] = tmp[i];
+            }
+        }
+        for (int j = 0; j < size; ++j) { /* eigenvectors(): matV.col(j).normalize() */
+            const float z = (U[0][j] * U[0][j] + U[1][j] * U[1][j]) + U[2][j] * U[2][j];
+            if (z > 0.f) { const float s = std::sqrt(z); for (int i = 0; i < size; ++i) U[i][j] /= s; }
+        }
+    }
+};
+
+/* Matrix4f::inverse(): Eigen's generic 4 x 4 path (cofactors, InverseImpl.h compute_inverse_size4).  The SSE build
+   of Eigen runs Intel's 4 x 4 routine instead, whose entries differ from these in the last bits. */
+inline float det3_helper(const float m[4][4], int i1, int i2, int i3, int j1, int j2, int j3)
+{
+    return m[i1][j1] * (m[i2][j2] * m[i3][j3] - m[i2][j3] * m[i3][j2]);
+}
+inline float cofactor_4x4(const float m[4][4], int i, int j)
+{
+    const int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4, j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+    return det3_helper(m, i1, i2, i3, j1, j2, j3) + det3_helper(m, i2, i3, i1, j1, j2, j3) + det3_helper(m, i3, i1, i2, j1, j2, j3);
+}
+inline void inverse_4x4(const float m[4][4], float r[4][4])
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) r[j][i] = (((i + j) & 1) ? -1.f : 1.f) * cofactor_4x4(m, i, j);
+    const float det = ((m[0][0] * r[0][0] + m[1][0] * r[0][1]) + m[2][0] * r[0][2]) + m[3][0] * r[0][3];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r[i][j] /= det;
+}
+/* pcl::transformPointCloud, float transform, SSE2 build (common/impl/transforms.hpp detail::Transformer<float>::se3):
+   p0 + (p1 + (p2 + c3)) per row; non-finite points pass unchanged */
+inline void transform_se3(const float m[4][4], const float *src, float *dst)
+{
+    const float x = src[0], y = src[1], z = src[2];
+    for (int r = 0; r < 3; ++r) dst[r] = m[r][0] * x + (m[r][1] * y + (m[r][2] * z + m[r][3]));
+}
+
 /* the same pcl::eigen33 path with Scalar = double (pcl::MLSResult::computeMLSSurface calls it on a Matrix3d) */
 void compute_roots2_d(double b, double c, double roots[3])
 {
@@ -1306,6 +1595,57 @@ struct ppo_handle {
         invalidate();
         return (int)cloud.size();
     }
+    /* SectPath::trans2center (path_slicing_alg.cpp:82-99): pcl::compute3DCentroid and pcl::computeCovarianceMatrix
+       (float accumulators in cloud order, non-finite points skipped), Eigen::EigenSolver<Matrix3f> eigenvectors,
+       TransAlign = [V^T | -V^T c], pcl::transformPointCloud(*cloud, *cloud, TransAlign).
+       Returns 0, -1 without finite points, -2 when the float Schur form keeps a complex pair / does not converge. */
+    float TA[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    bool aligned = false;
+    float centroid3[3] = {0, 0, 0}, cov33[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    int trans2center()
+    {
+        float c[3] = {0.f, 0.f, 0.f};
+        size_t cp = 0;
+        for (const Pt &p : cloud) {
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            c[0] += p.x; c[1] += p.y; c[2] += p.z;
+            ++cp;
+        }
+        if (!cp) return -1;
+        for (int d = 0; d < 3; ++d) c[d] /= static_cast<float>(cp);
+        float cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (const Pt &p : cloud) {
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            float pt[3] = {p.x - c[0], p.y - c[1], p.z - c[2]};
+            cov[1][1] += pt[1] * pt[1];
+            cov[1][2] += pt[1] * pt[2];
+            cov[2][2] += pt[2] * pt[2];
+            const float x = pt[0];
+            pt[0] *= x; pt[1] *= x; pt[2] *= x; /* pt *= pt.x () */
+            cov[0][0] += pt[0];
+            cov[0][1] += pt[1];
+            cov[0][2] += pt[2];
+        }
+        cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+        for (int d = 0; d < 3; ++d) { centroid3[d] = c[d]; for (int e = 0; e < 3; ++e) cov33[d][e] = cov[d][e]; }
+        EigenSolver3f es;
+        es.compute(cov);
+        if (es.complex_pair || !es.converged) return -2;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) TA[i][j] = es.U[j][i];                                  /* eigen_vectors.transpose() */
+            TA[i][3] = ((-es.U[0][i]) * c[0] + (-es.U[1][i]) * c[1]) + (-es.U[2][i]) * c[2];       /* -V^T * centroid */
+        }
+        TA[3][0] = TA[3][1] = TA[3][2] = 0.f; TA[3][3] = 1.f;
+        for (Pt &p : cloud) {
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+            float o[3];
+            transform_se3(TA, &p.x, o);
+            p.x = o[0]; p.y = o[1]; p.z = o[2];
+        }
+        aligned = true;
+        invalidate();
+        return 0;
+    }
     void invalidate()
     {
         tree_built = false;
@@ -1362,7 +1702,9 @@ struct ppo_handle {
         int S = (int)path_set.size();
         int first = P.drop_ends ? 1 : 0, last = P.drop_ends ? S - 1 : S;
         for (int s = first; s < last; ++s) kept.push_back(&path_set[s]);
-        /* :156-169, invTransAlign = identity (Alignment = false) */
+        /* :146, :156-169: invTransAlign = TransAlign.inverse() (identity unless trans2center ran) */
+        float inv[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+        if (aligned) inverse_4x4(TA, inv);
         std::vector<std::vector<std::array<float, 3>>> lists;
         int flag = 1;
         for (const Spline *path : kept) {
@@ -1371,14 +1713,31 @@ struct ppo_handle {
             while (dy < path->big_y - P.trim) {
                 double p[3];
                 path->point(dy, p);
-                one.push_back({(float)p[0], (float)p[1], (float)p[2]});
+                std::array<float, 3> q = {(float)p[0], (float)p[1], (float)p[2]};
+                if (aligned) { /* wayPointXYZ = invTransAlign * wayPointXYZ (Matrix4f * Vector4f, w = 1) */
+                    std::array<float, 3> t;
+                    for (int r = 0; r < 3; ++r) t[r] = ((inv[r][0] * q[0] + inv[r][1] * q[1]) + inv[r][2] * q[2]) + inv[r][3] * 1.f;
+                    q = t;
+                }
+                one.push_back(q);
                 dy += P.path_resolution;
             }
             if (flag == -1) std::reverse(one.begin(), one.end());
             lists.push_back(one);
             flag *= -1;
         }
-        /* :173-174 */
+        /* :171-174: the cloud goes back through invTransAlign, the search tree and the normals are rebuilt on it */
+        std::vector<Pt> aligned_cloud;
+        if (aligned) {
+            aligned_cloud = cloud;
+            for (Pt &p : cloud) {
+                if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+                float o[3];
+                transform_se3(inv, &p.x, o);
+                p.x = o[0]; p.y = o[1]; p.z = o[2];
+            }
+            tree_built = false; normals.clear(); normal_done.clear();
+        }
         if (P.reference_complexity) { rebuild_tree(); estimate_normal_all(); }
         else ensure_tree();
         for (auto &one : lists) {
@@ -1397,6 +1756,10 @@ struct ppo_handle {
                 wp_normal.push_back({N[0], N[1], N[2], N[3]});
             }
             tail.push_back((int)wp.size() - 1);
+        }
+        if (aligned) { /* the reference leaves the cloud in the sensor frame; this handle stays reusable */
+            cloud.swap(aligned_cloud);
+            tree_built = false; normals.clear(); normal_done.clear();
         }
         wp_pre = wp;
         if (P.smooth && wp.size() > 0) sweeps = position_smooth(wp, P.smooth_max_sweeps);
@@ -1534,6 +1897,23 @@ int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *thresh
 int ppo_voxel_down(ppo_handle *h, float lx, float ly, float lz, int *overflow) { return h->voxel_down(lx, ly, lz, overflow); }
 
 int ppo_smooth_mls(ppo_handle *h, double radius, int order) { return h->smooth_mls(radius, order); }
+int ppo_trans2center(ppo_handle *h, float T16[16], float centroid[3], float cov9[9])
+{
+    int rc = h->trans2center();
+    if (T16) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T16[4 * i + j] = h->TA[i][j];
+    if (centroid) for (int d = 0; d < 3; ++d) centroid[d] = h->centroid3[d];
+    if (cov9) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) cov9[3 * i + j] = h->cov33[i][j];
+    return rc;
+}
+int ppo_eigensolver3f(const float A9[9], float evals[3], float evecs9[9])
+{
+    float A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = A9[3 * i + j];
+    EigenSolver3f es;
+    es.compute(A);
+    for (int i = 0; i < 3; ++i) { evals[i] = es.ev[i]; for (int j = 0; j < 3; ++j) evecs9[3 * i + j] = es.U[i][j]; }
+    return es.complex_pair ? -2 : (es.converged ? 0 : -3);
+}
 int ppo_knn(ppo_handle *h, const float q[3], int k, int *out)
 {
     h->ensure_tree();

@@ -111,6 +111,11 @@ void ppo_normal_at(ppo_handle *h, int idx, float n4[4]);
 int ppo_remove_outlier(ppo_handle *h, int mean_k, double std_mul, double *threshold, float *distances);
 /* path_generater::voxel_down (Path_Generation.cpp:53-59; pcl::VoxelGrid): replaces the cloud, returns the new size */
 int ppo_voxel_down(ppo_handle *h, float lx, float ly, float lz, int *overflow);
+/* SectPath::trans2center (path_slicing_alg.cpp:82-99): PCA alignment in place; the handle's get_path then applies
+   invTransAlign as path_translation_alg.cpp:146-172 does.  T16 row-major TransAlign; centroid / cov9 as accumulated. */
+int ppo_trans2center(ppo_handle *h, float T16[16], float centroid[3], float cov9[9]);
+/* Eigen::EigenSolver<Matrix3f>: eigenvalues as they come off the Schur form, eigenvectors in the columns of evecs9 (row-major) */
+int ppo_eigensolver3f(const float A9[9], float evals[3], float evecs9[9]);
 /* SectPath::smooth (path_slicing_alg.cpp:111-139; pcl::MovingLeastSquares, order 3, radius 15): replaces the cloud */
 int ppo_smooth_mls(ppo_handle *h, double radius, int order);
 /* dynamic adjustment building blocks (for the cross-check tests) */

@@ -10,6 +10,7 @@
 #include "ppp_kernels.h"
 #include "ppp_preproc.h"
 #include "ppp_sort.h"
+#include "ppp_align.h"
 #include "../../include/ppp_hip.h"
 
 #include <dlfcn.h>
@@ -65,6 +66,11 @@ struct ppp_handle_s {
     int h_nvalid = 0;
     /* slice-range handles (SURVEY.md 8e case ii) */
     bool ranged = false;          /* plans a strict sub-range of the slices: getPath stops after a12 */
+    /* trans2center ran (Alignment = true): TransAlign, its inverse, and a second handle holding the cloud carried back by
+       the inverse with its own slab index (path_translation_alg.cpp:171-174 searches and estimates normals there) */
+    bool aligned = false;
+    float TA[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}, invTA[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    ppp_handle back = nullptr;
     int sb = 0, se = 0;           /* the range, resolved against the walk */
     float incl_lo = -INFINITY, incl_hi = INFINITY;
     int n_range = 0;              /* expected number of indexed points */
@@ -137,6 +143,7 @@ struct ppp_handle_s {
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
+        if (back) { delete back; back = nullptr; }
     }
 };
 
@@ -620,6 +627,8 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
 {
     if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
     h->n = n;
+    h->aligned = false; /* a new cloud: TransAlign = identity (path_slicing_alg.cpp:25) */
+    if (h->back) { delete h->back; h->back = nullptr; }
     if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
     HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
     if (n) {
@@ -684,7 +693,8 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_smooth_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(0));
     (void)hipFuncSetAttribute((const void *)k_smooth_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(1));
-    (void)hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
@@ -737,6 +747,135 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
+}
+
+namespace {
+
+/* the slab index of a handle, complete: built, its meta block read back, the arena passes run if a slab overflowed */
+int index_ready(ppp_handle h)
+{
+    int rc = ensure_index(h);
+    if (rc) return rc;
+    rc = fetch_meta(h);
+    if (rc) return rc;
+    if (overflowed_fast_path(h)) {
+        h->big_path = true; h->drop_graph();
+        HIPCHK(h, h->arena.ensure((size_t)64 * std::max<size_t>(h->n, 1) + (1u << 20)));
+        rc = enqueue_index(h); if (rc) return rc;
+        rc = fetch_meta(h); if (rc) return rc;
+    }
+    return map_dev_err(h);
+}
+
+/* path_translation_alg.cpp:171-174: the cloud carried back by invTransAlign, with its own slab index (same point
+   indices).  The cloud is fixed between runs, so this happens once per cloud change, not per getPath. */
+int rebuild_back(ppp_handle h)
+{
+    if (!h->back) {
+        int rc = ppp_create(h->device, &h->back);
+        if (rc) return fail(h, rc, "sensor-frame handle");
+    }
+    ppp_handle b = h->back;
+    b->P = h->P;
+    b->P.tool_radius = 1.0e6; b->P.dynamic_adjustment = 0; b->P.slice_begin = 0; b->P.slice_end = 0; /* one slice: this handle only ever serves its index */
+    b->n = h->n;
+    memcpy(b->vp, h->vp, sizeof(b->vp));
+    HIPCHK(h, b->X.ensure(h->n)); HIPCHK(h, b->Y.ensure(h->n)); HIPCHK(h, b->Z.ensure(h->n));
+    if (h->n) {
+        Mat34 M;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) M.m[r][c] = h->invTA[r][c];
+        LAUNCH(h, "k_transform_se3", k_transform_se3, (unsigned)((h->n + 255) / 256), 256, 0, h->X.p, h->Y.p, h->Z.p, (int)h->n, M, b->X.p, b->Y.p, b->Z.p);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    b->big_path = false;
+    int rc = refresh_bounds_and_plan(b);
+    if (rc == PPP_OK) rc = index_ready(b);
+    if (rc == PPP_OK) { hipError_t e = hipStreamSynchronize(b->stream); if (e != hipSuccess) rc = PPP_ERR_HIP; }
+    if (rc != PPP_OK) return fail(h, rc, std::string("sensor-frame index: ") + b->err);
+    return PPP_OK;
+}
+
+/* the resident cloud was replaced or moved: bounds, plan, and the sensor-frame copy when the cloud is aligned */
+int cloud_changed(ppp_handle h)
+{
+    int rc = refresh_bounds_and_plan(h);
+    if (rc == PPP_OK && h->aligned) rc = rebuild_back(h);
+    return rc;
+}
+
+} // namespace
+
+int ppp_trans2center(ppp_handle h, float *trans_align16, float *centroid3, float *covariance9)
+{
+    if (!h) return PPP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (h->aligned) return fail(h, PPP_ERR_ARG, "the cloud is aligned already (TransAlign would be overwritten): set the cloud again");
+    const int n = (int)h->n;
+    if (n == 0 || h->h_nvalid == 0) return fail(h, PPP_ERR_ARG, "no finite point to align");
+    const size_t stride = ((size_t)n + 3) & ~(size_t)3;
+    DevBuf<float> V, sums;
+    DevBuf<int> cnt;
+    auto cleanup = [&]() { V.release(); sums.release(); cnt.release(); };
+    hipError_t e = V.ensure(6 * stride);
+    if (e == hipSuccess) e = sums.ensure(8);
+    if (e == hipSuccess) e = cnt.ensure(1);
+    if (e != hipSuccess) { cleanup(); return fail(h, PPP_ERR_HIP, std::string("trans2center buffers: ") + hipGetErrorString(e)); }
+    float hs[6] = {0, 0, 0, 0, 0, 0}, c[3] = {0, 0, 0};
+    int hcnt = 0;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    auto phase1 = [&]() -> int { /* pcl::compute3DCentroid: three running float sums, / float(count) */
+        HIPCHK(h, hipMemsetAsync(cnt.p, 0, sizeof(int), h->stream));
+        LAUNCH(h, "k_seq_prep_centroid", k_seq_prep_centroid, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, stride, V.p, cnt.p);
+        LAUNCH(h, "k_seq_sum", k_seq_sum, 3, 64, 0, V.p, stride, n, sums.p);
+        HIPCHK(h, hipMemcpyAsync(hs, sums.p, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&hcnt, cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    auto phase2 = [&]() -> int { /* pcl::computeCovarianceMatrix: six running float sums of float products */
+        LAUNCH(h, "k_seq_prep_cov", k_seq_prep_cov, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, c[0], c[1], c[2], stride, V.p);
+        LAUNCH(h, "k_seq_sum", k_seq_sum, 6, 64, 0, V.p, stride, n, sums.p);
+        HIPCHK(h, hipMemcpyAsync(hs, sums.p, 6 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    int rc = phase1();
+    if (rc == PPP_OK && hcnt <= 0) rc = fail(h, PPP_ERR_ARG, "no finite point to align");
+    if (rc == PPP_OK) {
+        for (int d = 0; d < 3; ++d) c[d] = hs[d] / static_cast<float>(hcnt);
+        rc = phase2();
+    }
+    if (rc != PPP_OK) { cleanup(); return rc; }
+    float cov[3][3];
+    cov[1][1] = hs[0]; cov[1][2] = hs[1]; cov[2][2] = hs[2]; cov[0][0] = hs[3]; cov[0][1] = hs[4]; cov[0][2] = hs[5];
+    cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+    if (centroid3) memcpy(centroid3, c, sizeof(c));
+    if (covariance9) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) covariance9[3 * i + j] = cov[i][j];
+    ppp_align::EigenSolver3f es;
+    es.compute(cov);
+    if (es.complex_pair || !es.converged) {
+        cleanup();
+        return fail(h, PPP_ERR_DOMAIN, "trans2center: the float Schur form of the covariance keeps a complex pair (two equal extents) or did not converge");
+    }
+    ppp_align::trans_align(es, c, h->TA);
+    ppp_align::inverse4(h->TA, h->invTA);
+    if (trans_align16) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) trans_align16[4 * i + j] = h->TA[i][j];
+    auto phase3 = [&]() -> int { /* pcl::transformPointCloud(*cloud, *cloud, TransAlign) */
+        Mat34 M;
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 4; ++cc) M.m[r][cc] = h->TA[r][cc];
+        LAUNCH(h, "k_transform_se3", k_transform_se3, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, M, h->X.p, h->Y.p, h->Z.p);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return PPP_OK;
+    };
+    rc = phase3();
+    cleanup();
+    if (rc != PPP_OK) return rc;
+    h->aligned = true;
+    h->drop_graph();
+    return cloud_changed(h);
 }
 
 int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_kept, double *threshold)
@@ -799,7 +938,7 @@ int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_ke
     if (threshold) *threshold = hst.threshold;
     cleanup();
     h->drop_graph();
-    return refresh_bounds_and_plan(h);
+    return cloud_changed(h);
 }
 
 int ppp_voxel_down(ppp_handle h, float lx, float ly, float lz, size_t *n_out, int *overflow)
@@ -885,7 +1024,7 @@ int ppp_voxel_down(ppp_handle h, float lx, float ly, float lz, size_t *n_out, in
     if (n_out) *n_out = h->n;
     cleanup();
     h->drop_graph();
-    return refresh_bounds_and_plan(h);
+    return cloud_changed(h);
 }
 
 int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out)
@@ -945,7 +1084,7 @@ int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out)
     if (n_out) *n_out = h->n;
     cleanup();
     h->drop_graph();
-    return refresh_bounds_and_plan(h);
+    return cloud_changed(h);
 }
 
 int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n)
@@ -1034,10 +1173,23 @@ int ppp_get_path_async(ppp_handle h)
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
     DevParams D = dev_params(h);
     int nk = std::max(1, h->S_cap);
-    LAUNCH(h, "k_pose", k_pose, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+    PoseBack PB;
+    memset(&PB, 0, sizeof(PB));
+    if (h->aligned) {
+        if (h->ranged) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment with a slice range");
+        if (!h->back || !h->back->index_built) return fail(h, PPP_ERR_ARG, "aligned cloud without its sensor-frame index");
+        PB.sorted4 = h->back->sorted4.p; PB.slab_start = h->back->slab_start.p; PB.slab_xmin = h->back->slab_xmin.p; PB.slab_xmax = h->back->slab_xmax.p;
+        PB.m = h->back->meta.p;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) PB.inv[r][c] = h->invTA[r][c];
+        LAUNCH(h, "k_pose<aligned>", k_pose<true>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+               h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
+               h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
+               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p, PB);
+    } else
+    LAUNCH(h, "k_pose", k_pose<false>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
            h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
-           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p);
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p, PB);
     h->path_done = true;
     h->list_final = false;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */

@@ -1529,6 +1529,17 @@ __host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE
 #ifndef POSE_GMAX
 #define POSE_GMAX 4
 #endif
+/* ALIGNED (trans2center ran): path_translation_alg.cpp:146-174 -- every sampled point goes through invTransAlign, and
+   the nearest point and its normal are looked up in the cloud carried back by invTransAlign (`back`: that cloud's own
+   slab index, built once by ppp_trans2center; same point indices) */
+struct PoseBack {
+    const float4 *sorted4;
+    const int *slab_start;
+    const float *slab_xmin, *slab_xmax;
+    const DevMeta *m;
+    float inv[3][4];
+};
+template <bool ALIGNED>
 __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
                                               const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                               const float *__restrict__ slab_xmax, const float *__restrict__ px,
@@ -1536,7 +1547,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                               int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
-                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx)
+                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx, PoseBack back)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     float4 *s_pts = (float4 *)s_raw;
@@ -1592,7 +1603,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
         if (bR - bc >= bc - bL) --bR; else ++bL;
     }
     int lds_lo = slab_start[bL], lds_hi = slab_start[bR + 1];
-    if (lds_hi - lds_lo > POSE_STAGE_CAP) lds_hi = lds_lo; /* one over-full slab: no staging */
+    if (lds_hi - lds_lo > POSE_STAGE_CAP || ALIGNED) lds_hi = lds_lo; /* one over-full slab: no staging (nor for the other frame's index) */
     for (int i = lds_lo + threadIdx.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
     const bool nodes_in_lds = mm <= capb;
     if (nodes_in_lds)
@@ -1600,6 +1611,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
     __syncthreads();
     STAMP(1, 0); /* staging */
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
+    if (ALIGNED) { V.sorted4 = back.sorted4; V.slab_start = back.slab_start; V.slab_xmin = back.slab_xmin; V.slab_xmax = back.slab_xmax; V.m = back.m; }
     const float *ny = nodes_in_lds ? s_ny : node_y + st, *nz = nodes_in_lds ? s_nz : node_z + st;
     const float *nx = nodes_in_lds ? s_nx : node_x + st; /* the plane x, or cloud x after the dynamic adjustment */
     auto Yf = [&](int i) { return (double)ny[i]; };
@@ -1622,7 +1634,13 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
             const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
             /* Vector4f(point) then invTransAlign (identity: Alignment=false); std::reverse on every second slice */
             const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
-            const float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
+            float4 q = make_float4((float)xd, (float)dy, (float)zd, 1.f);
+            if (ALIGNED) { /* wayPointXYZ = invTransAlign * wayPointXYZ: Matrix4f * Vector4f, the products added left to right */
+                const float ax = q.x, ay = q.y, az = q.z;
+                q.x = ((back.inv[0][0] * ax + back.inv[0][1] * ay) + back.inv[0][2] * az) + back.inv[0][3] * 1.f;
+                q.y = ((back.inv[1][0] * ax + back.inv[1][1] * ay) + back.inv[1][2] * az) + back.inv[1][3] * 1.f;
+                q.z = ((back.inv[2][0] * ax + back.inv[2][1] * ay) + back.inv[2][2] * az) + back.inv[2][3] * 1.f;
+            }
             STAMP(1, 1); /* dy accumulation + spline */
             float n4[4] = {NAN, NAN, NAN, NAN};
             const bool finite = q.x == q.x && q.y == q.y && q.z == q.z;

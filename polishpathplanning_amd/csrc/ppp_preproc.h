@@ -515,3 +515,175 @@ __global__ void __launch_bounds__(256) k_flag_compact(const float4 *__restrict__
         __syncthreads();
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* trans2center: SectPath::trans2center (path_slicing_alg.cpp:82-99; v1 Path_Generation.cpp:60-92).                     */
+/* pcl::compute3DCentroid and pcl::computeCovarianceMatrix accumulate in FLOAT, point after point: at a million points  */
+/* the rounding of those running sums moves the centroid by hundredths of a millimetre and tilts the axes by 1e-5, and  */
+/* everything downstream (band membership, pairing) is decided on the aligned coordinates -- so the sums are reproduced */
+/* bit for bit.  A running float sum is sequential, but while it stays inside one binade [2^e, 2^(e+1)) every addition  */
+/* is  S <- S + round(x / ulp)  on the integer mantissa S, ties resolved by the parity of the result.  So: one wave per  */
+/* sum, 512 values per step; each value becomes a pair (increment if S is even, increment if S is odd), the pairs are   */
+/* composed by a wave scan, every prefix is checked to stay inside the binade, and the first value that leaves it is    */
+/* added with a real float addition before the scan resumes behind it.  Non-finite points contribute +0 (PCL skips      */
+/* them).                                                                                                               */
+/* ------------------------------------------------------------------------------------------------------------------ */
+#define SEQ_E 8
+#define SEQ_CHUNK (64 * SEQ_E)
+
+__global__ void __launch_bounds__(256) k_seq_prep_centroid(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+                                                           int n, size_t stride, float *V, int *n_finite)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int fin = 0;
+    if (i < n) {
+        const float x = X[i], y = Y[i], z = Z[i];
+        fin = isfinite(x) && isfinite(y) && isfinite(z);
+        V[i] = fin ? x : 0.f; V[stride + i] = fin ? y : 0.f; V[2 * stride + i] = fin ? z : 0.f;
+    }
+    const int c = wave_sum(fin);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_finite, c);
+}
+
+/* the six products of computeCovarianceMatrix, in its order: yy yz zz, then pt *= pt.x: xx yx zx */
+__global__ void __launch_bounds__(256) k_seq_prep_cov(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+                                                      int n, float cx, float cy, float cz, size_t stride, float *V)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = X[i], y0 = Y[i], z0 = Z[i];
+    const bool fin = isfinite(x0) && isfinite(y0) && isfinite(z0);
+    const float x = x0 - cx, y = y0 - cy, z = z0 - cz;
+    V[i] = fin ? y * y : 0.f;
+    V[stride + i] = fin ? y * z : 0.f;
+    V[2 * stride + i] = fin ? z * z : 0.f;
+    V[3 * stride + i] = fin ? x * x : 0.f;
+    V[4 * stride + i] = fin ? y * x : 0.f;
+    V[5 * stride + i] = fin ? z * x : 0.f;
+}
+
+__device__ inline float seq_pick(const float (&x)[SEQ_E], int k)
+{
+    float v = x[0];
+#pragma unroll
+    for (int j = 1; j < SEQ_E; ++j) v = (k == j) ? x[j] : v;
+    return v;
+}
+__device__ inline long long shfl_ll(long long v, int src)
+{
+    const int lo = __shfl((int)(v & 0xffffffffLL), src, 64), hi = __shfl((int)(v >> 32), src, 64);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+__device__ inline long long shfl_up_ll(long long v, int d)
+{
+    const int lo = __shfl_up((int)(v & 0xffffffffLL), d, 64), hi = __shfl_up((int)(v >> 32), d, 64);
+    return ((long long)hi << 32) | (unsigned)lo;
+}
+
+/* out[b] = the float obtained by adding vals[b * stride + 0 .. n-1] to 0.f one after the other */
+__global__ void __launch_bounds__(64) k_seq_sum(const float *__restrict__ vals, size_t stride, int n, float *out)
+{
+    const float *v = vals + (size_t)blockIdx.x * stride;
+    const int lane = threadIdx.x;
+    auto load = [&](int base, float (&x)[SEQ_E]) {
+        const int i0 = base + lane * SEQ_E;
+        if (i0 + SEQ_E <= n) {
+            const float4 a = *(const float4 *)(v + i0), b = *(const float4 *)(v + i0 + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < SEQ_E; ++k) x[k] = (i0 + k < n) ? v[i0 + k] : 0.f;
+        }
+    };
+    float s = 0.f;
+    const long long LO = 1LL << 23, HI = 1LL << 24;
+    auto process = [&](const float (&x)[SEQ_E]) {
+        int done = 0;
+        while (done < SEQ_CHUNK) {
+            const int E = (int)((__float_as_uint(s) >> 23) & 0xffu);
+            if (E == 0 || E == 255) { /* zero, denormal, inf, nan: no binade to stay in */
+                s = s + __shfl(seq_pick(x, done & (SEQ_E - 1)), done / SEQ_E, 64);
+                ++done;
+                continue;
+            }
+            const double inv_u = __hiloint2double((1023 + 150 - E) << 20, 0), u = __hiloint2double((1023 + E - 150) << 20, 0);
+            const long long S0 = (long long)((double)s * inv_u); /* exact: the signed 24-bit mantissa */
+            long long de[SEQ_E], dd[SEQ_E]; /* increment when S is even / odd */
+            unsigned bigmask = 0;
+            long long ae = 0, ao = 0; /* the lane's elements composed: total increment entering with S even / odd */
+#pragma unroll
+            for (int k = 0; k < SEQ_E; ++k) {
+                const bool active = lane * SEQ_E + k >= done;
+                const double q = active ? (double)x[k] * inv_u : 0.0;
+                const bool big = !(fabs(q) < 67108864.0); /* 2^26 ulps (or not a number): leaves the binade for sure */
+                const double fl = floor(q);
+                const long long d_e = big ? 0 : (long long)rint(q);
+                const long long d_o = (!big && (q - fl) == 0.5) ? (2 * (long long)fl + 1 - d_e) : d_e;
+                de[k] = d_e; dd[k] = d_o;
+                bigmask |= (big ? 1u : 0u) << k;
+                ae += (ae & 1) ? d_o : d_e;
+                ao += ((1 + ao) & 1) ? d_o : d_e;
+            }
+            long long ie = ae, io = ao; /* inclusive scan of the compositions */
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long le = shfl_up_ll(ie, o), lo = shfl_up_ll(io, o);
+                if (lane >= o) {
+                    const long long ne = le + ((le & 1) ? io : ie), no = lo + (((1 + lo) & 1) ? io : ie);
+                    ie = ne; io = no;
+                }
+            }
+            long long xe = shfl_up_ll(ie, 1), xo = shfl_up_ll(io, 1);
+            if (lane == 0) { xe = 0; xo = 0; }
+            long long S = S0 + ((S0 & 1) ? xo : xe);
+            int bad = -1;
+            long long S_before = S;
+#pragma unroll
+            for (int k = 0; k < SEQ_E; ++k) {
+                if (lane * SEQ_E + k >= done && bad < 0) {
+                    const long long Sn = S + ((S & 1) ? dd[k] : de[k]);
+                    const long long a = Sn < 0 ? -Sn : Sn;
+                    if (((bigmask >> k) & 1u) || a <= LO || a >= HI) { bad = k; S_before = S; } /* 2^23 itself may be a sum rounded up from the finer grid below */
+                    else S = Sn;
+                }
+            }
+            const unsigned long long m = __ballot(bad >= 0);
+            if (m == 0) {
+                s = (float)((double)shfl_ll(S, 63) * u);
+                done = SEQ_CHUNK;
+            } else {
+                const int f = __ffsll((long long)m) - 1;
+                const int kf = __shfl(bad, f, 64);
+                const float s_prev = (float)((double)shfl_ll(S_before, f) * u);
+                s = s_prev + __shfl(seq_pick(x, kf), f, 64); /* the real addition across the binade boundary */
+                done = f * SEQ_E + kf + 1;
+            }
+        }
+    };
+    float c0[SEQ_E], c1[SEQ_E], c2[SEQ_E];
+    load(0, c0);
+    load(SEQ_CHUNK, c1);
+    for (int base = 0; base < n; base += SEQ_CHUNK) {
+        load(base + 2 * SEQ_CHUNK, c2); /* two chunks ahead: the loads overlap the scan */
+        process(c0);
+#pragma unroll
+        for (int k = 0; k < SEQ_E; ++k) { c0[k] = c1[k]; c1[k] = c2[k]; }
+    }
+    if (lane == 0) out[blockIdx.x] = s;
+}
+
+/* pcl::transformPointCloud with a float Matrix4f, SSE2 build (detail::Transformer<float>::se3): per row
+   m0 * x + (m1 * y + (m2 * z + m3)); non-finite points pass unchanged.  src == dst allowed. */
+struct Mat34 { float m[3][4]; };
+__global__ void __launch_bounds__(256) k_transform_se3(const float *X, const float *Y, const float *Z, int n, Mat34 T, float *X2, float *Y2, float *Z2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[i], y = Y[i], z = Z[i];
+    float o[3] = {x, y, z};
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[r] = T.m[r][0] * x + (T.m[r][1] * y + (T.m[r][2] * z + T.m[r][3]));
+    }
+    X2[i] = o[0]; Y2[i] = o[1]; Z2[i] = o[2];
+}

@@ -77,7 +77,7 @@ EXPORTS = [
     "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
-    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
         L.ppp_remove_outlier.argtypes = [vp, C.c_int, C.c_double, szp, C.POINTER(C.c_double)]
         L.ppp_voxel_down.argtypes = [vp, C.c_float, C.c_float, C.c_float, szp, C.POINTER(C.c_int)]
         L.ppp_smooth_mls.argtypes = [vp, C.c_double, C.c_int, szp]
+        L.ppp_trans2center.argtypes = [vp, fp, fp, fp]
         L.ppp_copy_stage_to_device.argtypes = [vp, C.c_int, vp, sz, szp]
         L.ppp_finish_path_async.argtypes = [vp, vp, sz, ip, sz]
         L.ppp_minmax.argtypes = [vp, fp, fp]
@@ -389,6 +390,12 @@ class Engine:
         n = C.c_size_t()
         self._chk(self.L.ppp_smooth_mls(self.h, float(radius), int(order), C.byref(n)))
         return n.value
+
+    def trans2center(self):
+        """SectPath::trans2center on the resident cloud; returns (TransAlign 4x4, centroid, accumulated covariance 3x3)."""
+        T = np.zeros(16, np.float32); c = np.zeros(3, np.float32); cov = np.zeros(9, np.float32)
+        self._chk(self.L.ppp_trans2center(self.h, _f(T), _f(c), _f(cov)))
+        return T.reshape(4, 4), c, cov.reshape(3, 3)
 
     def gather_waypoints(self, comm_ptr, rank, nranks, root, counts, recv_ptr):
         """ppp_gather_waypoints: the finished lists of all ranks to `root` over RCCL (comm_ptr = ncclComm_t)."""

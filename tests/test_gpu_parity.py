@@ -723,6 +723,88 @@ def test_mls_smooth_matches_the_oracle(engine_mod, oracle_mod, order):
         assert np.abs(we[:, :3] - wo[:, :3]).max() < 1e-4
 
 
+def _rotated_plate(t, name="small_40k"):
+    """the synthetic plate in a tilted sensor frame; draw t of a fixed sequence of rotations"""
+    pts, cfg = synth.make_config(name)
+    rng = np.random.default_rng(1)
+    for _ in range(t + 1):
+        ax, ay, az = rng.uniform(-0.6, 0.6, 3)
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (pts.astype(np.float64) @ (Rz @ Ry @ Rx).T + np.array([0.3, -0.2, 0.8])).astype(np.float32)
+
+
+@pytest.mark.parametrize("t", [7, 11, 0, 2])
+def test_trans2center_matches_the_oracle(engine_mod, oracle_mod, t):
+    """SectPath::trans2center (Alignment = true): the float running sums of pcl::compute3DCentroid / computeCovarianceMatrix
+    bit for bit, the same TransAlign, the same aligned cloud; then getPath through invTransAlign with the nearest point
+    and the normals taken in the cloud carried back (path_translation_alg.cpp:146-174).  Rotations 7 and 11 leave the
+    thin axis third (a plan that makes sense, 11 through a reflection); 0 and 2 leave it second, where the reference's
+    unsorted eigenvectors slice the sheet across its thickness -- both sides must still do the same thing."""
+    pts = _rotated_plate(t)
+    pts[5] = np.nan
+    o = oracle_mod.Oracle(pts, tool_radius=6.0)
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    rc, To, co, covo = o.trans2center()
+    Te, ce, cove = e.trans2center()
+    assert rc == 0
+    assert ce.tobytes() == co.tobytes() and cove.tobytes() == covo.tobytes()
+    assert Te.tobytes() == To.tobytes()
+    assert np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(o.points()))
+    ext = np.nanmax(o.points(), axis=0) - np.nanmin(o.points(), axis=0)
+    if t in (7, 11):
+        assert ext[2] < 5 < ext[1] < ext[0]
+        assert_full_parity(engine_mod, e, o)
+    else:
+        So = o.gen_path()
+        try:
+            S = e.gen_path()
+        except engine_mod.PPPError:
+            S = -1
+        assert (S > 0) == (So > 0)
+        if So > 0:
+            assert S == So
+            no = o.get_path()
+            try:
+                e.get_path(); ne = len(e.waypoints())
+            except engine_mod.PPPError:
+                ne = -1
+            assert (ne >= 0) == (no >= 0)
+            if no > 0:
+                assert ne == no and np.abs(e.waypoints()[:, :3] - o.waypoints()[:, :3]).max() < 1e-4
+    with pytest.raises(engine_mod.PPPError):
+        e.trans2center()                      # TransAlign would be overwritten
+    e.set_cloud(pts)                          # a new cloud is unaligned again
+    assert np.array_equal(np.nan_to_num(e.cloud()), np.nan_to_num(pts * np.float32(1000)))
+    e.trans2center()
+
+
+def test_running_float_sums_are_exact_at_a_million_points(engine_mod):
+    """The wave-scan reproduction of a sequential float sum (k_seq_sum) against numpy's add.accumulate in float32:
+    a million points far from the origin (many binades crossed on the way up), NaNs skipped, mixed signs."""
+    pts, cfg = synth.make_config("cfg2_1m_s256")
+    pts = pts.copy()
+    pts[::1000] = np.nan
+    pts[:, 1] -= 0.35                                          # y on both sides of zero: the running sum turns around
+    e = engine_mod.Engine(0, tool_radius=6.0)
+    e.set_cloud(pts)
+    P = e.cloud()                                              # x1000, float
+    T, c, cov = e.trans2center()
+    fin = np.isfinite(P).all(axis=1)
+    Q = P[fin]
+    cnt = np.float32(len(Q))
+    c_np = np.array([np.add.accumulate(Q[:, d], dtype=np.float32)[-1] / cnt for d in range(3)], np.float32)
+    assert c.tobytes() == c_np.tobytes()
+    D = Q - c_np
+    want = np.zeros((3, 3), np.float32)
+    for (i, j) in [(1, 1), (1, 2), (2, 2), (0, 0), (0, 1), (0, 2)]:
+        prod = (D[:, j] * D[:, i]).astype(np.float32) if i == 0 else (D[:, i] * D[:, j]).astype(np.float32)
+        want[i, j] = want[j, i] = np.add.accumulate(prod, dtype=np.float32)[-1]
+    assert cov.tobytes() == want.tobytes()
+
+
 def test_distinct_handles_from_concurrent_host_threads(engine_mod):
     """thread-compatible -- distinct handles may be driven from different host threads at once
     (own stream, own graph capture in thread-local mode, no globals)."""
