@@ -29,7 +29,7 @@ public:
 
     void show() { planner.show_notice(); }
     void voxel_down(const float x, const float y, const float z) { planner.voxel_down(x, y, z); } /* Path_Generation.cpp:53-59 */
-    void trans2center() { note("trans2center"); }
+    void trans2center() { planner.trans2center(); } /* Path_Generation.cpp:60-92 */
     void smooth() { planner.smooth_mls(15, 3, file_name, true); } /* Path_Generation.cpp:340-360 */
     void Set_kdtree() {}
     void estimate_normal() {}

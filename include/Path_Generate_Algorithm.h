@@ -7,7 +7,8 @@
  *   - Dynamic_adjustment = true runs the curvature-driven re-spacing (path_dynamic_alg.cpp:77-306)
  *     on the GPU, RemoveOutlier = true the statistical outlier removal (path_slicing_alg.cpp:101-108),
  *     Smooth = true the moving-least-squares smoothing (path_slicing_alg.cpp:111-139);
- *     Alignment = true is reported and ignored;
+ *     Alignment = true the PCA alignment (path_slicing_alg.cpp:82-99; eigenvector order as Eigen's EigenSolver
+ *     leaves it);
  *   - conditions on which the reference aborts (GSL / FLANN) are reported on stderr instead.
  * Build connect1's single-direction walk with -DPPP_SDIR (it links dynamic_alg_sdir.cpp in the
  * reference, CMakeLists.txt:38-47).
@@ -37,10 +38,13 @@ public:
         init_common();
         planner.open(cloud_name);
         if (ifSmooth) smooth();         /* path_slicing_alg.cpp:27 */
+        if (ifAlign) trans2center();    /* path_slicing_alg.cpp:28 */
         if (ifRemove) remove_outlier(); /* path_slicing_alg.cpp:29 */
     }
     virtual ~SectPath() {}
 
+    /* path_slicing_alg.cpp:82-99: PCA alignment; getPath then goes back through the inverse (path_translation_alg.cpp:146-174) */
+    void trans2center() { planner.trans2center(); }
     /* path_slicing_alg.cpp:111-139: pcl::MovingLeastSquares, order 3, radius 15, and the smooth_<name> side file */
     void smooth() { planner.smooth_mls(15, 3, cloud_name, ifChangeRange); }
 
@@ -76,8 +80,6 @@ protected:
         toolRadius = c.params.tool_radius; PathResolution = c.params.path_resolution; RPYres = c.params.rpy_resolution;
         EElen = c.params.ee_length; ifChangeRange = c.params.change_range; ifAlign = c.alignment; ifSmooth = c.smooth_cloud;
         ifRemove = c.remove_outlier; pathFile = c.path_file;
-        if (ifAlign)
-            fprintf(stderr, "ppp: Alignment is outside the accelerated path and is ignored (SURVEY.md 8f rank 3)\n");
     }
     void init_common()
     {
@@ -122,6 +124,7 @@ public:
         init_common();
         planner.open(cloud_name);
         if (ifSmooth) smooth();         /* path_dynamic_alg.cpp:29 */
+        if (ifAlign) trans2center();    /* path_dynamic_alg.cpp:30 */
         if (ifRemove) remove_outlier(); /* path_dynamic_alg.cpp:32 */
     }
     void GenPath() override

@@ -113,6 +113,12 @@ public:
         if (ppp_save_pcd(side.c_str(), xyz.data(), n, 3, vp, 0) != PPP_OK) std::fprintf(stderr, "ppp: could not write %s\n", side.c_str());
         return true;
     }
+    bool trans2center()
+    {
+        if (!ok()) return false;
+        int rc = ppp_trans2center(h_, nullptr, nullptr, nullptr);
+        return rc == PPP_OK ? true : report(rc);
+    }
     bool apply_params()
     {
         int rc = ppp_set_params(h_, &cfg_.params);

@@ -817,27 +817,23 @@ int ppp_trans2center(ppp_handle h, float *trans_align16, float *centroid3, float
     if (n == 0 || h->h_nvalid == 0) return fail(h, PPP_ERR_ARG, "no finite point to align");
     const size_t stride = ((size_t)n + 3) & ~(size_t)3;
     DevBuf<float> V, sums;
-    DevBuf<int> cnt;
-    auto cleanup = [&]() { V.release(); sums.release(); cnt.release(); };
+    auto cleanup = [&]() { V.release(); sums.release(); };
     hipError_t e = V.ensure(6 * stride);
     if (e == hipSuccess) e = sums.ensure(8);
-    if (e == hipSuccess) e = cnt.ensure(1);
     if (e != hipSuccess) { cleanup(); return fail(h, PPP_ERR_HIP, std::string("trans2center buffers: ") + hipGetErrorString(e)); }
     float hs[6] = {0, 0, 0, 0, 0, 0}, c[3] = {0, 0, 0};
-    int hcnt = 0;
+    const int hcnt = h->h_nvalid; /* the finite points, counted with the bounds */
     const unsigned gb = (unsigned)((n + 255) / 256);
     auto phase1 = [&]() -> int { /* pcl::compute3DCentroid: three running float sums, / float(count) */
-        HIPCHK(h, hipMemsetAsync(cnt.p, 0, sizeof(int), h->stream));
-        LAUNCH(h, "k_seq_prep_centroid", k_seq_prep_centroid, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, stride, V.p, cnt.p);
-        LAUNCH(h, "k_seq_sum", k_seq_sum, 3, 64, 0, V.p, stride, n, sums.p);
+        LAUNCH(h, "k_seq_prep_centroid", k_seq_prep_centroid, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, stride, V.p);
+        LAUNCH(h, "k_seq_sum", k_seq_sum, 3, 64 * SEQ_WAVES, 0, V.p, stride, n, sums.p);
         HIPCHK(h, hipMemcpyAsync(hs, sums.p, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(&hcnt, cnt.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return PPP_OK;
     };
     auto phase2 = [&]() -> int { /* pcl::computeCovarianceMatrix: six running float sums of float products */
         LAUNCH(h, "k_seq_prep_cov", k_seq_prep_cov, gb, 256, 0, h->X.p, h->Y.p, h->Z.p, n, c[0], c[1], c[2], stride, V.p);
-        LAUNCH(h, "k_seq_sum", k_seq_sum, 6, 64, 0, V.p, stride, n, sums.p);
+        LAUNCH(h, "k_seq_sum", k_seq_sum, 6, 64 * SEQ_WAVES, 0, V.p, stride, n, sums.p);
         HIPCHK(h, hipMemcpyAsync(hs, sums.p, 6 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return PPP_OK;

@@ -532,17 +532,13 @@ __global__ void __launch_bounds__(256) k_flag_compact(const float4 *__restrict__
 #define SEQ_CHUNK (64 * SEQ_E)
 
 __global__ void __launch_bounds__(256) k_seq_prep_centroid(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
-                                                           int n, size_t stride, float *V, int *n_finite)
+                                                           int n, size_t stride, float *V)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int fin = 0;
-    if (i < n) {
-        const float x = X[i], y = Y[i], z = Z[i];
-        fin = isfinite(x) && isfinite(y) && isfinite(z);
-        V[i] = fin ? x : 0.f; V[stride + i] = fin ? y : 0.f; V[2 * stride + i] = fin ? z : 0.f;
-    }
-    const int c = wave_sum(fin);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_finite, c);
+    if (i >= n) return;
+    const float x = X[i], y = Y[i], z = Z[i];
+    const bool fin = isfinite(x) && isfinite(y) && isfinite(z);
+    V[i] = fin ? x : 0.f; V[stride + i] = fin ? y : 0.f; V[2 * stride + i] = fin ? z : 0.f;
 }
 
 /* the six products of computeCovarianceMatrix, in its order: yy yz zz, then pt *= pt.x: xx yx zx */
@@ -569,107 +565,159 @@ __device__ inline float seq_pick(const float (&x)[SEQ_E], int k)
     for (int j = 1; j < SEQ_E; ++j) v = (k == j) ? x[j] : v;
     return v;
 }
-__device__ inline long long shfl_ll(long long v, int src)
+/* out[b] = the float obtained by adding vals[b * stride + 0 .. n-1] to 0.f one after the other.
+   One workgroup of 16 waves per sum, a tile of 16 x 512 values per step: every wave composes its 512 values (wave scan),
+   the 16 chunk totals are composed in order, every lane replays its 8 values from the now known mantissa and checks the
+   binade; the first value that leaves it (if any) is added for real and the tile resumes behind it.  The next tile's
+   loads are in flight meanwhile.  Mantissa arithmetic in int32: before the first value that leaves the binade every
+   prefix is below 2^24 in magnitude, so the wrapped sums are exact there (and parities survive wrapping); whatever
+   lies behind that value is not used.  Sums that change binade all the time fall back to plain additions by one
+   lane for a stretch (see below): 2 ns per value, against 0.4 ns in the scan. */
+#define SEQ_WAVES 16
+#define SEQ_TILE (SEQ_WAVES * SEQ_CHUNK)
+#define SEQ_SERIAL_BELOW 2048
+#define SEQ_SERIAL_RUN 4096
+__global__ void __launch_bounds__(64 * SEQ_WAVES) k_seq_sum(const float *__restrict__ vals, size_t stride, int n, float *out)
 {
-    const int lo = __shfl((int)(v & 0xffffffffLL), src, 64), hi = __shfl((int)(v >> 32), src, 64);
-    return ((long long)hi << 32) | (unsigned)lo;
-}
-__device__ inline long long shfl_up_ll(long long v, int d)
-{
-    const int lo = __shfl_up((int)(v & 0xffffffffLL), d, 64), hi = __shfl_up((int)(v >> 32), d, 64);
-    return ((long long)hi << 32) | (unsigned)lo;
-}
-
-/* out[b] = the float obtained by adding vals[b * stride + 0 .. n-1] to 0.f one after the other */
-__global__ void __launch_bounds__(64) k_seq_sum(const float *__restrict__ vals, size_t stride, int n, float *out)
-{
+    __shared__ float s_x[SEQ_TILE];
+    __shared__ int s_te[SEQ_WAVES], s_to[SEQ_WAVES], s_bad[SEQ_WAVES], s_sb[SEQ_WAVES], s_send;
+    __shared__ float s_s;
+    __shared__ int s_done;
     const float *v = vals + (size_t)blockIdx.x * stride;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int slot = w * SEQ_CHUNK + lane * SEQ_E; /* this lane's 8 values inside the tile */
     auto load = [&](int base, float (&x)[SEQ_E]) {
-        const int i0 = base + lane * SEQ_E;
+        const int i0 = base + slot;
         if (i0 + SEQ_E <= n) {
             const float4 a = *(const float4 *)(v + i0), b = *(const float4 *)(v + i0 + 4);
             x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < SEQ_E; ++k) x[k] = (i0 + k < n) ? v[i0 + k] : 0.f;
+            for (int k = 0; k < SEQ_E; ++k) x[k] = (i0 + k < n) ? v[i0 + k] : 0.f; /* past the end: +0 */
         }
     };
-    float s = 0.f;
-    const long long LO = 1LL << 23, HI = 1LL << 24;
-    auto process = [&](const float (&x)[SEQ_E]) {
-        int done = 0;
-        while (done < SEQ_CHUNK) {
+    if (threadIdx.x == 0) s_s = 0.f;
+    const int LO = 1 << 23, HI = 1 << 24;
+    float xr[SEQ_E], x[SEQ_E];
+    load(0, xr);
+    for (int base = 0; base < n; base += SEQ_TILE) {
+#pragma unroll
+        for (int k = 0; k < SEQ_E; ++k) { x[k] = xr[k]; s_x[slot + k] = x[k]; }
+        if (threadIdx.x == 0) s_done = 0;
+        load(base + SEQ_TILE, xr); /* in flight while this tile is worked through */
+        __syncthreads();
+        for (;;) {
+            const int done = s_done;
+            if (done >= SEQ_TILE) break;
+            const float s = s_s;
             const int E = (int)((__float_as_uint(s) >> 23) & 0xffu);
-            if (E == 0 || E == 255) { /* zero, denormal, inf, nan: no binade to stay in */
-                s = s + __shfl(seq_pick(x, done & (SEQ_E - 1)), done / SEQ_E, 64);
-                ++done;
+            if (E < 24 || E == 255) { /* zero, tiny, inf, nan: no binade to work in -- one real addition */
+                __syncthreads();
+                if (threadIdx.x == 0) { s_s = s + s_x[done]; s_done = done + 1; }
+                __syncthreads();
                 continue;
             }
-            const double inv_u = __hiloint2double((1023 + 150 - E) << 20, 0), u = __hiloint2double((1023 + E - 150) << 20, 0);
-            const long long S0 = (long long)((double)s * inv_u); /* exact: the signed 24-bit mantissa */
-            long long de[SEQ_E], dd[SEQ_E]; /* increment when S is even / odd */
+            const float inv_u = __uint_as_float((unsigned)(127 + 150 - E) << 23), u = __uint_as_float((unsigned)(127 + E - 150) << 23);
+            const int S0 = (int)(s * inv_u); /* exact: the signed 24-bit mantissa */
+            int de[SEQ_E], dd[SEQ_E]; /* increment when S is even / odd */
             unsigned bigmask = 0;
-            long long ae = 0, ao = 0; /* the lane's elements composed: total increment entering with S even / odd */
+            int ae = 0, ao = 0; /* the lane's values composed: total increment entering with S even / odd */
 #pragma unroll
             for (int k = 0; k < SEQ_E; ++k) {
-                const bool active = lane * SEQ_E + k >= done;
-                const double q = active ? (double)x[k] * inv_u : 0.0;
-                const bool big = !(fabs(q) < 67108864.0); /* 2^26 ulps (or not a number): leaves the binade for sure */
-                const double fl = floor(q);
-                const long long d_e = big ? 0 : (long long)rint(q);
-                const long long d_o = (!big && (q - fl) == 0.5) ? (2 * (long long)fl + 1 - d_e) : d_e;
+                const bool active = slot + k >= done;
+                const float q = active ? x[k] * inv_u : 0.f; /* exact scaling by a power of two */
+                const bool big = !(fabsf(q) < 67108864.f); /* 2^26 ulps (or not a number): leaves the binade for sure */
+                const float fl = floorf(q);
+                const int d_e = big ? 0 : (int)rintf(q); /* ties to even: the increment that keeps an even S even */
+                const int d_o = (!big && (q - fl) == 0.5f) ? (2 * (int)fl + 1 - d_e) : d_e;
                 de[k] = d_e; dd[k] = d_o;
                 bigmask |= (big ? 1u : 0u) << k;
                 ae += (ae & 1) ? d_o : d_e;
                 ao += ((1 + ao) & 1) ? d_o : d_e;
             }
-            long long ie = ae, io = ao; /* inclusive scan of the compositions */
+            int ie = ae, io = ao; /* inclusive wave scan of the compositions */
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
-                const long long le = shfl_up_ll(ie, o), lo = shfl_up_ll(io, o);
+                const int le = __shfl_up(ie, o, 64), lo = __shfl_up(io, o, 64);
                 if (lane >= o) {
-                    const long long ne = le + ((le & 1) ? io : ie), no = lo + (((1 + lo) & 1) ? io : ie);
+                    const int ne = le + ((le & 1) ? io : ie), no = lo + (((1 + lo) & 1) ? io : ie);
                     ie = ne; io = no;
                 }
             }
-            long long xe = shfl_up_ll(ie, 1), xo = shfl_up_ll(io, 1);
+            int xe = __shfl_up(ie, 1, 64), xo = __shfl_up(io, 1, 64);
             if (lane == 0) { xe = 0; xo = 0; }
-            long long S = S0 + ((S0 & 1) ? xo : xe);
-            int bad = -1;
-            long long S_before = S;
+            if (lane == 63) { s_te[w] = ie; s_to[w] = io; }
+            __syncthreads();
+            int pe = 0, po = 0; /* the chunks before this wave's, composed */
+            for (int c = 0; c < w; ++c) {
+                const int ce = s_te[c], co = s_to[c];
+                const int ne = pe + ((pe & 1) ? co : ce), no = po + (((1 + po) & 1) ? co : ce);
+                pe = ne; po = no;
+            }
+            const int Sc = S0 + ((S0 & 1) ? po : pe);
+            int S = Sc + ((Sc & 1) ? xo : xe);
+            int bad = -1, S_before = S;
 #pragma unroll
             for (int k = 0; k < SEQ_E; ++k) {
-                if (lane * SEQ_E + k >= done && bad < 0) {
-                    const long long Sn = S + ((S & 1) ? dd[k] : de[k]);
-                    const long long a = Sn < 0 ? -Sn : Sn;
-                    if (((bigmask >> k) & 1u) || a <= LO || a >= HI) { bad = k; S_before = S; } /* 2^23 itself may be a sum rounded up from the finer grid below */
+                if (slot + k >= done && bad < 0) {
+                    const int Sn = S + ((S & 1) ? dd[k] : de[k]);
+                    const int a = Sn < 0 ? -Sn : Sn;
+                    /* 2^23 itself may be a sum rounded up from the finer grid below: leave it to the real addition too */
+                    if (((bigmask >> k) & 1u) || a <= LO || a >= HI) { bad = k; S_before = S; }
                     else S = Sn;
                 }
             }
             const unsigned long long m = __ballot(bad >= 0);
             if (m == 0) {
-                s = (float)((double)shfl_ll(S, 63) * u);
-                done = SEQ_CHUNK;
+                if (lane == 63) { s_bad[w] = 0x7fffffff; if (w == SEQ_WAVES - 1) s_send = S; }
             } else {
                 const int f = __ffsll((long long)m) - 1;
-                const int kf = __shfl(bad, f, 64);
-                const float s_prev = (float)((double)shfl_ll(S_before, f) * u);
-                s = s_prev + __shfl(seq_pick(x, kf), f, 64); /* the real addition across the binade boundary */
-                done = f * SEQ_E + kf + 1;
+                if (lane == f) { s_bad[w] = slot + bad; s_sb[w] = S_before; }
             }
-        }
-    };
-    float c0[SEQ_E], c1[SEQ_E], c2[SEQ_E];
-    load(0, c0);
-    load(SEQ_CHUNK, c1);
-    for (int base = 0; base < n; base += SEQ_CHUNK) {
-        load(base + 2 * SEQ_CHUNK, c2); /* two chunks ahead: the loads overlap the scan */
-        process(c0);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int c = 0;
+                while (c < SEQ_WAVES && s_bad[c] == 0x7fffffff) ++c; /* chunks before the first violation are exact */
+                if (c == SEQ_WAVES) { s_s = (float)s_send * u; s_done = SEQ_TILE; }
+                else {
+                    const int b = s_bad[c];
+                    float sv = (float)s_sb[c] * u + s_x[b]; /* the real addition across the binade boundary */
+                    int d = b + 1;
+                    /* a sum that hovers around zero (a centred coordinate, an off-diagonal product) changes binade every
+                       few hundred values: a parallel step costs about as much as 1500 plain additions by one lane, so
+                       after a short run the next stretch is simply added one value after the other */
+                    if (b - done < SEQ_SERIAL_BELOW) {
+                        const int end = min(SEQ_TILE, d + SEQ_SERIAL_RUN);
+                        /* batches of 32 LDS reads issued ahead of the 32 dependent additions that consume them */
+                        float cur[32], nxt[32];
+                        if (d + 32 <= end) {
 #pragma unroll
-        for (int k = 0; k < SEQ_E; ++k) { c0[k] = c1[k]; c1[k] = c2[k]; }
+                            for (int k = 0; k < 32; ++k) cur[k] = s_x[d + k];
+                        }
+                        while (d + 32 <= end) {
+                            const bool more = d + 64 <= end;
+                            if (more) {
+#pragma unroll
+                                for (int k = 0; k < 32; ++k) nxt[k] = s_x[d + 32 + k];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 32; ++k) sv = sv + cur[k];
+                            d += 32;
+                            if (more) {
+#pragma unroll
+                                for (int k = 0; k < 32; ++k) cur[k] = nxt[k];
+                            }
+                        }
+                        for (; d < end; ++d) sv = sv + s_x[d];
+                    }
+                    s_s = sv; s_done = d;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
     }
-    if (lane == 0) out[blockIdx.x] = s;
+    if (threadIdx.x == 0) out[blockIdx.x] = s_s;
 }
 
 /* pcl::transformPointCloud with a float Matrix4f, SSE2 build (detail::Transformer<float>::se3): per row

@@ -290,15 +290,17 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize("dynamic,remove,smooth", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 1, 1)])
-def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remove, smooth):
+@pytest.mark.parametrize("dynamic,remove,smooth,align", [(0, 0, 0, 0), (1, 0, 0, 0), (0, 1, 0, 0), (0, 1, 1, 0), (0, 1, 0, 1), (1, 0, 0, 1)])
+def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remove, smooth, align):
     """The drop-in C++ classes (include/Path_Generate_Algorithm.h) driven like src/connect.cpp:
     PCD in, pathFile out; with and without Dynamic_adjustment (config.txt:13), RemoveOutlier (config.txt:11) and
-    Smooth (config.txt:9, with its smooth_<name> side file)."""
+    Smooth (config.txt:9, with its smooth_<name> side file) and Alignment (config.txt:10, on a tilted plate)."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "connect1", "main"], stdout=subprocess.DEVNULL)
     pts, cfg = synth.make_config("small_40k")
+    if align:
+        pts = _rotated_plate(7)
     if remove:   # a few points floating above the sheet
         rng = np.random.default_rng(9)
         fly = pts[rng.integers(0, len(pts), 30)].copy()
@@ -309,9 +311,9 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
     out = str(tmp_path / "WayPoints.txt")
     conf = tmp_path / "config.txt"
     conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
-                    "Smooth = %s\nAlignment = false\nChangeRange = true\nRemoveOutlier = %s\nDynamic_adjustment = %s\n"
+                    "Smooth = %s\nAlignment = %s\nChangeRange = true\nRemoveOutlier = %s\nDynamic_adjustment = %s\n"
                     "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n"
-                    % (out, "true" if smooth else "false", "true" if remove else "false", "true" if dynamic else "false"))
+                    % (out, "true" if smooth else "false", "true" if align else "false", "true" if remove else "false", "true" if dynamic else "false"))
     env = dict(os.environ, PPP_CONFIG=str(conf))
     if smooth:
         pcd = "workpiece.pcd"               # "smooth_" + name must be a writable path: run in the directory
@@ -327,14 +329,17 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
             assert len(pts) - 30 <= o.smooth_mls(15.0, 3) <= len(pts)   # flyers more than 15 mm from the sheet have no neighbours
             side = engine_mod.load_pcd(str(tmp_path / "smooth_workpiece.pcd"))[0]
             assert np.abs(side * 1000.0 - o.points()).max() < 2e-3      # ascii, metres
+        if align:
+            assert o.trans2center()[0] == 0
         if remove:
             assert o.remove_outlier(50, 1.0)[0] < len(pts)
         o.gen_path(); o.get_path()
         want = o.waypoints()
         assert got.shape == want.shape
         assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 + 5e-6 * np.abs(want[:, :3]).max()  # 6 significant digits in the file
-    r = subprocess.run([os.path.join(root, "examples", "main"), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
-    assert r.returncode == 0 and "number of paths" in r.stdout
+    if not align:       # ./main never aligns (main.cpp:26 is commented out): it needs the plate in its own frame
+        r = subprocess.run([os.path.join(root, "examples", "main"), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 0 and "number of paths" in r.stdout
 
 
 @pytest.mark.parametrize("walk", [0, 1, 2, 3, 4])

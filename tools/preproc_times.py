@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall-clock of the cloud preprocessing entry points on the GPU for one synthetic cloud:
-   remove_outlier (SOR 50 / 1 sigma), voxel_down (main.cpp:25's 0.1 x 1 x 1 and a 3 mm cube), MLS smooth (order 3, r 15).
+   remove_outlier (SOR 50 / 1 sigma), trans2center, voxel_down (main.cpp:25's 0.1 x 1 x 1 and a 3 mm cube), MLS smooth (order 3, r 15).
    usage: preproc_times.py [config name, default cfg2_1m_s256] [--oracle N]   (--oracle: time the CPU port on the first N points' plate)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,13 +14,14 @@ def main():
     def fresh():
         e = engine.Engine(0, tool_radius=6.0)
         e.set_cloud(pts)
-        e.nearest(np.zeros((1, 3), np.float32))   # builds the slab index outside the timings
+        e.nearest(pts[:1] * 1000)   # builds the slab index outside the timings
         return e
     for label, fn in [("remove_outlier(50, 1.0)", lambda e: e.remove_outlier(50, 1.0)),
                       ("voxel_down(0.1, 1, 1)", lambda e: e.voxel_down(0.1, 1.0, 1.0)),
                       ("voxel_down(3, 3, 3)", lambda e: e.voxel_down(3.0, 3.0, 3.0)),
                       ("smooth_mls(15, 3)", lambda e: e.smooth_mls(15.0, 3)),
-                      ("smooth_mls(15, 2)", lambda e: e.smooth_mls(15.0, 2))]:
+                      ("smooth_mls(15, 2)", lambda e: e.smooth_mls(15.0, 2)),
+                      ("trans2center()", lambda e: e.trans2center()[1])]:
         best = 1e9
         res = None
         for rep in range(3):
