@@ -579,7 +579,7 @@ __device__ inline float seq_pick(const float (&x)[SEQ_E], int k)
 #define SEQ_SERIAL_RUN 4096
 __global__ void __launch_bounds__(64 * SEQ_WAVES) k_seq_sum(const float *__restrict__ vals, size_t stride, int n, float *out)
 {
-    __shared__ float s_x[SEQ_TILE];
+    __shared__ __attribute__((aligned(16))) float s_x[SEQ_TILE];
     __shared__ int s_te[SEQ_WAVES], s_to[SEQ_WAVES], s_bad[SEQ_WAVES], s_sb[SEQ_WAVES], s_send;
     __shared__ float s_s;
     __shared__ int s_done;
@@ -688,25 +688,26 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) k_seq_sum(const float *__restr
                        after a short run the next stretch is simply added one value after the other */
                     if (b - done < SEQ_SERIAL_BELOW) {
                         const int end = min(SEQ_TILE, d + SEQ_SERIAL_RUN);
-                        /* batches of 32 LDS reads issued ahead of the 32 dependent additions that consume them */
-                        float cur[32], nxt[32];
-                        if (d + 32 <= end) {
+                        /* 128-bit LDS reads issued a batch ahead of the dependent additions that consume them */
+                        while (d < end && (d & 3)) { sv = sv + s_x[d]; ++d; }
+                        const float4 *x4 = (const float4 *)s_x;
+                        float4 A[8], Bq[8];
+                        if (d + 64 <= end) {
 #pragma unroll
-                            for (int k = 0; k < 32; ++k) cur[k] = s_x[d + k];
+                            for (int k = 0; k < 8; ++k) A[k] = x4[(d >> 2) + k];
                         }
-                        while (d + 32 <= end) {
-                            const bool more = d + 64 <= end;
-                            if (more) {
+                        while (d + 64 <= end) {
 #pragma unroll
-                                for (int k = 0; k < 32; ++k) nxt[k] = s_x[d + 32 + k];
+                            for (int k = 0; k < 8; ++k) Bq[k] = x4[(d >> 2) + 8 + k];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { sv = sv + A[k].x; sv = sv + A[k].y; sv = sv + A[k].z; sv = sv + A[k].w; }
+                            if (d + 128 <= end) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) A[k] = x4[(d >> 2) + 16 + k];
                             }
 #pragma unroll
-                            for (int k = 0; k < 32; ++k) sv = sv + cur[k];
-                            d += 32;
-                            if (more) {
-#pragma unroll
-                                for (int k = 0; k < 32; ++k) cur[k] = nxt[k];
-                            }
+                            for (int k = 0; k < 8; ++k) { sv = sv + Bq[k].x; sv = sv + Bq[k].y; sv = sv + Bq[k].z; sv = sv + Bq[k].w; }
+                            d += 64;
                         }
                         for (; d < end; ++d) sv = sv + s_x[d];
                     }
