@@ -650,6 +650,15 @@ def test_randomised_sweep_against_the_oracle(engine_mod, oracle_mod):
                 bad.append((desc, res))
     finally:
         del os.environ["PPP_FUZZ_TINY"]
+    os.environ["PPP_FUZZ_PRE"] = "1"  # and 40 with the constructors' preprocessing (voxel grid, MLS, alignment of a tilted plate) in front
+    try:
+        rng = np.random.default_rng(41)
+        for i in range(40):
+            res, desc = fz.one_case(rng, i)
+            if res is not None and not res.startswith("both fail"):
+                bad.append((desc, res))
+    finally:
+        del os.environ["PPP_FUZZ_PRE"]
     rng = np.random.default_rng(31)   # and 8 clouds of 0.2 .. 1.5 M points (long dynamic chains, many slabs)
     for i in range(8):
         res, desc = fz.one_case(rng, i, big=True)
