@@ -531,7 +531,7 @@ int enqueue_meta_copy(ppp_handle h)
 
 int map_dev_err(ppp_handle h)
 {
-    if (h->hmeta.err == DERR_CAPACITY && !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0))
+    if (!h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0))
         return fail(h, PPP_ERR_CAPACITY, "a slab or band exceeds the LDS capacity: re-run (the arena passes are now enabled)");
     switch (h->hmeta.err) {
     case DERR_NONE: return PPP_OK;
@@ -564,7 +564,8 @@ int rerun_with_arena(ppp_handle h)
 
 bool overflowed_fast_path(ppp_handle h)
 {
-    return h->hmeta.err == DERR_CAPACITY && !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0);
+    /* (a GenPath on its own leaves no error behind: the slices parked for the arena pass are simply not planned yet) */
+    return !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0);
 }
 
 int ensure_ready(ppp_handle h, bool need_gen, bool need_path)
@@ -1130,7 +1131,11 @@ int ppp_gen_path_async(ppp_handle h)
     } else {
         LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p,
-               h->node_cnt.p, h->band_cnt.p);
+               h->node_cnt.p, h->band_cnt.p, h->big_slices.p);
+        if (h->big_path)
+            LAUNCH(h, "k_slice_brute_arena", k_slice_brute_arena, h->S_cap, 1024, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+                   h->lo.p, h->hi.p, h->P.pairing, (int)h->n, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p,
+                   h->node_cnt.p, h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
     }
     if (h->P.dynamic_adjustment) {
         int rc2 = enqueue_dynamic(h);

@@ -709,7 +709,7 @@ __device__ inline int flatten_nodes(const SliceLds &L, int ncand, float *out_y, 
 __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                const float *__restrict__ hi, int pairing, int capb, float *node_x, float *node_y,
-                                               float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt)
+                                               float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
@@ -723,8 +723,8 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
     SliceLds L = carve_slice_lds(s_raw, capb);
     const float Px = px[s];
     int n = band_gather_sorted(L, capb, sorted4, slab_start, m, lo[s], hi[s], &s_n);
-    if (n < 0) {
-        if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = s_n; }
+    if (n < 0) { /* does not fit LDS: leave it to the arena pass (k_slice_brute_arena) */
+        if (threadIdx.x == 0) { big_list[atomicAdd(&m->big_slices, 1)] = s; node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = s_n; }
         return;
     }
     if (threadIdx.x == 0) band_cnt[s] = n;
@@ -751,6 +751,209 @@ __global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted
     if (node_cnt[s] == 0 && tot != 0) return;
     flatten_nodes(L, ncand, node_y + s_base, node_z + s_base, tot, s_scr);
     for (int i = threadIdx.x; i < tot; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
+}
+
+/* insert_point of v1 (Path_Generation.cpp:107-206, either pairing) for a band that does not fit LDS: the same steps as
+   insert_point_lds on a segment of the arena, 32-bit positions, one workgroup per listed slice.  The greedy flag walk is
+   one thread over global memory -- this is the rare path of a very dense band, exact before fast. */
+__host__ __device__ inline size_t slice_brute_bytes(size_t n)
+{   /* a4 16 + keys 8 + el er rstar lstar pairL pairR 24 + hist 4 (NB <= n) + flags */
+    return n * 52 + (n / 4) + 256;
+}
+__global__ void __launch_bounds__(1024) k_slice_brute_arena(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+                                                            DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
+                                                            const float *__restrict__ hi, int pairing, int ncloud, float *node_x, float *node_y,
+                                                            float *node_z, int node_cap, int *node_start, int *node_cnt, const int *band_cnt,
+                                                            const int *big_list, char *arena, unsigned long long arena_cap)
+{
+    __shared__ int s_scr[17];
+    __shared__ int s_n, s_nl, s_nr, s_np, s_base, s_m;
+    __shared__ unsigned long long s_off;
+    if ((int)blockIdx.x >= m->big_slices) return;
+    const int s = big_list[blockIdx.x];
+    const size_t cap = (size_t)band_cnt[s];
+    const unsigned long long need = slice_brute_bytes(cap);
+    if (threadIdx.x == 0) { s_off = atomicAdd(&m->arena_cursor, (need + 15) & ~15ull); s_n = 0; s_nl = 0; s_nr = 0; s_m = 0; }
+    __syncthreads();
+    if (s_off + need > arena_cap) {
+        if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
+        return;
+    }
+    char *mem = arena + s_off;
+    float4 *a4 = (float4 *)mem;
+    u64 *keys = (u64 *)(a4 + cap);
+    int *el = (int *)(keys + cap), *er = el + cap, *rstar = er + cap, *lstar = rstar + cap, *pairL = lstar + cap, *pairR = pairL + cap;
+    int *hist = pairR + cap;                    /* cap + 1 ints at most (NB <= cap / 2 .. cap) */
+    u64 *flags = (u64 *)(((uintptr_t)(hist + cap + 2) + 7) & ~(uintptr_t)7);
+    const float Px = px[s], blo = lo[s], bhi = hi[s];
+    /* rangedX_index: the PassThrough band, every point of it */
+    if (blo <= bhi && m->n_valid > 0) {
+        const int b0 = slab_of(m, blo), b1 = slab_of(m, bhi);
+        const int i0 = slab_start[b0], i1 = slab_start[b1 + 1];
+        for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            const float4 p = sorted4[i];
+            if (!(p.x < blo || p.x > bhi)) {
+                const int slot = atomicAdd(&s_n, 1);
+                if ((size_t)slot < cap) a4[slot] = p;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if ((size_t)n > cap) { if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; } return; }
+    int NB = next_pow2(max(n, 64)) >> 1;
+    {   /* ascending cloud index, as PassThrough returns the indices */
+        const double scale = (double)NB / (double)max(ncloud, 1);
+        auto gen = [&](int i) { return ((u64)(u32)idx_of(a4[i]) << 32) | (u32)i; };
+        auto bucket = [&](u64 k) { int q = (int)((double)(u32)(k >> 32) * scale); return q < 0 ? 0 : (q >= NB ? NB - 1 : q); };
+        auto less = [&](u64 a, u64 b) { return a < b; };
+        block_bucket_sort(keys, n, hist, NB, s_scr, gen, bucket, less);
+    }
+    /* side split, order preserving (Path_Generation.cpp:115-127) */
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        int fl = 0, fr = 0, pos = 0;
+        if (j < n) {
+            pos = (int)(u32)keys[j];
+            const float4 p = a4[pos];
+            const float distance2plane = (p.x - Px) * 1.f + (p.y - 0.f) * 0.f + (p.z - 0.f) * 0.f;
+            fl = distance2plane > 0;
+            fr = distance2plane < 0;
+        }
+        int tl, tr;
+        const int pl = block_exscan(fl, s_scr, &tl);
+        const int pr = block_exscan(fr, s_scr, &tr);
+        const int ol = s_nl, orr = s_nr;
+        if (fl) el[ol + pl] = pos;
+        if (fr) er[orr + pr] = pos;
+        __syncthreads();
+        if (threadIdx.x == 0) { s_nl = ol + tl; s_nr = orr + tr; }
+        __syncthreads();
+    }
+    const int nEl = s_nl, nEr = s_nr;
+    if (nEl == 0 || nEr == 0) { /* empty map -> fewer than 3 knots; empty right side: the reference crashes */
+        if (threadIdx.x == 0) { set_err(m, DERR_SLICE, s); node_start[s] = 0; node_cnt[s] = 0; }
+        return;
+    }
+    int ncand = 0;
+    float *cy = (float *)rstar, *cz = (float *)lstar; /* reused once the pairs are read */
+    if (pairing == 0) {
+        for (int i = threadIdx.x; i < nEl; i += blockDim.x) {
+            const float4 q = a4[el[i]];
+            float best = INFINITY; int br = 0;
+            for (int j = 0; j < nEr; ++j) {
+                const float4 c = a4[er[j]];
+                const float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
+                if (d < best) { best = d; br = j; }
+            }
+            const float4 R = a4[er[br]];
+            best = INFINITY; int bl = 0;
+            for (int k = 0; k < nEl; ++k) {
+                const float4 c = a4[el[k]];
+                const float d = dist2_flann(R.x, R.y, R.z, c.x, c.y, c.z);
+                if (d < best) { best = d; bl = k; }
+            }
+            pairR[i] = br; pairL[i] = bl;
+        }
+        ncand = nEl;
+    } else {
+        for (int i = threadIdx.x; i < nEl; i += blockDim.x) {
+            const float4 q = a4[el[i]];
+            float best = INFINITY; int bj = 0;
+            for (int j = 0; j < nEr; ++j) {
+                const float4 c = a4[er[j]];
+                const float d = norm_eigen3(q.x - c.x, q.y - c.y, q.z - c.z);
+                if (d <= best) { best = d; bj = j; } /* compare[norm] = j : last j wins a tie */
+            }
+            rstar[i] = bj;
+        }
+        for (int j = threadIdx.x; j < nEr; j += blockDim.x) {
+            const float4 q = a4[er[j]];
+            float best = INFINITY; int bk = 0;
+            for (int k = 0; k < nEl; ++k) {
+                const float4 c = a4[el[k]];
+                const float d = norm_eigen3(q.x - c.x, q.y - c.y, q.z - c.z);
+                if (d <= best) { best = d; bk = k; }
+            }
+            lstar[j] = bk;
+        }
+        const int wl = (nEl + 63) >> 6, wr = (nEr + 63) >> 6;
+        for (int i = threadIdx.x; i < wl + wr; i += blockDim.x) flags[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) { /* the greedy flag walk (Path_Generation.cpp:137-179) */
+            int nl = 0, nr = 0;
+            for (int i = 0; i < nEl; ++i) {
+                if ((flags[i >> 6] >> (i & 63)) & 1) continue;
+                const int j = rstar[i];
+                if ((flags[wl + (j >> 6)] >> (j & 63)) & 1) continue;
+                pairR[nr++] = j;
+                flags[wl + (j >> 6)] |= 1ull << (j & 63);
+                const int k = lstar[j];
+                if (!((flags[k >> 6] >> (k & 63)) & 1)) {
+                    pairL[nl++] = k;
+                    flags[k >> 6] |= 1ull << (k & 63);
+                }
+            }
+            s_np = nl; /* the reference loops i < left_pair.size() (Path_Generation.cpp:189) */
+        }
+        __syncthreads();
+        ncand = s_np;
+    }
+    __syncthreads();
+    /* lerp onto the plane; the pairs are read before rstar / lstar become cy / cz */
+    for (int base = 0; base < ncand; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        float y = 0.f, z = 0.f;
+        if (i < ncand) {
+            const float4 R = a4[er[pairR[i]]];
+            const float4 Lp = a4[el[pairL[i]]];
+            const float t = (Px - R.x) / (Lp.x - R.x);
+            y = R.y + t * (Lp.y - R.y);
+            z = R.z + t * (Lp.z - R.z);
+            if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
+        }
+        __syncthreads(); /* (pairing 0 wrote pairR / pairL only; rstar / lstar are free either way once the walk is over) */
+        if (i < ncand) { cy[i] = y; cz[i] = z; }
+    }
+    __syncthreads();
+    {   /* std::map: ascending y, the last writer (highest i) of equal keys is the one kept */
+        NB = next_pow2(max(ncand, 64)) >> 1;
+        const float y0 = m->mn[1], yr = m->mx[1] - y0;
+        const float scale = yr > 0.f ? (float)NB / yr : 0.f;
+        auto gen = [&](int i) { return ((u64)f2ord(cy[i]) << 32) | (u32)i; };
+        auto bucket = [&](u64 k) { int q = (int)((ord2f((u32)(k >> 32)) - y0) * scale); return q < 0 ? 0 : (q >= NB ? NB - 1 : q); };
+        auto less = [&](u64 a, u64 b) { return a < b; };
+        block_bucket_sort(keys, ncand, hist, NB, s_scr, gen, bucket, less);
+    }
+    int mcount = 0;
+    for (int j = threadIdx.x; j < ncand; j += blockDim.x) mcount += (j == ncand - 1) || ((u32)(keys[j + 1] >> 32) != (u32)(keys[j] >> 32));
+    int tot;
+    block_exscan(mcount, s_scr, &tot);
+    if (threadIdx.x == 0) {
+        int base = atomicAdd(&m->node_cursor, tot);
+        if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
+        s_base = base; s_np = tot;
+        node_start[s] = base;
+        node_cnt[s] = tot;
+        if (tot < 3) set_err(m, DERR_SLICE, s);
+    }
+    __syncthreads();
+    const int nk = s_np;
+    if (nk == 0) return;
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) node_x[s_base + i] = Px;
+    for (int base = 0; base < ncand; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        int keep = 0;
+        u64 k = 0;
+        if (j < ncand) { k = keys[j]; keep = (j == ncand - 1) || ((u32)(keys[j + 1] >> 32) != (u32)(k >> 32)); }
+        int t2;
+        const int pre = block_exscan(keep, s_scr, &t2);
+        const int o = s_m;
+        if (keep) { node_y[s_base + o + pre] = ord2f((u32)(k >> 32)); node_z[s_base + o + pre] = cz[(u32)k]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_m = o + t2;
+        __syncthreads();
+    }
 }
 
 /* ------------------------------------------------------------------ */

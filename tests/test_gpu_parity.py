@@ -819,6 +819,26 @@ def test_running_float_sums_are_exact_at_a_million_points(engine_mod):
     assert cov.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("pairing,walk", [(1, 3), (1, 4), (0, 1)])
+def test_dense_bands_beyond_lds_take_the_arena_pass(engine_mod, oracle_mod, pairing, walk):
+    """A cloud so dense that every 4 mm band holds ~6500 points (more than the 4096 an LDS-resident slice kernel takes):
+    the slices are parked by the first pass and planned from the arena -- for the brute-force pairing of v1
+    (k_slice_brute_arena) as for the kd pairing -- with the same knots and waypoints, also when only GenPath runs."""
+    rng = np.random.default_rng(12)
+    x = rng.uniform(0, 70.0, 114000); y = rng.uniform(-78, 78, 114000)
+    z = 1500 + 6 * np.sin(x / 30) * np.cos(y / 40)
+    pts = (np.stack([x, y, z], axis=1) / 1000).astype(np.float32)
+    o = oracle_mod.Oracle(pts, tool_radius=6.0, pairing=pairing, walk=walk)
+    e = engine_mod.Engine(0, tool_radius=6.0, pairing=pairing, walk=walk)
+    e.set_cloud(pts)
+    So = o.gen_path(); S = e.gen_path()
+    assert S == So >= 3
+    assert max(len(e.slice_indices(s)) for s in range(S)) > 4096
+    for s in range(S):
+        assert all(np.array_equal(a, b) for a, b in zip(e.nodes(s), o.nodes(s))), s
+    assert_full_parity(engine_mod, e, o)
+
+
 def test_distinct_handles_from_concurrent_host_threads(engine_mod):
     """thread-compatible -- distinct handles may be driven from different host threads at once
     (own stream, own graph capture in thread-local mode, no globals)."""

@@ -196,10 +196,6 @@ def one_case_hard(rng, i, only=None, verbose=False, big=None):
             # chains per launch here, one after the other in the oracle): when both chains fail, which slice is named
             # first is an artefact of that order
             return "both fail (slice %d here, %d in the oracle's chain order)" % (e.failed_slice(), -(So + 1)), desc
-        if pairing == 1 and ex.code == -5:
-            # DESIGN.md "Limits": the brute-force pairing (v1) works on an LDS-resident band of at most 4096 points and has no
-            # arena variant; a cloud whose whole width is one band (an alignment that put the thin axis first) exceeds it
-            return "both fail (documented limit: brute-force pairing on a band of more than 4096 points; oracle S=%d)" % So, desc
         return "GPU error %s (oracle S=%d)" % (ex, So), desc
     if So < 0:
         return "oracle fails at slice %d, GPU S=%d" % (-(So + 1), S), desc
