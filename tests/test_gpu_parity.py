@@ -771,6 +771,13 @@ def test_trans2center_matches_the_oracle(engine_mod, oracle_mod, t):
     if t in (7, 11):
         assert ext[2] < 5 < ext[1] < ext[0]
         assert_full_parity(engine_mod, e, o)
+        want = e.waypoints().tobytes()
+        for _ in range(3):                    # the captured graph carries the sensor-frame index of the aligned variant
+            e.run_async(); e.sync()
+            assert e.waypoints().tobytes() == want
+        n_o = o.remove_outlier(50, 1.0)[0]    # constructor order: align, then remove -- the sensor-frame copy follows the cloud
+        assert e.remove_outlier(50, 1.0)[0] == n_o
+        assert_full_parity(engine_mod, e, o)
     else:
         So = o.gen_path()
         try:
