@@ -71,8 +71,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("PPP_BENCH_FORCE_DIST") == "1"   # rehearsal: a one-rank RCCL group on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29571"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     if args.mode == "slices" and world > 1:
@@ -102,29 +105,35 @@ def main():
     # the batch is fixed, so is every rank's waypoint count: exchanged once; the engines write straight into the
     # gatherer's send buffer, so a step's exchange is one collective and no copy.  N > 1 uses TWO gatherers: the
     # RCCL gather of step k-1 runs (on the framework's stream) while the planner works on step k (on its own stream).
-    from polishpathplanning_amd.robot_path import RobotPathGatherer, run_pipelined_steps
-    pipelined = world > 1 or os.environ.get("PPP_BENCH_FORCE_PIPELINE") == "1"
-    gatherers = [RobotPathGatherer(sum(w_all), dist if world > 1 else None, dev) for _ in range(2 if pipelined else 1)]
+    from polishpathplanning_amd.robot_path import RobotPathGatherer, StreamOrder, run_pipelined_steps, run_streamed_steps
+    host_waits = os.environ.get("PPP_BENCH_HOST_WAITS") == "1"   # the earlier loop: one host wait per step (kept for comparison)
+    gatherers = [RobotPathGatherer(sum(w_all), dist if (world > 1 or force_dist) else None, dev, force_collective=force_dist) for _ in range(2)]
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
     w_step = int(sum(w_all))
+    # the planner's own stream, wrapped so that framework events can order it against the collective's stream
+    # (one GPU, no collective: the "gather" is the identity on a buffer nobody else reads, there is nothing to order)
+    from polishpathplanning_amd.robot_path import NoOrder
+    order = StreamOrder(torch, torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)) if gatherers[0].dist else NoOrder()
 
     def plan(k):
         # GenPath + getPath of every workpiece of this rank as ONE hipGraph launch (a branch per workpiece); every
         # branch ends by writing its WayPointsList to its place in the gather buffer
-        engine.run_batch_async(engines, gatherers[k % len(gatherers)].send.data_ptr(), offs, w_all)
+        engine.run_batch_async(engines, gatherers[k % 2].send.data_ptr(), offs, w_all)
 
     def run_steps(count):
-        """`count` full steps: every step's robot path is planned and gathered on rank 0 before this returns"""
-        blocks = None
-        if not pipelined:
-            for k in range(count):
-                plan(k)
-                engine.sync_batch(engines)          # one host wait per step
-                blocks = gatherers[0].gather()
-            return blocks
-        # step k on the planner's stream while step k-1 is gathered on the framework's stream
-        return run_pipelined_steps(count, plan, lambda: engine.sync_batch(engines), gatherers,
-                                   lambda: torch.cuda.current_stream().synchronize())
+        """`count` full steps: every step's robot path is planned and gathered on rank 0 before this returns.
+        Step k is planned on the planner's stream while step k-1 is gathered on the framework's stream; the two
+        alternate between two send/receive buffer pairs and are ordered by events, so the host never waits inside
+        the loop -- it synchronises both streams once, here, at the end (a failed step is reported by sync_batch)."""
+        if count <= 0:
+            return None
+        if host_waits:
+            return run_pipelined_steps(count, plan, lambda: engine.sync_batch(engines), gatherers,
+                                       lambda: torch.cuda.current_stream().synchronize())
+        blocks = run_streamed_steps(count, plan, gatherers, order)
+        engine.sync_batch(engines)
+        torch.cuda.current_stream().synchronize()
+        return blocks
 
     def fence():
         if world > 1:
@@ -237,7 +246,7 @@ def main():
             "path_l2_err": err,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -49,9 +49,10 @@ class RobotPathGatherer:
     `send` (ppp_run_batch_async / ppp_copy_waypoints_to_device), gather() is then ONE collective and no copy.
     counts are exchanged at construction (a fixed batch has fixed counts; set_local_count() re-exchanges)."""
 
-    def __init__(self, w_local, dist=None, device=None):
+    def __init__(self, w_local, dist=None, device=None, force_collective=False):
         import torch
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        # force_collective: run the collective even in a one-rank group (rehearsal of the exchange on a single GPU)
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)) else None
         self.device = device
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
@@ -104,6 +105,77 @@ def run_pipelined_steps(count, plan, wait_planned, gatherers, wait_gathered, on_
         if on_blocks:
             on_blocks(count - 1, blocks)
         wait_gathered()
+    return blocks
+
+
+class StreamOrder:
+    """Orders the planner's stream and the framework's (collective) stream with events; the host never waits for the
+    step it has just enqueued.  Buffer b = step % 2.  planner_stream: torch.cuda.ExternalStream around Engine.stream_ptr()."""
+
+    def __init__(self, torch, planner_stream):
+        self.torch = torch
+        self.ps = planner_stream
+        self.planned = [torch.cuda.Event(), torch.cuda.Event()]
+        self.gathered = [torch.cuda.Event(), torch.cuda.Event()]
+        self.used = [False, False]
+
+    def before_plan(self, b):
+        # The gather that last read send[b] (two steps ago) must be over before the planner overwrites it.  The HOST
+        # waits for that event -- it is two steps old, so the wait normally returns at once and merely bounds how far the
+        # host runs ahead -- instead of the planner's stream: a cross-queue wait in front of every graph launch costs
+        # the planner ~10 us per step, a host-side check of an old event costs it nothing.
+        if self.used[b]:
+            self.gathered[b].synchronize()
+
+    def after_plan(self, b):
+        self.planned[b].record(self.ps)
+
+    def before_gather(self, b):
+        self.torch.cuda.current_stream().wait_event(self.planned[b])
+
+    def after_gather(self, b):
+        self.gathered[b].record(self.torch.cuda.current_stream())
+        self.used[b] = True
+
+
+class NoOrder:
+    """Synchronous back ends (the gloo tests): every call has finished when it returns."""
+
+    def before_plan(self, b): pass
+    def after_plan(self, b): pass
+    def before_gather(self, b): pass
+    def after_gather(self, b): pass
+
+
+def run_streamed_steps(count, plan, gatherers, order, on_blocks=None):
+    """`count` plan+gather steps with no host wait inside: step k's planning is enqueued, then step k-1's gather, and
+    the two streams are ordered by `order` (StreamOrder: events).  The host runs ahead of the device; the caller
+    synchronises once at the end (Engine.sync_batch + the framework stream).  Every step is planned and gathered.
+
+    plan(k)           enqueues step k's planning into gatherers[k % 2].send
+    on_blocks(k, b)   optional: enqueue the consumer of step k's gathered blocks (None off rank 0) on the framework stream
+    Returns the last step's blocks."""
+    assert len(gatherers) == 2
+    blocks = None
+
+    def gather(k):
+        b = k % 2
+        order.before_gather(b)
+        out = gatherers[b].gather()
+        if on_blocks:
+            on_blocks(k, out)
+        order.after_gather(b)
+        return out
+
+    for k in range(count):
+        b = k % 2
+        order.before_plan(b)
+        plan(k)
+        order.after_plan(b)
+        if k > 0:
+            blocks = gather(k - 1)
+    if count > 0:
+        blocks = gather(count - 1)
     return blocks
 
 

@@ -166,9 +166,32 @@ def _pipeline_worker(rank, world, port, q):
         else:
             assert blocks is None
 
-    for count in (0, 1, 2, 5):
+    from polishpathplanning_amd.robot_path import NoOrder, run_streamed_steps
+
+    class Recorder(NoOrder):                             # the order in which bench.py's event hooks are called
+        def __init__(self): self.calls = []
+        def before_plan(self, b): self.calls.append(("bp", b))
+        def after_plan(self, b): self.calls.append(("ap", b))
+        def before_gather(self, b): self.calls.append(("bg", b))
+        def after_gather(self, b): self.calls.append(("ag", b))
+
+    for count, streamed in [(0, False), (1, False), (2, False), (5, False), (0, True), (1, True), (2, True), (5, True)]:
         del seen[:]
-        last = run_pipelined_steps(count, plan, lambda: None, gatherers, lambda: None, on_blocks)
+        if streamed:
+            rec = Recorder()
+            last = run_streamed_steps(count, plan, gatherers, rec, on_blocks)
+            # every buffer: planned before it is gathered, gathered before it is planned again; the gather of step k-1
+            # is enqueued behind the planning of step k
+            want_calls = []
+            for k in range(count):
+                want_calls += [("bp", k % 2), ("ap", k % 2)]
+                if k > 0:
+                    want_calls += [("bg", (k - 1) % 2), ("ag", (k - 1) % 2)]
+            if count:
+                want_calls += [("bg", (count - 1) % 2), ("ag", (count - 1) % 2)]
+            assert rec.calls == want_calls
+        else:
+            last = run_pipelined_steps(count, plan, lambda: None, gatherers, lambda: None, on_blocks)
         if rank == 0:
             assert [k for k, _ in seen] == list(range(count))
             for k, blocks in seen:
@@ -186,8 +209,9 @@ def _pipeline_worker(rank, world, port, q):
 
 
 def test_pipelined_steps_world2_gloo():
-    """bench.py's N > 1 loop: the gather of step k-1 overlaps the planning of step k over two buffer pairs; every
-    step's blocks arrive intact and in order, for 0, 1, 2 and 5 steps."""
+    """bench.py's N > 1 loops (event-ordered run_streamed_steps, and the earlier run_pipelined_steps with host waits): the
+    gather of step k-1 overlaps the planning of step k over two buffer pairs; every step's blocks arrive intact and in
+    order, for 0, 1, 2 and 5 steps; the ordering hooks are called in the order the buffers need."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
