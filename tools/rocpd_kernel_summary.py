@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Per-kernel call count / mean / max duration from a rocprofv3 rocpd database (`rocprofv3 --kernel-trace -o x` writes
+x_results.db when no --output-format is given).  usage: rocpd_kernel_summary.py x_results.db"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
