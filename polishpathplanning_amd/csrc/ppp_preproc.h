@@ -412,6 +412,9 @@ __global__ void __launch_bounds__(256) k_mls(DevMeta *m, const float4 *__restric
 #pragma unroll
             for (int k = 0; k < NC; ++k) cv[k] = 0.0;
             for_each_neighbour([&](const float4 &c) {
+/* the one place of the engine where products may fuse into the additions: 65 f64 accumulations per neighbour, whose
+   grouping already differs from Eigen's blocked products -- the result is compared to the last float bit, not the last double bit */
+#pragma clang fp contract(fast)
                 const double dm[3] = {(double)c.x - mean[0], (double)c.y - mean[1], (double)c.z - mean[2]};
                 const double w = exp(-(dm[0] * dm[0] + dm[1] * dm[1] + dm[2] * dm[2]) / sqr_gauss);
                 const double u_coord = dm[0] * ua[0] + dm[1] * ua[1] + dm[2] * ua[2];
