@@ -6,6 +6,9 @@ over one synthetic workpiece cloud that is already resident in HBM, ending with 
 WayPointsList assembled on rank 0.  N = 1 runs configs[1] (1M-point wavy plate, 256 slices).
 N > 1 shards a batch of workpieces one per GPU (weak scaling, no data-path collective) and
 gathers the per-GPU robot paths to rank 0 over RCCL inside the timed region.
+The K steps are enqueued back to back (each into one of two alternating output / gather buffers, ordered against the
+collective's stream by events); the host synchronises once, at the end of the timed region, which is bracketed by
+barrier + device synchronisation on both sides.
 --mode slices (SURVEY.md 8e case ii, meant for cfg5_10m_s1024) instead shards the SLICES of one cloud:
 GPU g plans slices [g*S/N, (g+1)*S/N), the pre-smoothing blocks are gathered to rank 0, which runs
 postion_smooth / reduceRPY / flange offset once over the whole list (strong scaling).
