@@ -14,9 +14,14 @@
  *     flann::L2_Simple<float>), NormalEstimation (radius search,
  *     computeMeanAndCovarianceMatrix shifted by the first neighbour,
  *     pcl::eigen33, flipNormalTowardsViewpoint), getMinMax3D.
+ *     Dynamic adjustment: PrincipalCurvaturesEstimation, nearestKSearch order.
+ *     Preprocessing: StatisticalOutlierRemoval, VoxelGrid, MovingLeastSquares
+ *     (MLSResult::computeMLSSurface + SIMPLE projection), compute3DCentroid /
+ *     computeCovarianceMatrix (float running sums), transformPointCloud (SSE2 order).
  *   - GSL >= 2.0 interpolation/steffen.c (gsl_interp_steffen).
  *   - Eigen 3.3/3.4: Matrix3f::eulerAngles(2,1,0), AngleAxisf products
- *     (quaternion route), Matrix4f products.
+ *     (quaternion route), Matrix4f products; for trans2center EigenSolver<Matrix3f>
+ *     (RealSchur, eigenvectors unsorted) and the generic 4 x 4 inverse; LLT, unitOrthogonal for MLS.
  * Build with -ffp-contract=off: every float expression below is evaluated
  * with one rounding per operation, in the order written.
  *
