@@ -108,7 +108,7 @@ def main():
     # the batch is fixed, so is every rank's waypoint count: exchanged once; the engines write straight into the
     # gatherer's send buffer, so a step's exchange is one collective and no copy.  N > 1 uses TWO gatherers: the
     # RCCL gather of step k-1 runs (on the framework's stream) while the planner works on step k (on its own stream).
-    from polishpathplanning_amd.robot_path import RobotPathGatherer, StreamOrder, run_pipelined_steps, run_streamed_steps
+    from polishpathplanning_amd.robot_path import RobotPathGatherer, StreamOrder, run_chained_steps, run_pipelined_steps, run_streamed_steps
     host_waits = os.environ.get("PPP_BENCH_HOST_WAITS") == "1"   # the earlier loop: one host wait per step (kept for comparison)
     gatherers = [RobotPathGatherer(sum(w_all), dist if (world > 1 or force_dist) else None, dev, force_collective=force_dist) for _ in range(2)]
     offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
@@ -116,7 +116,8 @@ def main():
     # the planner's own stream, wrapped so that framework events can order it against the collective's stream
     # (one GPU, no collective: the "gather" is the identity on a buffer nobody else reads, there is nothing to order)
     from polishpathplanning_amd.robot_path import NoOrder
-    order = StreamOrder(torch, torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)) if gatherers[0].dist else NoOrder()
+    planner_stream = torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)
+    order = StreamOrder(torch, planner_stream) if gatherers[0].dist else NoOrder()
 
     def plan(k):
         # GenPath + getPath of every workpiece of this rank as ONE hipGraph launch (a branch per workpiece); every
@@ -125,15 +126,19 @@ def main():
 
     def run_steps(count):
         """`count` full steps: every step's robot path is planned and gathered on rank 0 before this returns.
-        Step k is planned on the planner's stream while step k-1 is gathered on the framework's stream; the two
-        alternate between two send/receive buffer pairs and are ordered by events, so the host never waits inside
-        the loop -- it synchronises both streams once, here, at the end (a failed step is reported by sync_batch)."""
+        Steps alternate between two send/receive buffer pairs.  Step k's collective is enqueued behind step k's
+        planning in the planner's own stream order, asynchronously, and is waited for (by the stream, not the host) two
+        steps later, before its buffers are planned into again -- so it overlaps the planning of step k+1 and the host
+        never waits inside the loop: it synchronises once, here, at the end (a failed step is reported by sync_batch)."""
         if count <= 0:
             return None
         if host_waits:
             return run_pipelined_steps(count, plan, lambda: engine.sync_batch(engines), gatherers,
                                        lambda: torch.cuda.current_stream().synchronize())
-        blocks = run_streamed_steps(count, plan, gatherers, order)
+        if os.environ.get("PPP_BENCH_EVENT_ORDER") == "1":          # the collective on the framework's stream, events in between
+            blocks = run_streamed_steps(count, plan, gatherers, order)
+        else:
+            blocks = run_chained_steps(count, plan, gatherers, planner_stream if gatherers[0].dist else None)
         engine.sync_batch(engines)
         torch.cuda.current_stream().synchronize()
         return blocks

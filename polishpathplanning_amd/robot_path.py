@@ -70,11 +70,34 @@ class RobotPathGatherer:
             self.recv = torch.empty((self.world * wmax, 6), dtype=torch.float32, device=self.device) if self.dist else None
         self.wmax = wmax
 
-    def gather(self):
-        """rank 0: list of per-rank [W_r, 6] views in rank order; other ranks: None"""
+    def gather_async(self, stream=None):
+        """Enqueue the collective behind `stream`'s work without making that stream wait for it; returns the work handle
+        (None without a process group).  blocks() is valid once the handle's wait() has been enqueued / has returned."""
+        if not self.dist:
+            return None
+        if stream is not None:
+            with self.torch.cuda.stream(stream):
+                return self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+        return self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+
+    def blocks(self):
+        """rank 0: list of per-rank [W_r, 6] views of the receive buffer in rank order; other ranks: None"""
         if not self.dist:
             return [self.send[: self.w_local]]
-        self.dist.all_gather_into_tensor(self.recv, self.send)
+        if self.rank != 0:
+            return None
+        return [self.recv[r * self.wmax: r * self.wmax + self.counts[r]] for r in range(self.world)]
+
+    def gather(self, stream=None):
+        """rank 0: list of per-rank [W_r, 6] views in rank order; other ranks: None.
+        stream: enqueue the collective behind this stream's work (default: the framework's current stream)"""
+        if not self.dist:
+            return [self.send[: self.w_local]]
+        if stream is not None:
+            with self.torch.cuda.stream(stream):
+                self.dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
         if self.rank != 0:
             return None
         return [self.recv[r * self.wmax: r * self.wmax + self.counts[r]] for r in range(self.world)]
@@ -176,6 +199,52 @@ def run_streamed_steps(count, plan, gatherers, order, on_blocks=None):
             blocks = gather(k - 1)
     if count > 0:
         blocks = gather(count - 1)
+    return blocks
+
+
+def run_chained_steps(count, plan, gatherers, planner_stream=None, on_blocks=None):
+    """`count` plan+gather steps on ONE stream order: step k's collective is enqueued behind step k's planning in the
+    planner's own stream (asynchronously: the planner does not wait for it), and the planner waits for it only two steps
+    later, just before it plans into the same buffer pair again -- by then it has long finished.  No second framework
+    stream and no host wait inside the loop; the collective of step k still overlaps the planning of step k+1.
+    (Measured on one GPU with a one-rank RCCL group, cfg 2: 0.166 ms per step, against 0.177 ms with the collective on the
+    framework's default stream and events in between -- a third active hardware queue slows every dispatch -- and 0.156 ms
+    with the planner waiting for each collective at once, which is the better choice only while the collective is as
+    short as a one-rank copy.  Without any exchange a step takes 0.144 ms.)
+
+    plan(k)           enqueues step k's planning into gatherers[k % 2].send on planner_stream
+    planner_stream    torch.cuda.ExternalStream around Engine.stream_ptr(); None for synchronous back ends (gloo tests)
+    on_blocks(k, b)   optional: called with step k's blocks once its collective has been waited for (None off rank 0)
+    The caller synchronises the planner stream once at the end.  Returns the last step's blocks."""
+    import contextlib
+    assert len(gatherers) == 2
+    torch = gatherers[0].torch
+    ctx = (lambda: torch.cuda.stream(planner_stream)) if planner_stream is not None else contextlib.nullcontext
+    works = [None, None]
+    pending = [None, None]      # step number whose collective is in flight on buffer b
+    blocks = None
+
+    def finish(b):
+        nonlocal blocks
+        if pending[b] is None:
+            return
+        if works[b] is not None:
+            with ctx():
+                works[b].wait()              # a stream wait (the host goes on), or a host wait for synchronous back ends
+        blocks = gatherers[b].blocks()
+        if on_blocks:
+            on_blocks(pending[b], blocks)
+        works[b] = None; pending[b] = None
+
+    for k in range(count):
+        b = k % 2
+        finish(b)
+        plan(k)
+        works[b] = gatherers[b].gather_async(planner_stream)
+        pending[b] = k
+    for k in (count - 2, count - 1):         # the last two steps, in order
+        if k >= 0:
+            finish(k % 2)
     return blocks
 
 

@@ -175,9 +175,13 @@ def _pipeline_worker(rank, world, port, q):
         def before_gather(self, b): self.calls.append(("bg", b))
         def after_gather(self, b): self.calls.append(("ag", b))
 
-    for count, streamed in [(0, False), (1, False), (2, False), (5, False), (0, True), (1, True), (2, True), (5, True)]:
+    from polishpathplanning_amd.robot_path import run_chained_steps
+    for count, streamed in [(0, False), (1, False), (2, False), (5, False), (0, True), (1, True), (2, True), (5, True),
+                            (0, "chained"), (1, "chained"), (2, "chained"), (3, "chained"), (6, "chained")]:
         del seen[:]
-        if streamed:
+        if streamed == "chained":          # bench.py's default loop: asynchronous collectives, waited for two steps later
+            last = run_chained_steps(count, plan, gatherers, None, on_blocks)
+        elif streamed:
             rec = Recorder()
             last = run_streamed_steps(count, plan, gatherers, rec, on_blocks)
             # every buffer: planned before it is gathered, gathered before it is planned again; the gather of step k-1
