@@ -1974,6 +1974,7 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 /* LDS of a tile; WP (wave partials) keeps one |delta| sum per wave and sweep instead of one per thread */
 #define SM_LDS_BYTES_OF(WP) (3 * SM_M * (8 + 4 + 4 + 4) + SM_K * ((WP) ? SM_T / 64 : SM_T) * 8)
 #define SM_LDS_BYTES SM_LDS_BYTES_OF(0)
+static_assert(SM_LDS_BYTES_OF(0) + 8 * (SM_MAXS + 1) + 1024 <= 160 * 1024, "k_smooth_batch: tile + snapshots exceed the 160 KiB of LDS a gfx950 workgroup can own");
 
 __host__ __device__ inline int smooth_tiles(int W) { return W > 2 ? (W - 2 + SM_OWN - 1) / SM_OWN : 1; }
 /* snapshot set q (0/1), level k (1..SM_K), coordinate j: float[W_cap] */
