@@ -525,11 +525,11 @@ __global__ void __launch_bounds__(256) k_flag_compact(const float4 *__restrict__
 /* the rounding of those running sums moves the centroid by hundredths of a millimetre and tilts the axes by 1e-5, and  */
 /* everything downstream (band membership, pairing) is decided on the aligned coordinates -- so the sums are reproduced */
 /* bit for bit.  A running float sum is sequential, but while it stays inside one binade [2^e, 2^(e+1)) every addition  */
-/* is  S <- S + round(x / ulp)  on the integer mantissa S, ties resolved by the parity of the result.  So: one wave per  */
-/* sum, 512 values per step; each value becomes a pair (increment if S is even, increment if S is odd), the pairs are   */
-/* composed by a wave scan, every prefix is checked to stay inside the binade, and the first value that leaves it is    */
-/* added with a real float addition before the scan resumes behind it.  Non-finite points contribute +0 (PCL skips      */
-/* them).                                                                                                               */
+/* is  S <- S + round(x / ulp)  on the integer mantissa S, ties resolved by the parity of the result.  So: one workgroup  */
+/* per sum, 8192 values per step; each value becomes a pair (increment if S is even, increment if S is odd), the pairs  */
+/* are composed by scans, every prefix is checked to stay inside the binade, and the first value that leaves it is       */
+/* added with a real float addition before the scan resumes behind it (k_seq_sum).  Non-finite points contribute +0      */
+/* (PCL skips them).                                                                                                    */
 /* ------------------------------------------------------------------------------------------------------------------ */
 #define SEQ_E 8
 #define SEQ_CHUNK (64 * SEQ_E)
@@ -561,13 +561,6 @@ __global__ void __launch_bounds__(256) k_seq_prep_cov(const float *__restrict__ 
     V[5 * stride + i] = fin ? z * x : 0.f;
 }
 
-__device__ inline float seq_pick(const float (&x)[SEQ_E], int k)
-{
-    float v = x[0];
-#pragma unroll
-    for (int j = 1; j < SEQ_E; ++j) v = (k == j) ? x[j] : v;
-    return v;
-}
 /* out[b] = the float obtained by adding vals[b * stride + 0 .. n-1] to 0.f one after the other.
    One workgroup of 16 waves per sum, a tile of 16 x 512 values per step: every wave composes its 512 values (wave scan),
    the 16 chunk totals are composed in order, every lane replays its 8 values from the now known mantissa and checks the
