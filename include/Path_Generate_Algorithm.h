@@ -20,12 +20,17 @@
 #include <vector>
 #include "Spline.h"
 
+#ifndef HANDEYEx /* (include/contour_alg.h brings its own calibration and trim) */
 #define HANDEYEx -0.764091
 #define HANDEYEy 0.025886
 #define HANDEYEz 0.663790
 #define HANDEYErx -3.1270175
 #define HANDEYEry -0.040124
 #define HANDEYErz -1.6063578
+#endif
+#ifndef PPP_GETPATH_TRIM
+#define PPP_GETPATH_TRIM 10 /* path_translation_alg.cpp:158-159: dy = miny + 10 ... bigy - 10 */
+#endif
 
 /* Base class: equal spacing path + robot path (path_slicing_alg.cpp, path_translation_alg.cpp) */
 class SectPath {
@@ -84,7 +89,7 @@ protected:
     void init_common()
     {
         ppp_params &p = planner.config().params;
-        p.pairing = PPP_PAIR_KD; p.trim = 10; p.drop_ends = 1; p.smooth = 1;
+        p.pairing = PPP_PAIR_KD; p.trim = PPP_GETPATH_TRIM; p.drop_ends = 1; p.smooth = 1;
         const float he[6] = {(float)HANDEYEx, (float)HANDEYEy, (float)HANDEYEz, (float)HANDEYErx, (float)HANDEYEry, (float)HANDEYErz};
         for (int i = 0; i < 6; ++i) p.handeye[i] = he[i];
     }

@@ -342,6 +342,34 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
         assert r.returncode == 0 and "number of paths" in r.stdout
 
 
+def test_contour_cli_trims_five_and_uses_its_own_hand_eye(engine_mod, oracle_mod, tmp_path):
+    """include/contour_alg.h driven like src/contour.cpp (+ the plan): SectPath with getPath's +-5 trim
+    (contour_alg.cpp:496-497) and the hand-eye calibration of contour_alg.h:37-42."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "contour"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("small_40k")
+    pcd = str(tmp_path / "workpiece.pcd")
+    engine_mod.save_pcd(pcd, pts, binary=True)
+    out = str(tmp_path / "WayPoints.txt")
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n" % out)
+    env = dict(os.environ, PPP_CONFIG=str(conf), PPP_CONTOUR_PLAN="1")
+    r = subprocess.run([os.path.join(root, "examples", "contour"), pcd], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
+    he = [-0.858533, 0.075348, 0.672533, -3.138775, -0.0405313, -1.5707969]
+    o = oracle_mod.Oracle(pts, tool_radius=6.0, walk=0, trim=5.0, handeye=he)
+    o.gen_path(); o.get_path()
+    want = o.waypoints()
+    assert got.shape == want.shape
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 + 5e-6 * np.abs(want[:, :3]).max()
+    o10 = oracle_mod.Oracle(pts, tool_radius=6.0, walk=0)
+    o10.gen_path(); o10.get_path()
+    assert len(want) > len(o10.waypoints())          # the shorter trim samples more of every path
+
+
 @pytest.mark.parametrize("walk", [0, 1, 2, 3, 4])
 def test_slice_walks_on_device_match_the_reference_loops(engine_mod, oracle_mod, walk):
     """a3: the device walk (closed forms / predicated float accumulation) against the literal loops."""
