@@ -108,7 +108,7 @@ struct ppp_handle_s {
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
     bool meta_in_flight = false;
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
-    float *out2 = nullptr;          /* batched form: k_finish also writes the list here (at most out2_cap rows) */
+    float *out2 = nullptr;          /* batched form: the emitting launch also writes the list here (at most out2_cap rows) */
     int out2_cap = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -1150,19 +1150,18 @@ int ppp_gen_path_async(ppp_handle h)
 /* getPath's second half: postion_smooth, reduceRPY, TransFlangeposition (path_translation_alg.cpp:212-214) */
 int enqueue_finish(ppp_handle h, const DevParams &D)
 {
-    const int gw = std::max(1, (h->W_cap + FIN_T - 1) / FIN_T);
-    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays and emits */
+    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays, emits, and finishes the list
+       (reduceRPY, flange offset, the copy into the caller's buffer of the batched form) */
     const int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
     const bool wave_partials = h->sm_tiles > h->num_cus; /* more tiles than CUs: the small-LDS variant runs several per CU */
     for (int b = 0; b <= nb; ++b) {
         if (wave_partials)
             LAUNCH(h, "k_smooth_batch", k_smooth_batch<true>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(1), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p, h->tail.p, h->out2, h->out2_cap);
         else
             LAUNCH(h, "k_smooth_batch", k_smooth_batch<false>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(0), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p);
+                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p, h->tail.p, h->out2, h->out2_cap);
     }
-    LAUNCH(h, "k_finish", k_finish, gw, FIN_T, 0, h->meta.p, D, h->tail.p, h->wp_smooth.p, h->wp_out.p, h->out2, h->out2_cap);
     return enqueue_meta_copy(h);
 }
 
@@ -1320,7 +1319,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
             rc = ppp_gen_path_async(h);
             h->chain_calls = false;
             if (dst_dev) { h->out2 = dst_dev + 6 * offset_rows[i]; h->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
-            if (rc == PPP_OK) rc = ppp_get_path_async(h); /* k_finish also writes the list to its place in dst_dev */
+            if (rc == PPP_OK) rc = ppp_get_path_async(h); /* the emitting launch also writes the list to its place in dst_dev */
             h->out2 = nullptr; h->out2_cap = 0;
             if (rc != PPP_OK) lead->err = "batch member " + std::to_string(i) + ": " + h->err;
             if (i && e == hipSuccess && rc == PPP_OK) {

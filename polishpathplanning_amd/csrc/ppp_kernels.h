@@ -24,6 +24,7 @@ struct DevMeta {
     int sweeps, any_short, rpy_oob;
     int node_cursor;
     int smooth_done;
+    int emit_ticket;         /* tiles that have emitted (only counted when the list is finished in order, App. B.6) */
     int big_slabs, big_slices;   /* work lists of the LDS-overflow fallback kernels */
     unsigned long long arena_cursor; /* bump allocator of the global arena those kernels use */
     int B;
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, cons
         }
         r.n_valid = c;
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
-        r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1;
+        r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1; r.emit_ticket = 0;
         r.big_slabs = 0; r.big_slices = 0; r.arena_cursor = 0;
         int S = 0;
         s_nfront = -1;
@@ -1316,7 +1317,7 @@ __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, i
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->rpy_oob = 0; m->smooth_done = -1;
+        m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->rpy_oob = 0; m->smooth_done = -1; m->emit_ticket = 0;
         m->any_short = s_short;
         m->nkept = nk;
         m->big_slabs = 0; m->big_slices = 0; /* the index of this handle plays no part in what follows */
@@ -1930,6 +1931,106 @@ __global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, co
 }
 
 /* ------------------------------------------------------------------ */
+/* a14: reduceRPY (path_translation_alg.cpp:37-86)                      */
+/* ------------------------------------------------------------------ */
+__device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int res, DevMeta *m)
+{
+    int lastId;
+    do {
+        double dr[3];
+        lastId = preId + res;
+        if (lastId >= n) { m->rpy_oob = 1; break; } /* the reference reads past the list here (App. B.6) */
+        for (int D = 3; D < 6; D++) {
+            float a = W6[6 * (size_t)lastId + D], b = W6[6 * (size_t)preId + D];
+            if (a * b >= 0) {
+                dr[D - 3] = (double)((a - b) / res);
+            } else {
+                double no1, no2;
+                if (a < 0) { no2 = b; no1 = 2 * M_PI + a; }
+                else { no2 = 2 * M_PI + b; no1 = a; }
+                dr[D - 3] = (double)fabsf(a - b) < fabs(no1 - no2) ? (double)(a - b) : (no1 - no2);
+                dr[D - 3] /= res;
+            }
+        }
+        for (int wi = 1; wi < res; wi++)
+            for (int D = 3; D < 6; ++D)
+                W6[6 * (size_t)(preId + wi) + D] = (float)(dr[D - 3] + W6[6 * (size_t)(preId + wi - 1) + D]);
+        preId = lastId;
+    } while ((preId + res) <= tailId);
+    if (preId != tailId)
+        for (int i = preId + 1; i <= tailId; i++)
+            for (int D = 3; D < 6; ++D) W6[6 * (size_t)i + D] = W6[6 * (size_t)preId + D];
+}
+
+/* reduceRPY (path_translation_alg.cpp:37-86) for ONE waypoint -- the key waypoints (every RPYres-th of a slice) are
+   never modified, so every interval is independent --, then the -180..180 limit (:81-85) and TransFlangeposition
+   (:89-112).  p: the waypoint after smoothing (xyz smoothed, rpy as computed); src: any list holding the computed rpy
+   of every waypoint (reduceRPY reads the key waypoints' angles).  Valid unless a slice is shorter than RPYres + 1. */
+__device__ inline void finish_one_waypoint(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
+                                           const float *__restrict__ src, int w, float p[6])
+{
+    const bool reduce = P.rpy_resolution > 2;
+    if (reduce) {
+        const int res = (int)P.rpy_resolution;
+        /* segment of w: first tail >= w */
+        int lo = 0, hi = m->nkept - 1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (tail[mid] < w) lo = mid + 1; else hi = mid; }
+        const int tl = tail[lo], p0 = lo == 0 ? 0 : tail[lo - 1] + 1;
+        const int nfull = (tl - p0) / res;       /* passes of the do-while */
+        const int lastkey = p0 + nfull * res;
+        const int r = w - p0;
+        if (w > lastkey) {
+            for (int D = 3; D < 6; ++D) p[D] = src[6 * (size_t)lastkey + D];
+        } else if (r % res != 0) {
+            const int pre = p0 + (r / res) * res, last = pre + res, wi = w - pre;
+            for (int D = 3; D < 6; D++) {
+                float a = src[6 * (size_t)last + D], bb = src[6 * (size_t)pre + D];
+                double dr;
+                if (a * bb >= 0) {
+                    dr = (double)((a - bb) / res);
+                } else {
+                    double no1, no2;
+                    if (a < 0) { no2 = bb; no1 = 2 * M_PI + a; }
+                    else { no2 = 2 * M_PI + bb; no1 = a; }
+                    dr = (double)fabsf(a - bb) < fabs(no1 - no2) ? (double)(a - bb) : (no1 - no2);
+                    dr /= res;
+                }
+                float v = bb;
+                for (int q = 1; q <= wi; ++q) v = (float)(dr + v); /* the reference accumulates in float */
+                p[D] = v;
+            }
+        }
+        for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
+    }
+    float R[3][3];
+    rot_zyx(p[3], p[4], p[5], R);
+    const float ee[3] = {0.f, 0.f, -P.ee_length};
+    float t[3];
+    for (int i = 0; i < 3; ++i) t[i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
+    p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+}
+
+/* The same three steps over the whole list in order, by one thread: only when a slice is shorter than RPYres + 1
+   waypoints do the reference's segments overlap (App. B.6).  out holds the smoothed list and becomes the final one. */
+__device__ inline void finish_list_in_order(DevMeta *m, const DevParams &P, const int *__restrict__ tail, float *out)
+{
+    const int W = m->W;
+    const int res = (int)P.rpy_resolution;
+    int preId = 0;
+    for (int id = 0; id < m->nkept; ++id) { rpy_segment(out, W, preId, tail[id], res, m); preId = tail[id] + 1; }
+    for (int q = 0; q < W; ++q) {
+        float p[6];
+        for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)q + d];
+        for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
+        float R[3][3];
+        rot_zyx(p[3], p[4], p[5], R);
+        const float ee[3] = {0.f, 0.f, -P.ee_length};
+        for (int i = 0; i < 3; ++i) out[6 * (size_t)q + i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
+        for (int D = 3; D < 6; ++D) out[6 * (size_t)q + D] = p[D];
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* a13: postion_smooth (path_translation_alg.cpp:114-141).              */
 /* One Gauss-Seidel sweep of the reference is the recurrence             */
 /*   y_i' = fl32( y_i + 0.65 (x_i - y_i) + 0.35 (y_{i+1} + y'_{i-1} - 2 y_i) )                   */
@@ -1990,7 +2091,8 @@ __host__ __device__ inline size_t smooth_snap_off(int q, int k, int j, int W_cap
 template <bool WP>
 __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, int b, int ntiles_cap, int W_cap,
                                                        const float *__restrict__ sx, float *snap, double *part, double *chist,
-                                                       const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out)
+                                                       const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out,
+                                                       const int *__restrict__ tail, float *dst2, int cap2)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     double (*s_c)[SM_M] = (double (*)[SM_M])s_raw;
@@ -2050,13 +2152,36 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
         if (s_kstar) { emit_level = s_kstar - SM_K * (b - 1); total_sweeps = s_kstar; }
     }
     if (emit_level >= 0) {
-        for (int j = 0; j < 3; ++j) {
-            const float *S = emit_level == 0 ? sx + (size_t)j * W : snap + smooth_snap_off((b - 1) & 1, emit_level, j, W_cap);
-            for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) {
-                float v = S[g];
-                float r = wp_pre[6 * (size_t)g + 3 + j];
-                wp_smooth[6 * (size_t)g + j] = v; wp_out[6 * (size_t)g + j] = v;
-                wp_smooth[6 * (size_t)g + 3 + j] = r; wp_out[6 * (size_t)g + 3 + j] = r;
+        /* The emitting launch also finishes the list (a14 reduceRPY, a15 flange offset) and, in the batched form, writes
+           it to its place in the caller's buffer: both are per-waypoint work on what this tile has in hand -- the
+           smoothed xyz and the computed rpy -- so the pass ends here, without a finishing launch. */
+        const float *S0 = emit_level == 0 ? sx : snap + smooth_snap_off((b - 1) & 1, emit_level, 0, W_cap);
+        const float *S1 = emit_level == 0 ? sx + (size_t)W : snap + smooth_snap_off((b - 1) & 1, emit_level, 1, W_cap);
+        const float *S2 = emit_level == 0 ? sx + 2 * (size_t)W : snap + smooth_snap_off((b - 1) & 1, emit_level, 2, W_cap);
+        const bool in_order = P.rpy_resolution > 2 && m->any_short; /* App. B.6: overlapping segments, finished by one thread below */
+        const bool copy2 = dst2 != nullptr && W <= cap2;
+        if (dst2 != nullptr && W > cap2 && tile == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
+        for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) {
+            float p[6];
+            p[0] = S0[g]; p[1] = S1[g]; p[2] = S2[g];
+            for (int d = 3; d < 6; ++d) p[d] = wp_pre[6 * (size_t)g + d];
+            for (int d = 0; d < 6; ++d) wp_smooth[6 * (size_t)g + d] = p[d];
+            if (!in_order) finish_one_waypoint(m, P, tail, wp_pre, g, p);
+            for (int d = 0; d < 6; ++d) wp_out[6 * (size_t)g + d] = p[d];
+            if (copy2 && !in_order) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)g + d] = p[d];
+        }
+        if (in_order) { /* the last tile to arrive finishes the whole list */
+            __shared__ int s_last;
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) s_last = atomicAdd(&m->emit_ticket, 1) == ntiles - 1;
+            __syncthreads();
+            if (s_last) {
+                __threadfence();
+                if (threadIdx.x == 0) { finish_list_in_order(m, P, tail, wp_out); m->emit_ticket = 0; }
+                __threadfence();
+                __syncthreads();
+                if (copy2) for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = wp_out[i];
             }
         }
         if (tile == 0 && threadIdx.x == 0) { m->sweeps = total_sweeps; m->smooth_done = b; }
@@ -2164,134 +2289,3 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
     STAMP(6, 4); /* per-sweep sums */
 }
 
-/* ------------------------------------------------------------------ */
-/* a14: reduceRPY (path_translation_alg.cpp:37-86)                      */
-/* ------------------------------------------------------------------ */
-__device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int res, DevMeta *m)
-{
-    int lastId;
-    do {
-        double dr[3];
-        lastId = preId + res;
-        if (lastId >= n) { m->rpy_oob = 1; break; } /* the reference reads past the list here (App. B.6) */
-        for (int D = 3; D < 6; D++) {
-            float a = W6[6 * (size_t)lastId + D], b = W6[6 * (size_t)preId + D];
-            if (a * b >= 0) {
-                dr[D - 3] = (double)((a - b) / res);
-            } else {
-                double no1, no2;
-                if (a < 0) { no2 = b; no1 = 2 * M_PI + a; }
-                else { no2 = 2 * M_PI + b; no1 = a; }
-                dr[D - 3] = (double)fabsf(a - b) < fabs(no1 - no2) ? (double)(a - b) : (no1 - no2);
-                dr[D - 3] /= res;
-            }
-        }
-        for (int wi = 1; wi < res; wi++)
-            for (int D = 3; D < 6; ++D)
-                W6[6 * (size_t)(preId + wi) + D] = (float)(dr[D - 3] + W6[6 * (size_t)(preId + wi - 1) + D]);
-        preId = lastId;
-    } while ((preId + res) <= tailId);
-    if (preId != tailId)
-        for (int i = preId + 1; i <= tailId; i++)
-            for (int D = 3; D < 6; ++D) W6[6 * (size_t)i + D] = W6[6 * (size_t)preId + D];
-}
-
-/* reduceRPY (path_translation_alg.cpp:37-86) per waypoint -- the key waypoints (every RPYres-th
-   of a slice) are never modified, so every interval is independent --, then the -180..180 limit
-   (:81-85) and TransFlangeposition (:89-112).  src: smoothed list; out: final WayPointsList. */
-__device__ inline void finish_waypoints(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
-                                               const float *__restrict__ src, float *out)
-{
-    const int W = m->W;
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m->err || W == 0) return;
-    const bool reduce = P.rpy_resolution > 2;
-    if (reduce && m->any_short) {
-        /* Only when a slice is shorter than RPYres+1 waypoints do the reference's segments overlap
-           (App. B.6): then, and only then, the whole list is finished in order by one thread. */
-        if (w != 0) return;
-        const int res = (int)P.rpy_resolution;
-        int preId = 0;
-        for (int id = 0; id < m->nkept; ++id) { rpy_segment(out, W, preId, tail[id], res, const_cast<DevMeta *>(m)); preId = tail[id] + 1; }
-        for (int q = 0; q < W; ++q) {
-            float p[6];
-            for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)q + d];
-            for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
-            float R[3][3];
-            rot_zyx(p[3], p[4], p[5], R);
-            const float ee[3] = {0.f, 0.f, -P.ee_length};
-            for (int i = 0; i < 3; ++i) out[6 * (size_t)q + i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
-            for (int D = 3; D < 6; ++D) out[6 * (size_t)q + D] = p[D];
-        }
-        return;
-    }
-    if (w >= W) return;
-    float p[6];
-    for (int d = 0; d < 6; ++d) p[d] = out[6 * (size_t)w + d]; /* k_smooth_batch wrote it */
-    if (reduce) {
-        const int res = (int)P.rpy_resolution;
-        /* segment of w: first tail >= w */
-        int lo = 0, hi = m->nkept - 1;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (tail[mid] < w) lo = mid + 1; else hi = mid; }
-        const int tl = tail[lo], p0 = lo == 0 ? 0 : tail[lo - 1] + 1;
-        const int nfull = (tl - p0) / res;       /* passes of the do-while */
-        const int lastkey = p0 + nfull * res;
-        const int r = w - p0;
-        if (w > lastkey) {
-            for (int D = 3; D < 6; ++D) p[D] = src[6 * (size_t)lastkey + D];
-        } else if (r % res != 0) {
-            const int pre = p0 + (r / res) * res, last = pre + res, wi = w - pre;
-            for (int D = 3; D < 6; D++) {
-                float a = src[6 * (size_t)last + D], bb = src[6 * (size_t)pre + D];
-                double dr;
-                if (a * bb >= 0) {
-                    dr = (double)((a - bb) / res);
-                } else {
-                    double no1, no2;
-                    if (a < 0) { no2 = bb; no1 = 2 * M_PI + a; }
-                    else { no2 = 2 * M_PI + bb; no1 = a; }
-                    dr = (double)fabsf(a - bb) < fabs(no1 - no2) ? (double)(a - bb) : (no1 - no2);
-                    dr /= res;
-                }
-                float v = bb;
-                for (int q = 1; q <= wi; ++q) v = (float)(dr + v); /* the reference accumulates in float */
-                p[D] = v;
-            }
-        }
-    }
-    if (reduce)
-        for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
-    float R[3][3];
-    rot_zyx(p[3], p[4], p[5], R);
-    const float ee[3] = {0.f, 0.f, -P.ee_length};
-    float t[3];
-    for (int i = 0; i < 3; ++i) t[i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
-    out[6 * (size_t)w + 0] = t[0]; out[6 * (size_t)w + 1] = t[1]; out[6 * (size_t)w + 2] = t[2];
-    out[6 * (size_t)w + 3] = p[3]; out[6 * (size_t)w + 4] = p[4]; out[6 * (size_t)w + 5] = p[5];
-}
-
-/* The launch: finish_waypoints, then (batched form) the list's copy into the caller's buffer -- the pass ends without a
-   separate copy-out launch.  (Also publishing the meta block from the last workgroup to retire, instead of the
-   device-to-host blit that follows, was measured and is slower: ~400 same-address tickets + stores across PCIe.) */
-#ifndef FIN_T
-#define FIN_T 64
-#endif
-__global__ void __launch_bounds__(FIN_T) k_finish(DevMeta *m, DevParams P, const int *__restrict__ tail, const float *__restrict__ src,
-                                               float *out, float *dst2, int cap2)
-{
-    finish_waypoints(m, P, tail, src, out);
-    const int W = m->W;
-    if (dst2 && !m->err && W > 0) {
-        if (W > cap2) { if (blockIdx.x == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1); }
-        else if (P.rpy_resolution > 2 && m->any_short) {
-            /* the sequential B.6 path finished the whole list in thread 0 of workgroup 0: that workgroup copies it */
-            if (blockIdx.x == 0) {
-                __syncthreads();
-                for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = out[i];
-            }
-        } else {
-            const int w = blockIdx.x * blockDim.x + threadIdx.x;
-            if (w < W) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)w + d] = out[6 * (size_t)w + d];
-        }
-    }
-}

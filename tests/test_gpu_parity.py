@@ -612,7 +612,7 @@ def test_slice_range_margin_too_small_is_reported(engine_mod):
 
 def test_run_batch_graph_matches_single_handles(engine_mod):
     """ppp_run_batch_async: several workpieces as one hipGraph with a branch each, lists landing in one device buffer."""
-    # the last member has slices shorter than RPYres + 1 waypoints: the sequential B.6 path of k_finish, which copies
+    # the last member has slices shorter than RPYres + 1 waypoints: the in-order B.6 path of the emitting launch (last tile to arrive), which copies
     # its list into the batch buffer from one workgroup
     kinds = [("small_40k", 1, {}), ("tiny_5k", 2, {}), ("small_40k", 3, {}), ("tiny_5k", 4, {}), ("small_40k", 5, {}),
              ("tiny_5k", 6, dict(path_resolution=9.0))]
