@@ -2161,12 +2161,20 @@ __global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, 
         const bool in_order = P.rpy_resolution > 2 && m->any_short; /* App. B.6: overlapping segments, finished by one thread below */
         const bool copy2 = dst2 != nullptr && W <= cap2;
         if (dst2 != nullptr && W > cap2 && tile == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
+        /* TailIndex in LDS: every waypoint's segment search is then eight LDS reads instead of eight dependent trips to L2 */
+        const int *tl = tail;
+        if (!in_order && P.rpy_resolution > 2 && m->nkept <= 4096) {
+            int *s_tail = (int *)s_raw;
+            for (int i = threadIdx.x; i < m->nkept; i += blockDim.x) s_tail[i] = tail[i];
+            __syncthreads();
+            tl = s_tail;
+        }
         for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) {
             float p[6];
             p[0] = S0[g]; p[1] = S1[g]; p[2] = S2[g];
             for (int d = 3; d < 6; ++d) p[d] = wp_pre[6 * (size_t)g + d];
             for (int d = 0; d < 6; ++d) wp_smooth[6 * (size_t)g + d] = p[d];
-            if (!in_order) finish_one_waypoint(m, P, tail, wp_pre, g, p);
+            if (!in_order) finish_one_waypoint(m, P, tl, wp_pre, g, p);
             for (int d = 0; d < 6; ++d) wp_out[6 * (size_t)g + d] = p[d];
             if (copy2 && !in_order) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)g + d] = p[d];
         }
