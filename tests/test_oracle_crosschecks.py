@@ -682,3 +682,19 @@ def test_trans2center_oracle_properties(oracle_mod):
     C2 = np.cov(Af.T)
     assert np.abs(C2 - np.diag(np.diag(C2))).max() < 1e-3 * np.abs(C2).max()
     assert np.allclose(Af, Q.astype(np.float64) @ Rm.T + T[:3, 3], atol=2e-3)
+
+
+def test_oracle_under_address_sanitizer():
+    """the CPU oracle built with -fsanitize=address,undefined, every entry point once (plans of all
+    pairings with and without the dynamic adjustment, the four preprocessing steps, the aligned getPath, a 50-point cloud)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not installed")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "oracle_sanitizer_drive.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
