@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -155,7 +156,19 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     if (ix < 0 || iy < 0 || iz < 0) return PPP_ERR_IO;
     if (data_kind == "binary" && (points > remaining || (size_t)off * points > remaining)) return PPP_ERR_IO;
     if (data_kind == "ascii" && points > remaining) return PPP_ERR_IO; /* a point takes at least one byte */
-    if (data_kind == "binary_compressed" && points > (size_t)1 << 40) return PPP_ERR_IO;
+    uint32_t csize = 0, usize = 0;
+    if (data_kind == "binary_compressed") {
+        /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream.  Both sizes are checked against the
+           file and the header before anything is allocated: an LZF stream expands by less than 90x (a 3-byte token copies
+           at most 264 bytes) */
+        unsigned char hdr[8];
+        f.read((char *)hdr, 8);
+        if (f.gcount() != 8) return PPP_ERR_IO;
+        memcpy(&csize, hdr, 4); memcpy(&usize, hdr + 4, 4);
+        if ((size_t)csize + 8 > remaining || (size_t)usize > (size_t)csize * 90 + 64) return PPP_ERR_IO;
+        if (off <= 0 || points > (size_t)usize || (size_t)usize != (size_t)off * points) return PPP_ERR_IO;
+    }
+    if (off <= 0 || points > ((size_t)1 << 40)) return PPP_ERR_IO;
     float *out = (float *)malloc(sizeof(float) * 3 * std::max<size_t>(points, 1));
     if (!out) return PPP_ERR_IO;
     if (data_kind == "ascii") {
@@ -191,12 +204,6 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     } else if (data_kind == "binary_compressed") {
         /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream; the decoded block is
            field-major (all x, then all y, ...) */
-        unsigned char hdr[8];
-        f.read((char *)hdr, 8);
-        if (f.gcount() != 8) { free(out); return PPP_ERR_IO; }
-        uint32_t csize, usize;
-        memcpy(&csize, hdr, 4); memcpy(&usize, hdr + 4, 4);
-        if ((size_t)usize != (size_t)off * points || (size_t)csize + 8 > remaining) { free(out); return PPP_ERR_IO; }
         std::vector<unsigned char> comp(csize), raw(usize);
         f.read((char *)comp.data(), (std::streamsize)csize);
         if ((size_t)f.gcount() != (size_t)csize) { free(out); return PPP_ERR_IO; }
@@ -256,6 +263,18 @@ void ppp_default_config(ppp_config *c)
     c->smooth_cloud = 0; c->remove_outlier = 0; c->alignment = 0; c->dynamic_adjustment = 1;
 }
 
+/* std::stod's acceptance without its exceptions: leading whitespace, the longest numeric prefix, trailing text ignored;
+   no conversion or a value out of range is an error (std::stod throws there, out of the reference's constructor) */
+static bool parse_double(const std::string &v, double *out)
+{
+    errno = 0;
+    char *end = nullptr;
+    const double d = strtod(v.c_str(), &end);
+    if (end == v.c_str() || errno == ERANGE) return false;
+    *out = d;
+    return true;
+}
+
 static int read_config_impl(const char *path, ppp_config *c)
 {
     if (!path || !c) return PPP_ERR_ARG;
@@ -270,23 +289,22 @@ static int read_config_impl(const char *path, ppp_config *c)
         auto pos = line.find("=");
         if (line.empty() || line[0] == '#' || pos == std::string::npos) continue;
         std::string name = line.substr(0, pos), value = line.substr(pos + 1);
-        try {
-            if (name == "pathFile") snprintf(c->path_file, sizeof(c->path_file), "%s", value.c_str());
-            else if (name == "Tool_Radius") c->params.tool_radius = std::stod(value);
-            else if (name == "depth") c->depth = std::stod(value);
-            else if (name == "Adjust_Threshold") c->adjust_threshold = std::stod(value);
-            else if (name == "toolthickness") c->toolthickness = std::stod(value);
-            else if (name == "PathResolution") c->params.path_resolution = std::stod(value);
-            else if (name == "RPYresolution") c->params.rpy_resolution = std::stod(value);
-            else if (name == "Endeffectorlength") c->params.ee_length = (float)std::stod(value);
-            else if (name == "Alignment") c->alignment = value == "true";
-            else if (name == "Smooth") c->smooth_cloud = value == "true";
-            else if (name == "ChangeRange") c->params.change_range = value == "true";
-            else if (name == "RemoveOutlier") c->remove_outlier = value == "true";
-            else if (name == "Dynamic_adjustment") c->dynamic_adjustment = value == "true";
-        } catch (...) {
-            return PPP_ERR_ARG; /* std::stod would have thrown out of the reference's constructor */
-        }
+        double d = 0;
+        bool ok = true;
+        if (name == "pathFile") snprintf(c->path_file, sizeof(c->path_file), "%s", value.c_str());
+        else if (name == "Tool_Radius") { if ((ok = parse_double(value, &d))) c->params.tool_radius = d; }
+        else if (name == "depth") { if ((ok = parse_double(value, &d))) c->depth = d; }
+        else if (name == "Adjust_Threshold") { if ((ok = parse_double(value, &d))) c->adjust_threshold = d; }
+        else if (name == "toolthickness") { if ((ok = parse_double(value, &d))) c->toolthickness = d; }
+        else if (name == "PathResolution") { if ((ok = parse_double(value, &d))) c->params.path_resolution = d; }
+        else if (name == "RPYresolution") { if ((ok = parse_double(value, &d))) c->params.rpy_resolution = d; }
+        else if (name == "Endeffectorlength") { if ((ok = parse_double(value, &d))) c->params.ee_length = (float)d; }
+        else if (name == "Alignment") c->alignment = value == "true";
+        else if (name == "Smooth") c->smooth_cloud = value == "true";
+        else if (name == "ChangeRange") c->params.change_range = value == "true";
+        else if (name == "RemoveOutlier") c->remove_outlier = value == "true";
+        else if (name == "Dynamic_adjustment") c->dynamic_adjustment = value == "true";
+        if (!ok) return PPP_ERR_ARG;
     }
     /* the adjustment parameters travel inside ppp_params */
     c->params.depth = c->depth; c->params.adjust_threshold = c->adjust_threshold; c->params.toolthickness = c->toolthickness;
