@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < SORT_T / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); } /* launched with 256 or SORT_T threads */
         slab_xmin[b] = mn; slab_xmax[b] = mx;
     }
 }
