@@ -168,6 +168,14 @@ def main():
 
     out = None
     if rank == 0:
+        # ---- the last step's assembled robot path (untimed check): rank 0's own block is its engine's list, every
+        # rank's block has the row count that rank announced ----
+        assembled = None
+        if blocks is not None:
+            own = eng.waypoints()
+            got0 = blocks[0][: own.shape[0]].cpu().numpy()
+            assembled = {"rank0_block_equals_its_list": bool(np.array_equal(got0, own)),
+                         "rows_per_rank": [int(b.shape[0]) for b in blocks]}
         # ---- roofline of the dominant kernel: HIP events on the engine's own stream ----
         eng.enable_timing(True)
         acc, launches = {}, {}
@@ -254,6 +262,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "path_l2_err": err,
+            "assembled_path": assembled,
         }
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
