@@ -803,6 +803,13 @@ def test_trans2center_matches_the_oracle(engine_mod, oracle_mod, t):
         for _ in range(3):                    # the captured graph carries the sensor-frame index of the aligned variant
             e.run_async(); e.sync()
             assert e.waypoints().tobytes() == want
+        if t == 7:                            # an aligned and an unaligned handle as branches of one batch graph
+            pts2, _ = synth.make_config("tiny_5k")
+            e2 = engine_mod.Engine(0, tool_radius=6.0); e2.set_cloud(pts2); e2.gen_path(); e2.get_path()
+            want2 = e2.waypoints().tobytes()
+            for _ in range(2):
+                engine_mod.run_batch_async([e, e2]); engine_mod.sync_batch([e, e2])
+                assert e.waypoints().tobytes() == want and e2.waypoints().tobytes() == want2
         n_o = o.remove_outlier(50, 1.0)[0]    # constructor order: align, then remove -- the sensor-frame copy follows the cloud
         assert e.remove_outlier(50, 1.0)[0] == n_o
         assert_full_parity(engine_mod, e, o)
