@@ -654,13 +654,13 @@ def test_run_batch_graph_matches_single_handles(engine_mod):
 
 
 def test_randomised_sweep_against_the_oracle(engine_mod, oracle_mod):
-    """tools/fuzz_parity.py, 40 seeded cases: random shape / radius / walk / pairing / dynamic adjustment / duplicates /
+    """tests/tools/fuzz_parity.py, 40 seeded cases: random shape / radius / walk / pairing / dynamic adjustment / duplicates /
     non-finite points; knots bit-exact, waypoints <= 1e-4 m, identical failing slice where the reference would abort,
     slice-range sharding byte-identical to the single handle."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tests", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     rng = np.random.default_rng(2024)

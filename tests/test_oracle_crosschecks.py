@@ -127,7 +127,7 @@ def test_nearest_and_radius_match_brute_force(small):
 
 
 def test_kdtree_leaves_non_finite_points_out(oracle_mod):
-    """pcl::KdTreeFLANN indexes finite points only (a cloud read with NaNs is not dense); found by tools/fuzz_parity.py:
+    """pcl::KdTreeFLANN indexes finite points only (a cloud read with NaNs is not dense); found by tests/tools/fuzz_parity.py:
     NaNs inside the median split used to corrupt the tree and return a far point for ~1 % of the queries."""
     from polishpathplanning_amd import synth
     pts = synth.make_plate(200, 80, kind="wavy", amp=20.0, seed=5)

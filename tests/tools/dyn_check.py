@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Dynamic adjustment on one synthetic config: GPU time per kernel, and the knots /
-waypoints against the oracle.  usage: python tools/dyn_check.py [config] [walk] [--no-oracle]"""
+waypoints against the oracle.  usage: python tests/tools/dyn_check.py [config] [walk] [--no-oracle]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from polishpathplanning_amd import engine, synth  # noqa: E402
 
 

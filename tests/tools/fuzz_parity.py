@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle sweep over cloud shapes, tool radii, walks, pairings and the dynamic adjustment.
 Every case must agree on S, the knots of every slice (bit-exact), W and the waypoints (<= 1e-4 m), or both
-sides must report the same failing slice.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+sides must report the same failing slice.  usage: python tests/tools/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from polishpathplanning_amd import engine, synth  # noqa: E402
 from oracle import ppo  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Developer tool: stage-by-stage comparison of the HIP engine with the CPU oracle on a GPU box.
-Usage: python tools/gpu_check.py [config ...]"""
+Usage: python tests/tools/gpu_check.py [config ...]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from polishpathplanning_amd import engine, synth
 from oracle import ppo

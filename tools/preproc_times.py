@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock of the cloud preprocessing entry points on the GPU for one synthetic cloud:
    remove_outlier (SOR 50 / 1 sigma), trans2center, voxel_down (main.cpp:25's 0.1 x 1 x 1 and a 3 mm cube), MLS smooth (order 3, r 15).
-   usage: preproc_times.py [config name, default cfg2_1m_s256] [--oracle N]   (--oracle: time the CPU port on the first N points' plate)"""
+   usage: preproc_times.py [config name, default cfg2_1m_s256]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,15 +30,7 @@ def main():
             res = fn(e)
             best = min(best, time.perf_counter() - t0)
         print("%-26s %9.3f ms   -> %s" % (label, best * 1e3, res))
-    if "--oracle" in sys.argv:
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-        import ppo
-        sub, _ = synth.make_config("small_40k")
-        for label, fn in [("remove_outlier", lambda o: o.remove_outlier(50, 1.0)), ("voxel_down(0.1,1,1)", lambda o: o.voxel_down(0.1, 1, 1)),
-                          ("smooth_mls(15,3)", lambda o: o.smooth_mls(15.0, 3))]:
-            o = ppo.Oracle(sub, tool_radius=6.0)
-            t0 = time.perf_counter(); fn(o); dt = time.perf_counter() - t0
-            print("oracle %-20s %9.1f ms for %d points = %.2f us/point" % (label, dt * 1e3, len(sub), dt * 1e6 / len(sub)))
+
 
 if __name__ == "__main__":
     main()
