@@ -1,4 +1,7 @@
 // Mirror of the reference's src/main.cpp (:6-36): ./main workpiece.pcd, tool radius 15.
+// The calls main.cpp:25-29 keeps commented out can be switched on from the environment: PPP_MAIN_VOXEL=1 (voxel_down(0.1, 1, 1)),
+// PPP_MAIN_ALIGN=1 (trans2center), PPP_MAIN_SLICING=1 (slicing_method), PPP_MAIN_SMOOTH=1 (smooth).
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include "Path_Generate.h"
@@ -16,6 +19,11 @@ int main(int argc, char **argv)
     }
     double step_size = 15;
     path_generater path_planner(pcd, step_size);
+    auto on = [](const char *name) { const char *v = std::getenv(name); return v && v[0] == '1'; };
+    if (on("PPP_MAIN_VOXEL")) path_planner.voxel_down(0.1, 1, 1);
+    if (on("PPP_MAIN_ALIGN")) path_planner.trans2center();
+    if (on("PPP_MAIN_SLICING")) path_planner.slicing_method();
+    if (on("PPP_MAIN_SMOOTH")) path_planner.smooth();
     path_planner.estimate_normal();
     path_planner.Contact_Path_Generation();
     path_planner.show();

@@ -340,6 +340,11 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
     if not align:       # ./main never aligns (main.cpp:26 is commented out): it needs the plate in its own frame
         r = subprocess.run([os.path.join(root, "examples", "main"), pcd], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
         assert r.returncode == 0 and "number of paths" in r.stdout
+        if smooth:      # the calls main.cpp:25-29 keeps commented out, switched on: voxel grid, slicing_method, MLS (+ its side file)
+            env2 = dict(env, PPP_MAIN_VOXEL="1", PPP_MAIN_SLICING="1", PPP_MAIN_SMOOTH="1")
+            r = subprocess.run([os.path.join(root, "examples", "main"), "workpiece.pcd"], env=env2, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+            assert r.returncode == 0 and r.stdout.count("number of paths") == 2, r.stdout + r.stderr
+            assert os.path.exists(str(tmp_path / "smooth_workpiece.pcd"))
 
 
 def test_contour_cli_trims_five_and_uses_its_own_hand_eye(engine_mod, oracle_mod, tmp_path):
