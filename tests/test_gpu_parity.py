@@ -347,6 +347,33 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
             assert os.path.exists(str(tmp_path / "smooth_workpiece.pcd"))
 
 
+def test_robot_path_class_end_to_end(engine_mod, oracle_mod, tmp_path):
+    """include/robot_path.h (class RobotPath, robot_path.h:58-98; behaviour of the July snapshot path_connect_ex0720.cpp): the
+    three-argument constructor, single-direction float walk from min.x + Radius, +-5 trim, no first/last drop, no
+    position smoothing, its own hand-eye calibration -- through examples/robot against the oracle with those parameters."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "robot"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("small_40k")
+    pcd = str(tmp_path / "workpiece.pcd")
+    engine_mod.save_pcd(pcd, pts, binary=True)
+    out = str(tmp_path / "WayPoints.txt")
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 12\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\n" % out)
+    r = subprocess.run([os.path.join(root, "examples", "robot"), pcd, "7.5"], env=dict(os.environ, PPP_CONFIG=str(conf)),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(out, dtype=np.float64).reshape(-1, 6)
+    he = [0.792078, -0.042662, 0.6656017, -3.1531625, -0.048573, 1.609157]
+    o = oracle_mod.Oracle(pts, tool_radius=7.5, pairing=0, walk=3, trim=5.0, drop_ends=0, smooth=0, handeye=he)
+    S = o.gen_path(); o.get_path()
+    want = o.waypoints()
+    assert "waypoints: %d" % len(want) in r.stdout
+    assert got.shape == want.shape and len(o.tail_index()) == S          # every slice is kept
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 + 5e-6 * np.abs(want[:, :3]).max()
+
+
 def test_contour_cli_trims_five_and_uses_its_own_hand_eye(engine_mod, oracle_mod, tmp_path):
     """include/contour_alg.h driven like src/contour.cpp (+ the plan): SectPath with getPath's +-5 trim
     (contour_alg.cpp:496-497) and the hand-eye calibration of contour_alg.h:37-42."""
