@@ -942,7 +942,26 @@ def test_distinct_handles_from_concurrent_host_threads(engine_mod):
         except Exception as ex:  # noqa: BLE001
             errors.append((i, repr(ex)))
 
-    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(clouds))]
+    # ... while another thread preprocesses clouds (allocations, the library sort, a second handle made inside trans2center)
+    tilted = _rotated_plate(7)
+    ref = engine_mod.Engine(0, tool_radius=6.0); ref.set_cloud(tilted); ref.smooth_mls(15.0, 3); ref.trans2center(); ref.remove_outlier(50, 1.0)
+    ref.gen_path(); ref.get_path()
+    want_pre = ref.waypoints().tobytes()
+
+    def preprocessor():
+        try:
+            for rep in range(4):
+                e = engine_mod.Engine(0, tool_radius=6.0)
+                e.set_cloud(tilted)
+                e.smooth_mls(15.0, 3); e.trans2center(); e.remove_outlier(50, 1.0)
+                e.run_async(); e.sync()
+                if e.waypoints().tobytes() != want_pre:
+                    errors.append(("pre", rep, "list differs"))
+                e.voxel_down(0.5, 0.5, 5.0)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("pre", repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(clouds))] + [threading.Thread(target=preprocessor)]
     for t in threads:
         t.start()
     for t in threads:
