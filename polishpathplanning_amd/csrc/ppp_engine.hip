@@ -11,6 +11,12 @@
 #include "ppp_preproc.h"
 #include "ppp_sort.h"
 #include "ppp_align.h"
+/* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
+   clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
+   slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
+#ifndef PPP_SLAB_CAP_FACTOR
+#define PPP_SLAB_CAP_FACTOR 1.6
+#endif
 #include "../../include/ppp_hip.h"
 
 #include <dlfcn.h>
@@ -348,7 +354,7 @@ int make_plan(ppp_handle h)
     {
         double mean = (double)h->h_nvalid / B;
         int cap = 2048; /* 24 KiB of LDS per workgroup: still 6 workgroups per CU */
-        while (cap < 4096 && cap < 2.0 * mean) cap <<= 1;
+        while (cap < 4096 && cap < PPP_SLAB_CAP_FACTOR * mean) cap <<= 1;
         h->slab_cap = cap;
     }
     HIPCHK(h, h->big_slabs.ensure(B));
