@@ -14,6 +14,12 @@
 /* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
    clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
    slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
+#ifndef PPP_PPT8_FROM
+#define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
+#endif
+#ifndef PPP_MM_GRID_MAX
+#define PPP_MM_GRID_MAX 256 /* workgroups of the bounds + histogram pass (measured) */
+#endif
 #ifndef PPP_SLAB_CAP_FACTOR
 #define PPP_SLAB_CAP_FACTOR 1.6
 #endif
@@ -428,7 +434,7 @@ int enqueue_index(ppp_handle h)
     {   /* a2 and the slab histogram in ONE pass over the cloud (the slab grid comes from the bounds cached with the
            cloud).  At most 256 workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
            that flush, not the streaming, is what grows with the grid. */
-        const int gf = std::max(1, std::min(h->mm_grid, 256));
+        const int gf = std::max(1, std::min(h->mm_grid, PPP_MM_GRID_MAX));
         LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
                h->incl_lo, h->incl_hi);
         h->mm_grid_used = gf;
@@ -439,7 +445,7 @@ int enqueue_index(ppp_handle h)
        atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global atomic per
        non-empty (workgroup, slab) pair, so larger clouds use 8 instead of 4 points per thread */
-    const bool ppt8 = n > 1500000;
+    const bool ppt8 = n > PPP_PPT8_FROM;
     const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
     const int gs = std::max(1, (n + chunk - 1) / chunk);
     if (!h->two_pass_scatter) {
