@@ -14,6 +14,9 @@
 /* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
    clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
    slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
+#ifndef PPP_SLAB_PTS
+#define PPP_SLAB_PTS 832 /* mean points per x-slab (measured, see make_plan) */
+#endif
 #ifndef PPP_PPT8_FROM
 #define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
 #endif
@@ -353,7 +356,7 @@ int make_plan(ppp_handle h)
        in the same order and the sharded list is bit-identical to the unsharded one. */
     /* 832 points per slab on average (measured: 640 .. 960 within 5 %, best here; from 1024 on the sort needs the
        larger LDS block and loses occupancy) -- a slab 2.4 times denser than the mean still sorts in LDS */
-    const int SLAB_PTS = 832;
+    const int SLAB_PTS = PPP_SLAB_PTS;
     int B = (h->h_nvalid + SLAB_PTS - 1) / SLAB_PTS;
     B = std::max(1, std::min(B, 8192));
     h->B = B;
