@@ -14,6 +14,9 @@
 /* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
    clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
    slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
+#ifndef PPP_NN_HINT_SPACINGS
+#define PPP_NN_HINT_SPACINGS 3.0 /* first bound of a waypoint's nearest-neighbour search, in mean point spacings (a hint: nothing found -> unbounded repeat) */
+#endif
 #ifndef PPP_SLAB_PTS
 #define PPP_SLAB_PTS 832 /* mean points per x-slab (measured, see make_plan) */
 #endif
@@ -213,7 +216,7 @@ DevParams dev_params(const ppp_handle h)
     {   /* mean spacing of a sheet-like cloud from its bounding rectangle; only a search hint, never a cut-off */
         const double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
         const double spacing = (area > 0 && h->h_nvalid > 0) ? std::sqrt(area / h->h_nvalid) : 1.0;
-        const double r = std::max(1.0, 3.0 * spacing);
+        const double r = std::max(1.0, PPP_NN_HINT_SPACINGS * spacing);
         D.nn_hint2 = (float)(r * r);
     }
     return D;
