@@ -24,7 +24,7 @@
 #define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
 #endif
 #ifndef PPP_MM_GRID_MAX
-#define PPP_MM_GRID_MAX 256 /* workgroups of the bounds + histogram pass (measured) */
+#define PPP_MM_GRID_MAX 192 /* workgroups of the bounds + histogram pass: every one flushes its LDS histogram with an atomic per non-empty slab, which is what grows with the grid (1 M points: 192 is 1.5 us ahead of 256; 128 .. 160 the same) */
 #endif
 #ifndef PPP_SLAB_CAP_FACTOR
 #define PPP_SLAB_CAP_FACTOR 1.6
@@ -438,7 +438,7 @@ int enqueue_index(ppp_handle h)
     const float xr = h->h_mx[0] - h->h_mn[0];
     const float slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f;
     {   /* a2 and the slab histogram in ONE pass over the cloud (the slab grid comes from the bounds cached with the
-           cloud).  At most 256 workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
+           cloud).  At most PPP_MM_GRID_MAX workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
            that flush, not the streaming, is what grows with the grid. */
         const int gf = std::max(1, std::min(h->mm_grid, PPP_MM_GRID_MAX));
         LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
