@@ -66,7 +66,8 @@ typedef struct ppp_params {
     int    smooth;            /* 1: postion_smooth() applied (path_translation_alg.cpp:212)   */
     float  handeye[6];        /* HANDEYEx..rz (Path_Generate_Algorithm.h:43-48)               */
     float  normal_radius;     /* 2.5 (path_slicing_alg.cpp:147)                               */
-    int    smooth_max_sweeps; /* cap of the smoothing loop                   */
+    int    smooth_max_sweeps; /* unused by the engine (postion_smooth is solved directly, ppp_kernels.h a13); the
+                                 oracle's sequential sweep takes it as its cap     */
     int    alignment;         /* must be 0: Alignment / Smooth / RemoveOutlier are the ppp_trans2center / ppp_smooth_mls / ppp_remove_outlier calls */
     int    dynamic_adjustment;/* Dynamic_adjustment (config.txt:13): path_dynamic_alg.cpp:77-306 for the connect /
                                  connect1 walks, Path_Generation.cpp:362-634 for PPP_WALK_V1_CONTACT            */
@@ -234,6 +235,7 @@ enum { PPP_STAGE_WP_XYZ = 0,      /* W x 3 float: sampled points, mm (path_trans
        PPP_STAGE_WP_PRESMOOTH = 3,/* W x 6 float: after HandEyeTransform (:208)                         */
        PPP_STAGE_WP_SMOOTHED = 4  /* W x 6 float: after postion_smooth (:212)                           */ };
 int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *count);
+/* sweeps of postion_smooth: always 0 -- the engine solves the sweeps' fixed point directly (one launch) */
 int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
 
 /* ---- host-side file formats of the reference (no device work) ---- */

@@ -113,12 +113,11 @@ struct ppp_handle_s {
     DevBuf<int> wp_cnt, wp_off, tail;
     DevBuf<float4> wp_xyz, wp_normal;
     DevBuf<int> wp_nn;
-    DevBuf<float> wp_pre, wp_smooth, wp_out, sx, snap;
+    DevBuf<float> wp_pre, wp_smooth, wp_out;
     DevBuf<MinMaxPart> mm_part;
     DevBuf<int> big_slabs, big_slices; /* work lists of the LDS-overflow fallback kernels */
     DevBuf<char> arena;                /* their global scratch, allocated on first need */
     bool big_path = false;             /* launch the fallback kernels (set by the plan or after an overflow) */
-    DevBuf<double> sm_part, sm_chist;
     int mm_grid = 1, mm_grid_used = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
 
@@ -155,7 +154,7 @@ struct ppp_handle_s {
         normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
-        sx.release(); snap.release(); mm_part.release(); sm_part.release(); sm_chist.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
+        mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
         drop_graph();
         drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
@@ -416,11 +415,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->wp_xyz.ensure(h->W_cap)); HIPCHK(h, h->wp_normal.ensure(h->W_cap)); HIPCHK(h, h->wp_nn.ensure(h->W_cap));
     HIPCHK(h, h->wp_pre.ensure(6 * (size_t)h->W_cap)); HIPCHK(h, h->wp_smooth.ensure(6 * (size_t)h->W_cap));
     HIPCHK(h, h->wp_out.ensure(6 * (size_t)h->W_cap));
-    HIPCHK(h, h->sx.ensure(3 * (size_t)h->W_cap));
-    HIPCHK(h, h->snap.ensure(2 * (size_t)SM_K * 3 * (size_t)h->W_cap));
     h->sm_tiles = smooth_tiles(h->W_cap);
-    HIPCHK(h, h->sm_part.ensure((size_t)(SM_MAXS + SM_K + 1) * h->sm_tiles));
-    HIPCHK(h, h->sm_chist.ensure(SM_MAXS + SM_K + 1));
     h->planned = true;
     h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
     h->drop_graph(); /* buffer addresses and launch geometry are baked into the captured graph */
@@ -713,8 +708,6 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-    (void)hipFuncSetAttribute((const void *)k_smooth_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(0));
-    (void)hipFuncSetAttribute((const void *)k_smooth_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES_OF(1));
     (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -1171,18 +1164,10 @@ int ppp_gen_path_async(ppp_handle h)
 /* getPath's second half: postion_smooth, reduceRPY, TransFlangeposition (path_translation_alg.cpp:212-214) */
 int enqueue_finish(ppp_handle h, const DevParams &D)
 {
-    /* postion_smooth: SM_K sweeps per launch; the launch after the stop sweep replays, emits, and finishes the list
-       (reduceRPY, flange offset, the copy into the caller's buffer of the batched form) */
-    const int nb = h->P.smooth ? (h->P.smooth_max_sweeps + SM_K - 1) / SM_K : 0;
-    const bool wave_partials = h->sm_tiles > h->num_cus; /* more tiles than CUs: the small-LDS variant runs several per CU */
-    for (int b = 0; b <= nb; ++b) {
-        if (wave_partials)
-            LAUNCH(h, "k_smooth_batch", k_smooth_batch<true>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(1), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p, h->tail.p, h->out2, h->out2_cap);
-        else
-            LAUNCH(h, "k_smooth_batch", k_smooth_batch<false>, h->sm_tiles, SM_T, SM_LDS_BYTES_OF(0), h->meta.p, D, b, h->sm_tiles, h->W_cap, h->sx.p,
-                   h->snap.p, h->sm_part.p, h->sm_chist.p, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p, h->tail.p, h->out2, h->out2_cap);
-    }
+    /* postion_smooth solved directly (one 65-tap filter per waypoint), then reduceRPY, the flange offset and the copy into
+       the caller's buffer of the batched form: ONE launch */
+    LAUNCH(h, "k_smooth_solve", k_smooth_solve, h->sm_tiles, SMF_T, 0, h->meta.p, D, h->W_cap, h->wp_pre.p, h->wp_smooth.p, h->wp_out.p,
+           h->tail.p, h->out2, h->out2_cap);
     return enqueue_meta_copy(h);
 }
 
@@ -1205,12 +1190,12 @@ int ppp_get_path_async(ppp_handle h)
         LAUNCH(h, "k_pose<aligned>", k_pose<true>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
                h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
                h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
-               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p, PB);
+               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB);
     } else
     LAUNCH(h, "k_pose", k_pose<false>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
            h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
-           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, h->sx.p, PB);
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB);
     h->path_done = true;
     h->list_final = false;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
@@ -1236,7 +1221,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
     DevParams D = dev_params(h);
     if (nkept) HIPCHK(h, hipMemcpyAsync(h->wp_cnt.p, counts, nkept * sizeof(int), hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "k_count_given", k_count_given, 1, 1024, 0, h->meta.p, D, (int)nkept, (int)W, h->wp_cnt.p, h->wp_off.p, h->tail.p, h->W_cap);
-    if (W) LAUNCH(h, "k_load_pre", k_load_pre, (unsigned)((W + 255) / 256), 256, 0, h->meta.p, pre6_dev, h->wp_pre.p, h->sx.p);
+    if (W) LAUNCH(h, "k_load_pre", k_load_pre, (unsigned)((W + 255) / 256), 256, 0, h->meta.p, pre6_dev, h->wp_pre.p);
     int rc = enqueue_finish(h, D);
     if (rc) return rc;
     h->gen_done = true; h->path_done = true; h->list_final = true;

@@ -1328,18 +1328,13 @@ __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, i
     }
 }
 
-/* ... and the list itself into the layouts k_pose leaves behind (AoS for the output stages, SoA positions
-   for the smoothing tiles) */
-__global__ void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float *__restrict__ pre6, float *wp_pre, float *sx)
+/* ... and the list itself into the buffer k_pose leaves it in */
+__global__ void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float *__restrict__ pre6, float *wp_pre)
 {
     const int W = m->W;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (m->err || w >= W) return;
-    for (int d = 0; d < 6; ++d) {
-        const float v = pre6[6 * (size_t)w + d];
-        wp_pre[6 * (size_t)w + d] = v;
-        if (d < 3) sx[(size_t)d * W + w] = v;
-    }
+    for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = pre6[6 * (size_t)w + d];
 }
 
 __global__ void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const float *__restrict__ node_y,
@@ -1751,7 +1746,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                               int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
-                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, float *sx, PoseBack back)
+                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     float4 *s_pts = (float4 *)s_raw;
@@ -1873,7 +1868,6 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                 wp_nn[w] = id;
                 wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
                 for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = wp[d];
-                for (int d = 0; d < 3; ++d) sx[(size_t)d * W + w] = wp[d];
             }
             STAMP(1, 4); /* pose + hand-eye */
         }
@@ -2031,269 +2025,130 @@ __device__ inline void finish_list_in_order(DevMeta *m, const DevParams &P, cons
 }
 
 /* ------------------------------------------------------------------ */
-/* a13: postion_smooth (path_translation_alg.cpp:114-141).              */
-/* One Gauss-Seidel sweep of the reference is the recurrence             */
-/*   y_i' = fl32( y_i + 0.65 (x_i - y_i) + 0.35 (y_{i+1} + y'_{i-1} - 2 y_i) )                   */
-/*        = fl32( c_i + 0.35 y'_{i-1} ),  c_i = y_i + 0.65 (x_i - y_i) + 0.35 (y_{i+1} - 2 y_i)  */
-/* where c_i only needs the previous sweep.  The serial chain is issue   */
-/* bound (12 f64 instructions per step), so the kernel evaluates it as   */
-/* a filter: c is computed for every element in parallel, then each      */
-/* thread runs  acc = c_i + 0.35 acc  (one FMA per step) over a run-up   */
-/* of SM_D = 8 elements -- the seed is the element's value one sweep     */
-/* earlier, off by at most that sweep's change (<= 1e-3 m); the error    */
-/* decays by 0.35 per step, 0.35^9 of it is < 1e-7 m, below the float    */
-/* rounding the difference to the reference already carries (measured:   */
-/* run-ups of 8, 12 and 16 give the same 2.4e-7 m) -- and over its own   */
-/* SM_L elements.  The run-up is the kernel's LDS traffic and the halo   */
-/* a tile carries per sweep: 16 -> 8 took cfg 5 from 209 to 118 us.      */
-/* Difference from the reference: the chain carries the unrounded double */
-/* instead of the float-rounded y'_{i-1}; that perturbs each sweep by    */
-/* < 1 float ulp (6e-8 m) and the sweeps contract by ~0.5, so the        */
-/* smoothed list differs from the sequential one by ~1e-7 m (tolerance   */
-/* 1e-4 m; tests/test_gpu_parity.py bounds it at 1e-6 m).                */
-/* A workgroup keeps a tile + halo in LDS for SM_K sweeps per launch and */
-/* snapshots its owned range after every sweep; the per-sweep sums of    */
-/* |delta| that drive the stop rule are written per     */
-/* workgroup and summed in a fixed order by the next launch, which       */
-/* either continues from the last snapshot or emits the snapshot of the  */
-/* stop sweep.                                                           */
+/* a13: postion_smooth (path_translation_alg.cpp:114-141), solved directly.                          */
+/* The reference sweeps  y_i += 0.65 (x_i - y_i) + 0.35 (y_{i+1} + y_{i-1} - 2 y_i)  (Gauss-Seidel, ends fixed)   */
+/* until the list is stationary; what it converges to is, per coordinate, the solution of the        */
+/* tridiagonal system  1.35 y_i - 0.35 y_{i-1} - 0.35 y_{i+1} = 0.65 x_i,  y_0 = x_0, y_{W-1} = x_{W-1}          */
+/* (SURVEY.md App. A.7).  The matrix is Toeplitz and strongly diagonally dominant, so its inverse is  */
+/* a two-sided geometric kernel: with r = (1.35 - sqrt(1.35^2 - 0.7^2)) / 0.7 = 0.2795... the root of  */
+/* 0.35 r^2 - 1.35 r + 0.35 = 0 and c = 0.65 / (1.35 - 0.7 r),                                         */
+/*   p_i = c * sum_j r^|i-j| x_j   (j over the interior 1..W-2)                                       */
+/* satisfies every interior equation, and  y_i = p_i + A r^i + B r^(W-1-i)  with A, B from the two    */
+/* fixed ends is THE solution.  r^33 < 1e-18: truncated to 32 neighbours either side the sum is exact */
+/* in double precision, so every waypoint is an independent 65-tap filter over its neighbours --      */
+/* one launch, no sweeps, no stop rule, no snapshots -- evaluated outside-in (Horner in r), always in */
+/* the same order, so the result does not depend on how the list is tiled or sharded.                 */
+/* Against the oracle's sequential float sweep (which stops when the float state is stationary,       */
+/* DESIGN.md B.12) the difference is the float storage floor: <= 1.2e-7 m measured for W >= 50,        */
+/* <= 6e-7 m for the 3..5-waypoint lists where the reference's own 1e-5 test ends the sweeps early.   */
+/* The same launch finishes the list per waypoint: reduceRPY, the +-pi limit, the flange offset and,  */
+/* in the batched form, the copy into the caller's gather buffer.                                     */
 /* ------------------------------------------------------------------ */
-#ifndef SM_K
-#define SM_K 16
+#define SM_MAXS 512          /* ppp_params.smooth_max_sweeps is validated against it (the oracle's sweep cap) */
+#ifndef SMF_T
+#define SMF_T 256            /* waypoints (= threads) per tile */
 #endif
-#ifndef SM_D
-#define SM_D 8
-#endif
-#define SM_L 1
-#ifndef SM_T
-#define SM_T 512
-#endif
-#define SM_M (SM_T * SM_L)
-#define SM_HB ((SM_D + 1) * SM_K + 1)
-#define SM_OWN (SM_M - SM_HB - SM_K)
-#define SM_MAXS 512
-/* LDS of a tile; WP (wave partials) keeps one |delta| sum per wave and sweep instead of one per thread */
-#define SM_LDS_BYTES_OF(WP) (3 * SM_M * (8 + 4 + 4 + 4) + SM_K * ((WP) ? SM_T / 64 : SM_T) * 8)
-#define SM_LDS_BYTES SM_LDS_BYTES_OF(0)
-static_assert(SM_LDS_BYTES_OF(0) + 8 * (SM_MAXS + 1) + 1024 <= 160 * 1024, "k_smooth_batch: tile + snapshots exceed the 160 KiB of LDS a gfx950 workgroup can own");
+#define SMF_K 32             /* filter half-width: r^33 = 5e-19 */
+#define SMF_END 72           /* r^72 = 1e-40: beyond that many waypoints an end's homogeneous term is exactly absorbed */
+#define SMF_M (SMF_T + 2 * SMF_K)
+__host__ __device__ inline int smooth_tiles(int W) { return W > 0 ? (W + SMF_T - 1) / SMF_T : 1; }
 
-__host__ __device__ inline int smooth_tiles(int W) { return W > 2 ? (W - 2 + SM_OWN - 1) / SM_OWN : 1; }
-/* snapshot set q (0/1), level k (1..SM_K), coordinate j: float[W_cap] */
-__host__ __device__ inline size_t smooth_snap_off(int q, int k, int j, int W_cap)
+/* p of the fixed end `e` (0 or W-1): only the interior neighbours on its one side contribute */
+__device__ inline double smooth_end_p(const float *__restrict__ wp_pre, int W, int e, int j, double r, double c)
 {
-    return ((size_t)(q * SM_K + (k - 1)) * 3 + j) * (size_t)W_cap;
+    const int dir = e == 0 ? 1 : -1;
+    double acc = 0.0;
+    for (int k = SMF_K; k >= 1; --k) {
+        const int g = e + dir * k;
+        const double x = (g >= 1 && g <= W - 2) ? (double)wp_pre[6 * (size_t)g + j] : 0.0;
+        acc = x + r * acc;
+    }
+    return c * (r * acc);
 }
 
-/* WP = false: every thread parks its |delta| sum of every sweep in LDS and the sums are reduced once per launch -- the
-   fastest sweep, but 64 KB of LDS: one workgroup per CU.  WP = true: a shuffle tree per sweep leaves one partial per
-   wave -- 0.3 us more per sweep, but 32 KB: lists with more tiles than the GPU has CUs run two to four tiles per CU
-   (10 M points: 112 -> 86 us).  The host picks by the tile count. */
-template <bool WP>
-__global__ void __launch_bounds__(SM_T) k_smooth_batch(DevMeta *m, DevParams P, int b, int ntiles_cap, int W_cap,
-                                                       const float *__restrict__ sx, float *snap, double *part, double *chist,
-                                                       const float *__restrict__ wp_pre, float *wp_smooth, float *wp_out,
-                                                       const int *__restrict__ tail, float *dst2, int cap2)
+__global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
+                                                        float *wp_smooth, float *wp_out, const int *__restrict__ tail,
+                                                        float *dst2, int cap2)
 {
-    extern __shared__ __attribute__((aligned(16))) char s_raw[];
-    double (*s_c)[SM_M] = (double (*)[SM_M])s_raw;
-    float (*s_x)[SM_M] = (float (*)[SM_M])(s_raw + 3 * SM_M * 8);
-    float (*s_a)[SM_M] = s_x + 3;
-    float (*s_b)[SM_M] = s_a + 3;
-    constexpr int CHW = WP ? SM_T / 64 : SM_T;
-    double (*s_chg)[CHW] = (double (*)[CHW])(s_b + 3); /* per-thread (or per-wave) |delta| sums of every sweep of the batch */
-    __shared__ double s_change[SM_MAXS + 1];
-    __shared__ int s_kstar;
+    __shared__ float s_x[3][SMF_M];
+    __shared__ int s_tail[4096];
+    __shared__ int s_last;
     const int W = m->W;
     if (m->err || W == 0) return;
-    if (m->smooth_done >= 0 && m->smooth_done < b) return; /* an earlier launch emitted the list */
-    const int inner = W - 2;
     const int ntiles = smooth_tiles(W);
     const int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    const double weight_data = 0.65, weight_smooth = 1 - weight_data, tolerance = 0.00001;
-    const int t0 = 1 + tile * SM_OWN;
-    const int t1 = min(W - 1, t0 + SM_OWN);
-    const int w0 = tile == 0 ? 0 : t0, w1 = (t1 == W - 1 || W <= 2) ? W : t1; /* border tiles carry the fixed ends */
-
-    /* ---- emit or continue?  (identical decision in every workgroup) ---- */
-    int emit_level = -1; /* >= 0: emit; 0 = the unsmoothed list */
-    int total_sweeps = 0;
-    if (!P.smooth || inner <= 0) {
-        if (b != 0) return;
-        emit_level = 0; total_sweeps = P.smooth ? 1 : 0;
-    } else if (b > 0) {
-        /* change[k] of the sweeps before the last batch was summed by the previous launch
-           (chist); the last batch's SM_K sweeps are summed here, all threads in parallel,
-           always in the same order (deterministic). */
-        const int done = SM_K * b, first_new = SM_K * (b - 1) + 1;
-        for (int k = 1 + threadIdx.x; k < first_new; k += blockDim.x) s_change[k] = chist[k];
-        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int k = first_new + wid; k <= done; k += nw) { /* one wave per sweep */
-            const double *pp = part + (size_t)k * ntiles_cap;
-            double c = 0;
-            for (int q = lane; q < ntiles; q += 64) c += pp[q];
-            c = wave_sum(c);
-            if (lane == 0) s_change[k] = c;
-        }
-        __syncthreads();
-        if (tile == 0) for (int k = first_new + threadIdx.x; k <= done; k += blockDim.x) chist[k] = s_change[k];
-        if (threadIdx.x == 0) {
-            int ks = 0;
-            for (int k = 1; k <= done && !ks; ++k) {
-                double c = s_change[k];
-                bool stop = !(c >= tolerance);
-                if (k >= 2 && c >= 0.9 * s_change[k - 1]) stop = true;
-                if (k >= P.smooth_max_sweeps) stop = true;
-                if (stop) ks = k;
-            }
-            s_kstar = ks;
-        }
-        __syncthreads();
-        if (s_kstar) { emit_level = s_kstar - SM_K * (b - 1); total_sweeps = s_kstar; }
+    /* weight_data = 0.65, weight_smooth = 1 - weight_data (path_translation_alg.cpp:118): r = 0.27951480..., c = 0.56309250... */
+    const double wd = 0.65, ws = 1 - wd, dg = wd + 2 * ws;
+    const double r = (dg - sqrt(dg * dg - 4 * ws * ws)) / (2 * ws), c = wd / (dg - 2 * ws * r);
+    const int t0 = tile * SMF_T;
+    const int base = t0 - SMF_K; /* LDS slot l <-> list index base + l */
+    const bool solve = P.smooth && W > 2;
+    /* tile + halo; the sources are the INTERIOR waypoints: the two fixed ends enter through A and B */
+    for (int l = threadIdx.x; l < SMF_M; l += blockDim.x) {
+        const int g = base + l;
+        const bool src = g >= 1 && g <= W - 2;
+        for (int j = 0; j < 3; ++j) s_x[j][l] = src ? wp_pre[6 * (size_t)g + j] : 0.f;
     }
-    if (emit_level >= 0) {
-        /* The emitting launch also finishes the list (a14 reduceRPY, a15 flange offset) and, in the batched form, writes
-           it to its place in the caller's buffer: both are per-waypoint work on what this tile has in hand -- the
-           smoothed xyz and the computed rpy -- so the pass ends here, without a finishing launch. */
-        const float *S0 = emit_level == 0 ? sx : snap + smooth_snap_off((b - 1) & 1, emit_level, 0, W_cap);
-        const float *S1 = emit_level == 0 ? sx + (size_t)W : snap + smooth_snap_off((b - 1) & 1, emit_level, 1, W_cap);
-        const float *S2 = emit_level == 0 ? sx + 2 * (size_t)W : snap + smooth_snap_off((b - 1) & 1, emit_level, 2, W_cap);
-        const bool in_order = P.rpy_resolution > 2 && m->any_short; /* App. B.6: overlapping segments, finished by one thread below */
-        const bool copy2 = dst2 != nullptr && W <= cap2;
-        if (dst2 != nullptr && W > cap2 && tile == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
-        /* TailIndex in LDS: every waypoint's segment search is then eight LDS reads instead of eight dependent trips to L2 */
-        const int *tl = tail;
-        if (!in_order && P.rpy_resolution > 2 && m->nkept <= 4096) {
-            int *s_tail = (int *)s_raw;
-            for (int i = threadIdx.x; i < m->nkept; i += blockDim.x) s_tail[i] = tail[i];
-            __syncthreads();
-            tl = s_tail;
-        }
-        for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) {
-            float p[6];
-            p[0] = S0[g]; p[1] = S1[g]; p[2] = S2[g];
-            for (int d = 3; d < 6; ++d) p[d] = wp_pre[6 * (size_t)g + d];
-            for (int d = 0; d < 6; ++d) wp_smooth[6 * (size_t)g + d] = p[d];
-            if (!in_order) finish_one_waypoint(m, P, tl, wp_pre, g, p);
-            for (int d = 0; d < 6; ++d) wp_out[6 * (size_t)g + d] = p[d];
-            if (copy2 && !in_order) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)g + d] = p[d];
-        }
-        if (in_order) { /* the last tile to arrive finishes the whole list */
-            __shared__ int s_last;
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) s_last = atomicAdd(&m->emit_ticket, 1) == ntiles - 1;
-            __syncthreads();
-            if (s_last) {
-                __threadfence();
-                if (threadIdx.x == 0) { finish_list_in_order(m, P, tail, wp_out); m->emit_ticket = 0; }
-                __threadfence();
-                __syncthreads();
-                if (copy2) for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = wp_out[i];
-            }
-        }
-        if (tile == 0 && threadIdx.x == 0) { m->sweeps = total_sweeps; m->smooth_done = b; }
-        return;
-    }
-
-    /* ---- SM_K more sweeps from the state after SM_K*b sweeps ---- */
-    STAMP_BEGIN();
-    const int base = t0 - SM_HB; /* LDS slot l <-> list index base + l */
-    for (int j = 0; j < 3; ++j) {
-        const float *X = sx + (size_t)j * W;
-        const float *S = b == 0 ? X : snap + smooth_snap_off((b - 1) & 1, SM_K, j, W_cap);
-        for (int l = threadIdx.x; l < SM_M; l += blockDim.x) {
-            int g = base + l;
-            float xv = 0.f, yv = 0.f;
-            if (g >= 0 && g < W) { xv = X[g]; yv = S[g]; }
-            s_x[j][l] = xv; s_a[j][l] = yv; s_b[j][l] = yv;
-        }
+    const bool in_order = P.rpy_resolution > 2 && m->any_short; /* App. B.6: overlapping segments, finished by one thread below */
+    const bool copy2 = dst2 != nullptr && W <= cap2;
+    if (dst2 != nullptr && W > cap2 && tile == 0 && threadIdx.x == 0) set_err(m, DERR_CAPACITY, -1);
+    /* TailIndex in LDS: every waypoint's segment search is then eight LDS reads instead of eight dependent trips to L2 */
+    const int *tl = tail;
+    if (!in_order && P.rpy_resolution > 2 && m->nkept <= 4096) {
+        for (int i = threadIdx.x; i < m->nkept; i += blockDim.x) s_tail[i] = tail[i];
+        tl = s_tail;
     }
     __syncthreads();
-    STAMP(6, 0); /* tile load */
-    float (*cur)[SM_M] = s_a, (*nxt)[SM_M] = s_b;
-    const int l0 = threadIdx.x * SM_L; /* this thread's LDS slots l0 .. l0+SM_L-1 */
-    for (int k = 1; k <= SM_K; ++k) {
-        /* level k is exact on [lo_k, hi_k); the fixed end points 0 and W-1 are exact on every level */
-        const int lo_k = max(1, base + 1 + (SM_D + 1) * k), lo_km1 = max(1, base + 1 + (SM_D + 1) * (k - 1));
-        const int hi_k = min(W - 1, base + SM_M - k);
-        /* c_i from level k-1, for every slot whose neighbours exist */
+    const int g = t0 + threadIdx.x;
+    if (g < W) {
+        float p[6];
+        for (int d = 0; d < 6; ++d) p[d] = wp_pre[6 * (size_t)g + d];
+        if (solve) {
+            const int l = g - base;
+            double y[3];
 #pragma unroll
-        for (int q = 0; q < SM_L; ++q) {
-            const int l = l0 + q, i = base + l;
-            if (i >= lo_km1 && i < hi_k) {
+            for (int j = 0; j < 3; ++j) {
+                double acc = (double)s_x[j][l - SMF_K] + (double)s_x[j][l + SMF_K];
+#pragma unroll 8
+                for (int k = SMF_K - 1; k >= 1; --k) acc = ((double)s_x[j][l - k] + (double)s_x[j][l + k]) + r * acc;
+                y[j] = c * ((double)s_x[j][l] + r * acc);
+            }
+            const bool near0 = g <= SMF_END, near1 = (W - 1 - g) <= SMF_END;
+            if (near0 || near1) {
+                double D = 0.0; /* r^(W-1): couples the two ends of a short list */
+                if (W - 1 <= 2 * SMF_END + 16) { D = 1.0; for (int q = 0; q < W - 1; ++q) D *= r; }
+                double r0 = 0.0, r1 = 0.0; /* r^g, r^(W-1-g) */
+                if (near0 || D != 0.0) { r0 = 1.0; for (int q = 0; q < g; ++q) r0 *= r; }
+                if (near1 || D != 0.0) { r1 = 1.0; for (int q = 0; q < W - 1 - g; ++q) r1 *= r; }
+                const double det = 1.0 - D * D;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    double x_i = (double)s_x[j][l], y_i = (double)cur[j][l], y_next = (double)cur[j][l + 1];
-                    s_c[j][l] = y_i + (weight_data * (x_i - y_i) + weight_smooth * (y_next - 2 * y_i));
+                    const double e0 = (double)wp_pre[j] - smooth_end_p(wp_pre, W, 0, j, r, c);
+                    const double e1 = (double)wp_pre[6 * (size_t)(W - 1) + j] - smooth_end_p(wp_pre, W, W - 1, j, r, c);
+                    const double A = (e0 - D * e1) / det, B = (e1 - D * e0) / det;
+                    y[j] = y[j] + (A * r0 + B * r1);
                 }
             }
+            if (g >= 1 && g <= W - 2) { p[0] = (float)y[0]; p[1] = (float)y[1]; p[2] = (float)y[2]; } /* the ends stay what they are */
         }
-        lds_barrier();
-        STAMP(6, 1); /* c_i */
-        const int a = max(base + l0, lo_k), e = min(base + l0 + SM_L, hi_k);
-        double change = 0;
-        if (a < e) {
-            const int rs = max(a - SM_D, lo_km1);
-            double acc[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[j] = (double)cur[j][rs - 1 - base];
-            for (int i = rs; i < a; ++i) { /* (hoisting the reads -- all of them, or four steps at a time -- measured no faster) */
-                const int l = i - base;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[j] = s_c[j][l] + weight_smooth * acc[j];
-            }
-            for (int i = a; i < e; ++i) {
-                const int l = i - base;
-                const bool owned = i >= t0 && i < t1;
-                /* all six LDS operands first, then the arithmetic; `owned` selects instead of branching (the compiler
-                   otherwise emits three guarded read-wait sequences) */
-                const double c0 = s_c[0][l], c1 = s_c[1][l], c2 = s_c[2][l];
-                const float y0 = cur[0][l], y1 = cur[1][l], y2 = cur[2][l];
-                acc[0] = c0 + weight_smooth * acc[0];
-                acc[1] = c1 + weight_smooth * acc[1];
-                acc[2] = c2 + weight_smooth * acc[2];
-                nxt[0][l] = (float)acc[0]; nxt[1][l] = (float)acc[1]; nxt[2][l] = (float)acc[2];
-                const double d0 = fabs(acc[0] - (double)y0), d1 = fabs(acc[1] - (double)y1), d2 = fabs(acc[2] - (double)y2);
-                change += owned ? d0 : 0.0;
-                change += owned ? d1 : 0.0;
-                change += owned ? d2 : 0.0;
-            }
-        }
-        /* one partial per wave and sweep (a shuffle tree, no barrier; a block-wide reduction per sweep cost more than
-           the sweep itself, and one partial per THREAD made the tile too large for a second workgroup on the CU) */
-        if (WP) {
-            change = wave_sum(change);
-            if ((threadIdx.x & 63) == 0) s_chg[k - 1][threadIdx.x >> 6] = change;
-        } else s_chg[k - 1][threadIdx.x] = change;
-        lds_barrier(); /* publishes nxt; the snapshot stores below stay in flight */
-        STAMP(6, 2); /* run-up + own element */
-        float (*t)[SM_M] = cur; cur = nxt; nxt = t;
-        /* snapshot of level k (owned range; the last level is the next launch's input) */
-        for (int j = 0; j < 3; ++j) {
-            float *D = snap + smooth_snap_off(b & 1, k, j, W_cap);
-            for (int g = w0 + threadIdx.x; g < w1; g += blockDim.x) D[g] = cur[j][g - base];
-        }
-        STAMP(6, 3); /* snapshot stores */
+        for (int d = 0; d < 6; ++d) wp_smooth[6 * (size_t)g + d] = p[d];
+        if (!in_order) finish_one_waypoint(m, P, tl, wp_pre, g, p);
+        for (int d = 0; d < 6; ++d) wp_out[6 * (size_t)g + d] = p[d];
+        if (copy2 && !in_order) for (int d = 0; d < 6; ++d) dst2[6 * (size_t)g + d] = p[d];
     }
-    /* per-sweep sums of this tile, fixed summation order: one wave per sweep */
-    {
-        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        if (WP) {
-            for (int k = 1 + (int)threadIdx.x; k <= SM_K; k += blockDim.x) { /* the waves' partials in wave order */
-                double c = 0;
-                for (int w = 0; w < CHW; ++w) c += s_chg[k - 1][w];
-                part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
-            }
-        } else {
-            for (int k = 1 + wid; k <= SM_K; k += nw) { /* one wave per sweep */
-                double c = 0;
-                for (int q = lane; q < CHW; q += 64) c += s_chg[k - 1][q];
-                c = wave_sum(c);
-                if (lane == 0) part[(size_t)(SM_K * b + k) * ntiles_cap + tile] = c;
-            }
+    if (in_order) { /* the last tile to arrive finishes the whole list */
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&m->emit_ticket, 1) == ntiles - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (threadIdx.x == 0) { finish_list_in_order(m, P, tail, wp_out); m->emit_ticket = 0; }
+            __threadfence();
+            __syncthreads();
+            if (copy2) for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = wp_out[i];
         }
     }
-    STAMP(6, 4); /* per-sweep sums */
+    if (tile == 0 && threadIdx.x == 0) { m->sweeps = 0; m->smooth_done = 0; }
 }
-

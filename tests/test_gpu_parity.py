@@ -49,8 +49,9 @@ def assert_full_parity(engine_mod, e, o, every_slice=True, unit=1.0):
     pre, opre = e.stage(engine_mod.STAGE_WP_PRESMOOTH), o.waypoints_presmooth()
     assert np.abs(pre[:, :3] - opre[:, :3]).max() <= 1e-6 * unit
     sm, osm = e.stage(engine_mod.STAGE_WP_SMOOTHED), o.waypoints_smoothed()
-    assert np.abs(sm[:, :3] - osm[:, :3]).max() <= 1e-6 * unit  # filter form of the sweep: ~1e-7 m (ppp_kernels.h a13)
-    assert abs(e.smooth_sweeps() - o.smooth_sweeps()) <= 1
+    # the GPU solves the sweeps' fixed point directly (ppp_kernels.h a13); the oracle sweeps sequentially in float until the
+    # list is stationary: they differ by the float storage floor (1.2e-7 m typical, 6e-7 m on 3..5-waypoint lists)
+    assert np.abs(sm[:, :3] - osm[:, :3]).max() <= 1e-6 * unit
     wp, owp = e.waypoints(), o.waypoints()
     assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M * unit
     d = np.abs(wp[:, 3:] - owp[:, 3:])

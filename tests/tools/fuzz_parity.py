@@ -94,9 +94,8 @@ def one_case_hard(rng, i, only=None, verbose=False, big=None):
         kw["path_resolution"] = float(rng2.choice([0.5, 1.0, 2.5, 11.0, 30.0]))
         kw["rpy_resolution"] = float(rng2.choice([0.0, 1.0, 2.0, 2.5, 3.0, 15.0]))
         kw["trim"] = float(rng2.choice([0.0, 1.0, 5.0, 10.0, 20.0]))
-        kw["smooth_max_sweeps"] = int(rng2.choice([1, 2, 16, 17, 32, 33, 64]))
-        desc = "odd R %.1f res %.1f rpy %.1f trim %.0f sweeps %d | " % (kw["tool_radius"], kw["path_resolution"], kw["rpy_resolution"], kw["trim"],
-                                                                      kw["smooth_max_sweeps"])
+        rng2.choice([1, 2, 16, 17, 32, 33, 64])         # (was the sweep cap of the iterative smoother; drawn to keep the other cases' streams)
+        desc = "odd R %.1f res %.1f rpy %.1f trim %.0f | " % (kw["tool_radius"], kw["path_resolution"], kw["rpy_resolution"], kw["trim"])
     else:
         desc = ""
     unit = 1.0
