@@ -52,14 +52,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2_1m_s256")
+    ap.add_argument("--config", default=None,
+                    help="workload (polishpathplanning_amd.synth.CONFIGS); default: cfg2_1m_s256 on one GPU (BASELINE configs[1]), "
+                         "cfg4_2m_s256 per GPU for --gpus N > 1 (configs[3]), cfg5_10m_s1024 for --mode slices (configs[4])")
     ap.add_argument("--batch", type=int, default=1,
                     help="workpieces per GPU per step, one engine handle (= one HIP stream) each (BASELINE config 3)")
     ap.add_argument("--mode", choices=["workpieces", "slices"], default="workpieces",
                     help="N > 1: one workpiece per GPU (weak scaling, default) or the slice ranges of ONE cloud (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=20)
+    ap.add_argument("--rotate", type=int, default=None,
+                    help="also report the step time over K distinct resident clouds planned round-robin (K x working set beyond "
+                         "the 256 MiB Infinity Cache) and the cold time of a never-seen cloud; 0 = off, the default run uses 8")
     args = ap.parse_args()
+    if args.rotate is None:
+        args.rotate = 8 if (args.gpus == 1 and args.batch == 1) else 0
+    if args.config is None:
+        args.config = "cfg5_10m_s1024" if (args.mode == "slices" and args.gpus > 1) else ("cfg4_2m_s256" if args.gpus > 1 else "cfg2_1m_s256")
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything touches the GPU (a
+    # process that has initialised HIP must never exec or fork GPU children), relay rank 0's JSON line and exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -71,6 +92,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("PPP_BENCH_ECHO_RANK") == "1":
+        print("bench.py rank %d of %d: %s, mode %s" % (rank, world, args.config, args.mode), file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -88,8 +111,12 @@ def main():
     # ---- synthetic workpiece of this rank (untimed: generation + H2D) ----
     base_seed = sorted(synth.CONFIGS).index(args.config) + 1
     engines, clouds = [], []
+    amp_rng = np.random.default_rng(base_seed + 1000 * rank)
     for bi in range(args.batch):
-        pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank + 17 * bi)
+        over = {}
+        if args.batch > 1:   # every workpiece of a batch has its own seed and surface amplitude
+            over["amp"] = float(synth.CONFIGS[args.config]["amp"] * amp_rng.uniform(0.5, 1.5))
+        pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank + 17 * bi, **over)
         e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
         e.set_cloud(pts)
         engines.append(e)
@@ -180,9 +207,13 @@ def main():
         eng.enable_timing(True)
         acc, launches = {}, {}
         for _ in range(args.profile_passes):
-            eng.gen_path_async()
-            eng.get_path_async()
-            eng.sync()
+            if args.batch > 1:      # the batched launches (one per stage over all members), eagerly, events on the lead's stream
+                engine.run_batch_async(engines, gatherers[0].send.data_ptr(), offs, w_all)
+                engine.sync_batch(engines)
+            else:
+                eng.gen_path_async()
+                eng.get_path_async()
+                eng.sync()
             kt, kl = eng.kernel_times(with_launches=True)
             for k, v in kt.items():
                 acc.setdefault(k, []).append(v)
@@ -190,20 +221,27 @@ def main():
         eng.enable_timing(False)
         kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}  # per pass, summed over that kernel's launches
         dom = max(kern_ms, key=kern_ms.get)
-        w_one = float(w_all[0])
-        alg_bytes = 12.0 * n_points + 24.0 * w_one  # SURVEY.md 8(d), per workpiece: xyz read once + waypoints written once
+        # 12 B per point read once + 24 B per waypoint written once; one launch processes the whole batch
+        alg_bytes = 12.0 * float(sum(int(c.shape[0]) for c in clouds)) + 24.0 * float(sum(w_all))
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
-        traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), args.config)
+        workload_key = args.config + ("_b%d" % args.batch if args.batch > 1 else "")
+        traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), workload_key)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_pass": launches.get(dom, 1),
                     "avg_launch_ms": kern_ms[dom] / max(1, launches.get(dom, 1)),
-                    "note": "one pass = one workpiece; kernel_ms are per pass (summed over a kernel's launches). "
-                            "12.6 MB of algorithmic traffic is 2 us at the HBM roof: this workload is launch/latency bound",
+                    "note": "one pass = one launch of every stage over the %d workpiece(s) of a step; kernel_ms are per pass (summed "
+                            "over a kernel's launches); algorithmic_bytes = 12 B x points + 24 B x waypoints of the step" % args.batch,
                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
                     "algorithmic_bytes": alg_bytes,
-                    "pipeline_gbs": alg_bytes * args.batch / (elapsed / args.steps) / 1e9}
+                    "pipeline_gbs": alg_bytes / (elapsed / args.steps) / 1e9}
+
+        # ---- what a stream of NEW workpieces sees: the replay above plans one resident cloud whose working
+        # set sits in the 256 MiB Infinity Cache, with its slab grid and buffers prepared by set_cloud ----
+        latency = None
+        if world == 1 and args.batch == 1 and args.rotate > 0:
+            latency = measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, eng, pts, local_rank)
 
         # ---- CPU baseline: the oracle in reference-complexity mode on the node's host cores ----
         cpu = None
@@ -263,12 +301,67 @@ def main():
             "cpu_baseline": cpu,
             "path_l2_err": err,
             "assembled_path": assembled,
+            "latency": latency,
+            "exchange": ("torch.distributed gather to rank 0 over RCCL (direct send/recv of padded blocks), asynchronous behind each "
+                         "step in the planner's stream order" if gatherers[0].dist else None),
         }
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, eng, pts, local_rank):
+    """K distinct resident clouds planned round-robin (K x ~45 MB at cfg 2: beyond the Infinity Cache) against the same
+    loop on ONE cloud, both with a host wait per step (the clouds live on different handles = different streams); and the
+    cold path of a never-seen cloud: ppp_set_cloud_device (ingest, bounds, plan) + the first ppp_run_async (graph capture
+    and instantiation included) + the wait for the list, cloud already in device memory."""
+    K = args.rotate
+    steps = max(args.steps, 2 * K)
+    others = []
+    for k in range(1, K):
+        p2, _ = synth.make_config(args.config, seed=base_seed + 7919 * k)
+        e2 = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+        e2.set_cloud(p2)
+        e2.run_async(); e2.sync()
+        others.append(e2)
+    ring = [eng] + others
+
+    def loop(engs, count):
+        t = time.perf_counter()
+        for k in range(count):
+            e = engs[k % len(engs)]
+            e.run_async()
+            e.sync()
+        return (time.perf_counter() - t) / count * 1e3
+
+    eng.run_async(); eng.sync()
+    loop([eng], 5); one = min(loop([eng], steps) for _ in range(3))
+    loop(ring, K); rot = min(loop(ring, steps) for _ in range(3))
+    for e2 in others:
+        e2.close()
+    # cold: new clouds of the same size into one handle
+    cold = []
+    ec = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+    for k in range(4):
+        p2, _ = synth.make_config(args.config, seed=base_seed + 104729 * (k + 1))
+        d = torch.from_numpy(np.ascontiguousarray(p2)).to(dev)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ec.set_cloud_device(d.data_ptr(), int(p2.shape[0]), 12)
+        t1 = time.perf_counter()
+        ec.run_async()
+        ec.sync()
+        t2 = time.perf_counter()
+        cold.append(((t2 - t) * 1e3, (t1 - t) * 1e3, (t2 - t1) * 1e3))
+        del d
+    ec.close()
+    return {"replay_one_cloud_hostwait_ms": one, "rotate_clouds": K, "rotate_hostwait_ms": rot,
+            "cold_first_ms": cold[0][0], "cold_ms": min(c[0] for c in cold[1:]),
+            "cold_split_ms": {"set_cloud_device": min(c[1] for c in cold[1:]), "first_run_async_and_wait": min(c[2] for c in cold[1:])},
+            "note": "host wait after every step in both loops; cold = set_cloud_device + first run_async + wait on a never-seen cloud "
+                    "already in device memory (cold_first also pays the handle's buffer allocations)"}
 
 
 def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth):
@@ -300,6 +393,7 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
     w_ranks = exchange_counts(w_local, dist, dev)
     W = int(counts_all.sum())
     send = torch.zeros((max(w_local, 1), 6), dtype=torch.float32, device=dev)
+    planner_stream = torch.cuda.ExternalStream(eng.stream_ptr(), device=dev) if eng is not None else None
 
     def step():
         w = 0
@@ -309,10 +403,12 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
         blocks = gather_robot_path(send[:w], dist, dev, w_ranks)
         if rank == 0:
             pre = torch.cat(blocks, dim=0).contiguous()
+            # the gather and the cat run on the framework's stream, the planner on its own: order them on the GPU
+            planner_stream.wait_stream(torch.cuda.current_stream())
             eng.finish_path_async(pre.data_ptr(), pre.shape[0], counts_all)   # a13..a15 once, over the whole list
             eng.sync()
-            return pre.shape[0]
-        return 0
+            return pre
+        return None
 
     def fence():
         dist.barrier()
@@ -331,7 +427,12 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
     elapsed = float(tt.item())
     out = None
     if rank == 0:
-        assert got == W
+        assert got.shape[0] == W
+        # untimed check of the last step: the list finished from the gathered blocks is the unsharded handle's list
+        whole = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+        whole.set_cloud(pts); whole.gen_path(); whole.get_path()
+        sharded_equals_whole = bool(np.array_equal(eng.waypoints(), whole.waypoints()))
+        whole.close()
         n_points = int(pts.shape[0])
         alg_bytes = 12.0 * n_points + 24.0 * W
         out = {
@@ -346,6 +447,7 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
                          "frac": alg_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole pipeline, every rank reads the whole cloud once (k_minmax) and indexes its own x interval"},
             "cpu_baseline": None,
+            "assembled_path": {"sharded_list_equals_unsharded_handle": sharded_equals_whole, "rows": W},
         }
         print(json.dumps(out), flush=True)
     dist.barrier()

@@ -36,6 +36,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -127,6 +128,12 @@ struct ppp_handle_s {
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
     float *out2 = nullptr;          /* batched form: the emitting launch also writes the list here (at most out2_cap rows) */
     int out2_cap = 0;
+    float *last_out2 = nullptr;     /* where the last batch put this handle's list: a re-run after an LDS overflow writes there too */
+    int last_out2_cap = 0;
+    std::shared_ptr<struct BatchMetas> bmetas; /* batched launches publish every member's meta block in one pinned array ... */
+    size_t bslot = 0;                          /* ... this handle's is entry bslot */
+    bool meta_from_batch = false;
+    int internal = 0;               /* > 0 while GenPath / getPath are enqueued on behalf of a batch or a re-run (keeps last_out2) */
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
@@ -164,6 +171,11 @@ struct ppp_handle_s {
     }
 };
 
+/* the meta blocks of a batch on the host (pinned), shared by the batch graph and the member handles that read them */
+struct BatchMetas {
+    DevMeta *pinned = nullptr;
+    ~BatchMetas() { if (pinned) (void)hipHostFree(pinned); }
+};
 struct BatchGraph {
     std::vector<ppp_handle> hs;
     std::vector<unsigned> epochs;
@@ -173,12 +185,21 @@ struct BatchGraph {
     hipGraphExec_t ge = nullptr;
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
+    /* batched form (one launch per stage over all members): the members' records and meta blocks */
+    bool batched = false, eager = false; /* eager: launched directly every time (kernel timing), no graph */
+    int maxB = 1, max_slab_cap = 2048, max_capb = 1024; /* launch geometry over all members */
+    int gx_mm = 1, gx_scat = 1, gx_sort = 1, gx_slice = 1, gx_pose = 1, gx_smooth = 1;
+    bool full_slabs = false, ppt8 = false;
+    DevBuf<BatchMember> members;
+    DevBuf<DevMeta> metas;
+    std::shared_ptr<BatchMetas> hmetas;
     ~BatchGraph()
     {
         if (ge) (void)hipGraphExecDestroy(ge);
         if (g) (void)hipGraphDestroy(g);
         if (fork) (void)hipEventDestroy(fork);
         for (auto e : join) if (e) (void)hipEventDestroy(e);
+        members.release(); metas.release();
     }
 };
 void ppp_handle_s::drop_batch()
@@ -529,7 +550,7 @@ int fetch_meta(ppp_handle h)
     { int rc = settle(h); if (rc) return rc; }
     if (h->meta_in_flight) { /* GenPath / getPath already enqueued the copy behind their last kernel */
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->hmeta = *h->hmeta_pinned;
+        h->hmeta = (h->meta_from_batch && h->bmetas) ? h->bmetas->pinned[h->bslot] : *h->hmeta_pinned;
         h->meta_in_flight = false;
         return PPP_OK;
     }
@@ -542,6 +563,7 @@ int enqueue_meta_copy(ppp_handle h)
 {
     HIPCHK(h, hipMemcpyAsync(h->hmeta_pinned, h->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, h->stream));
     h->meta_in_flight = true;
+    h->meta_from_batch = false;
     return PPP_OK;
 }
 
@@ -572,8 +594,13 @@ int rerun_with_arena(ppp_handle h)
     h->big_path = true;
     h->drop_graph();
     HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max<size_t>(h->n, 1) + (1u << 20)));
+    ++h->internal;
     int rc = ppp_gen_path_async(h);
+    /* a member of a batch: the re-planned list must land where the batch put the first one (the caller's gather buffer) */
+    h->out2 = h->last_out2; h->out2_cap = h->last_out2_cap;
     if (rc == PPP_OK && had_path) rc = ppp_get_path_async(h);
+    h->out2 = nullptr; h->out2_cap = 0;
+    --h->internal;
     if (rc) return rc;
     return fetch_meta(h);
 }
@@ -708,6 +735,11 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_minmax_b, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_pose_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -1130,6 +1162,7 @@ int ppp_gen_path_async(ppp_handle h)
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (!h->internal) { h->last_out2 = nullptr; h->last_out2_cap = 0; } /* a plain call: the list stays in the handle */
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
     int rc = enqueue_index(h);
@@ -1235,6 +1268,7 @@ int ppp_run_async(ppp_handle h)
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    h->last_out2 = nullptr; h->last_out2_cap = 0;
     if (h->timing) {
         int rc = ppp_gen_path_async(h);
         return rc ? rc : ppp_get_path_async(h);
@@ -1242,9 +1276,11 @@ int ppp_run_async(ppp_handle h)
     if (!h->graph_exec) {
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         h->chain_calls = true;
+        ++h->internal;
         int rc = ppp_gen_path_async(h);
         h->chain_calls = false;
         if (rc == PPP_OK) rc = ppp_get_path_async(h);
+        --h->internal;
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(h->stream, &g);
         if (rc != PPP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -1257,8 +1293,106 @@ int ppp_run_async(ppp_handle h)
     h->index_built = true; h->gen_done = true; h->path_done = true;
     h->list_final = !h->ranged;
     h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
+    h->meta_from_batch = false;
     return PPP_OK;
 }
+
+extern "C++" {
+namespace {
+
+/* can this handle's pass run as rows of the batched launches?  (kd pairing on the LDS fast path, whole cloud, one-level
+   scatter; anything else -- dynamic adjustment, alignment, slice ranges, arena passes -- keeps its own launch sequence) */
+bool batch_eligible(const ppp_handle h)
+{
+    return h->P.pairing == PPP_PAIR_KD && !h->P.dynamic_adjustment && !h->aligned && !h->ranged && !h->big_path && !h->two_pass_scatter &&
+           slice_lds_ok(h, h->capb);
+}
+
+#define LAUNCHB(lead, name, kern, grid, block, shmem, ...)                                            \
+    do {                                                                                              \
+        KTimer *_t = (lead)->timing ? timer_for((lead), name) : nullptr;                              \
+        if (_t) (void)hipEventRecord(_t->e0[_t->used], (lead)->stream);                               \
+        (void)hipGetLastError();                                                                      \
+        hipLaunchKernelGGL(kern, grid, dim3(block), (shmem), (lead)->stream, __VA_ARGS__);            \
+        if (_t) { (void)hipEventRecord(_t->e1[_t->used], (lead)->stream); _t->used++; }               \
+        hipError_t _le = hipGetLastError();                                                           \
+        if (_le != hipSuccess) return fail((lead), PPP_ERR_HIP, std::string(name) + ": " + hipGetErrorString(_le)); \
+    } while (0)
+
+/* the members' records (host -> device, synchronous, outside any capture) and the launch geometry of the batch */
+int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows)
+{
+    const size_t count = bg->hs.size();
+    std::vector<BatchMember> mem(count);
+    int &maxB = bg->maxB, &max_slab_cap = bg->max_slab_cap, &max_capb = bg->max_capb;
+    int &gx_mm = bg->gx_mm, &gx_scat = bg->gx_scat, &gx_sort = bg->gx_sort, &gx_slice = bg->gx_slice, &gx_pose = bg->gx_pose, &gx_smooth = bg->gx_smooth;
+    bool &full_slabs = bg->full_slabs, &ppt8 = bg->ppt8;
+    int max_n = 0;
+    for (size_t i = 0; i < count; ++i) max_n = std::max(max_n, (int)bg->hs[i]->n);
+    ppt8 = max_n > PPP_PPT8_FROM;
+    const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
+    /* the bounds + histogram pass: about 2048 workgroups over the whole batch (each flushes its LDS histogram with one
+       atomic per non-empty slab) */
+    const int mm_share = std::max(4, (int)(2048 / count));
+    for (size_t i = 0; i < count; ++i) {
+        ppp_handle h = bg->hs[i];
+        BatchMember &M = mem[i];
+        memset(&M, 0, sizeof(M));
+        M.m = h->meta.p; M.P = dev_params(h);
+        M.X = h->X.p; M.Y = h->Y.p; M.Z = h->Z.p; M.n = (int)h->n;
+        M.mm_part = h->mm_part.p;
+        const float xr = h->h_mx[0] - h->h_mn[0];
+        M.slab_x0 = h->h_mn[0]; M.slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f; /* as enqueue_index */
+        M.incl_lo = h->incl_lo; M.incl_hi = h->incl_hi;
+        M.B = h->B; M.S_cap = h->S_cap; M.slab_cap = h->slab_cap; M.capb = h->capb; M.node_cap = h->node_cap; M.W_cap = h->W_cap;
+        M.out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
+        M.out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
+        M.g_minmax = std::max(1, std::min(std::min(h->mm_grid, PPP_MM_GRID_MAX), mm_share));
+        M.g_scatter = std::max(1, ((int)h->n + chunk - 1) / chunk);
+        M.g_sort = h->B; M.g_slice = h->S_cap; M.g_pose = std::max(1, h->S_cap); M.g_smooth = h->sm_tiles;
+        M.slab_cnt = h->slab_cnt.p; M.slab_start = h->slab_start.p; M.slab_cursor = h->slab_cursor.p; M.coarse_cursor = h->coarse_cursor.p;
+        M.px = h->px.p; M.lo = h->lo.p; M.hi = h->hi.p;
+        M.unsorted4 = h->unsorted4.p; M.sorted4 = h->sorted4.p; M.slab_xmin = h->slab_xmin.p; M.slab_xmax = h->slab_xmax.p;
+        M.big_slabs = h->big_slabs.p; M.big_slices = h->big_slices.p;
+        M.node_x = h->node_x.p; M.node_y = h->node_y.p; M.node_z = h->node_z.p;
+        M.node_start = h->node_start.p; M.node_cnt = h->node_cnt.p; M.band_cnt = h->band_cnt.p;
+        M.wp_cnt = h->wp_cnt.p; M.wp_off = h->wp_off.p; M.tail = h->tail.p;
+        M.wp_xyz = h->wp_xyz.p; M.wp_normal = h->wp_normal.p; M.wp_nn = h->wp_nn.p;
+        M.wp_pre = h->wp_pre.p; M.wp_smooth = h->wp_smooth.p; M.wp_out = h->wp_out.p;
+        h->mm_grid_used = M.g_minmax;
+        maxB = std::max(maxB, h->B); max_slab_cap = std::max(max_slab_cap, h->slab_cap); max_capb = std::max(max_capb, h->capb);
+        full_slabs = full_slabs || (h->B > 0 && h->h_nvalid / h->B > 1000);
+        gx_mm = std::max(gx_mm, M.g_minmax); gx_scat = std::max(gx_scat, M.g_scatter); gx_sort = std::max(gx_sort, M.g_sort);
+        gx_slice = std::max(gx_slice, M.g_slice); gx_pose = std::max(gx_pose, M.g_pose); gx_smooth = std::max(gx_smooth, M.g_smooth);
+    }
+    HIPCHK(lead, copy_sync(lead, bg->members.p, mem.data(), sizeof(BatchMember) * count, hipMemcpyHostToDevice));
+    return PPP_OK;
+}
+
+/* one launch per stage over all members (blockIdx.y = member); ends with ONE copy of all meta blocks */
+int enqueue_batched(ppp_handle lead, BatchGraph *bg)
+{
+    const size_t count = bg->hs.size();
+    const int maxB = bg->maxB, max_slab_cap = bg->max_slab_cap, max_capb = bg->max_capb;
+    const int gx_mm = bg->gx_mm, gx_scat = bg->gx_scat, gx_sort = bg->gx_sort, gx_slice = bg->gx_slice, gx_pose = bg->gx_pose, gx_smooth = bg->gx_smooth;
+    const bool full_slabs = bg->full_slabs, ppt8 = bg->ppt8;
+    const unsigned gy = (unsigned)count;
+    const size_t hist_lds = sizeof(int) * (size_t)maxB;
+    LAUNCHB(lead, "k_minmax_b", k_minmax_b, dim3(gx_mm, gy), MM_T, hist_lds, bg->members.p);
+    LAUNCHB(lead, "k_setup_b", k_setup_b, dim3(1, gy), SETUP_T, 0, bg->members.p);
+    if (ppt8) LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
+    else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
+    LAUNCHB(lead, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, bg->members.p);
+    LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), SLICE_KD_T, slice_kd_bytes(max_capb), bg->members.p);
+    LAUNCHB(lead, "k_pose_b", k_pose_b, dim3(gx_pose, gy), POSE_T, pose_lds_bytes(max_capb), bg->members.p);
+    LAUNCHB(lead, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, bg->members.p);
+    LAUNCHB(lead, "k_collect_meta", k_collect_meta, dim3(gy), 64, 0, bg->members.p, (int)count, bg->metas.p);
+    HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->metas.p, sizeof(DevMeta) * count, hipMemcpyDeviceToHost, lead->stream));
+    return PPP_OK;
+}
+
+} // namespace
+} // extern "C++"
 
 int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows)
 {
@@ -1266,7 +1400,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     ppp_handle lead = hs[0];
     if (dst_dev && (!offset_rows || !cap_rows)) return fail(lead, PPP_ERR_ARG, "offset_rows / cap_rows are needed with a destination");
     HIPCHK(lead, hipSetDevice(lead->device));
-    bool plain = false;
+    bool plain = false, batched = true;
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = hs[i];
         if (!h) return fail(lead, PPP_ERR_ARG, "null handle in the batch");
@@ -1277,20 +1411,31 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         if (rc) return rc;
         if (!h->planned) { rc = make_plan(h); if (rc) { lead->err = h->err; return rc; } }
         plain = plain || h->timing;
+        batched = batched && batch_eligible(h);
     }
-    if (plain) { /* kernel timing brackets every launch with events: plain per-handle calls */
+    auto remember_dst = [&](size_t i) { /* where a re-run after an LDS overflow must put the list (rerun_with_arena) */
+        hs[i]->last_out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
+        hs[i]->last_out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
+    };
+    /* kernel timing brackets every launch with events: the batched launches run eagerly on the lead's stream (timers of the
+       lead), members that need their own launch sequence run as plain per-handle calls */
+    const bool eager = plain && batched;
+    if (plain && !batched) {
         for (size_t i = 0; i < count; ++i) {
+            ++hs[i]->internal;
             int rc = ppp_gen_path_async(hs[i]);
             if (dst_dev) { hs[i]->out2 = dst_dev + 6 * offset_rows[i]; hs[i]->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
             if (rc == PPP_OK) rc = ppp_get_path_async(hs[i]);
             hs[i]->out2 = nullptr; hs[i]->out2_cap = 0;
+            --hs[i]->internal;
+            remember_dst(i);
             if (rc) { lead->err = hs[i]->err; return rc; }
         }
         return PPP_OK;
     }
     BatchGraph *bg = nullptr;
     for (BatchGraph *cand : lead->batches) {
-        bool same = cand && cand->hs.size() == count && cand->dst == dst_dev;
+        bool same = cand && cand->hs.size() == count && cand->dst == dst_dev && cand->batched == batched && cand->eager == eager;
         for (size_t i = 0; same && i < count; ++i)
             same = cand->hs[i] == hs[i] && cand->epochs[i] == hs[i]->epoch && (!dst_dev || (cand->off[i] == offset_rows[i] && cand->cap[i] == cap_rows[i]));
         if (same) { bg = cand; break; }
@@ -1305,56 +1450,83 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         lead->batches[slot] = bg;
         bg->hs.assign(hs, hs + count);
         bg->dst = dst_dev;
+        bg->batched = batched;
+        bg->eager = eager;
         if (dst_dev) { bg->off.assign(offset_rows, offset_rows + count); bg->cap.assign(cap_rows, cap_rows + count); }
-        HIPCHK(lead, hipEventCreateWithFlags(&bg->fork, hipEventDisableTiming));
-        bg->join.resize(count, nullptr);
-        for (size_t i = 1; i < count; ++i) HIPCHK(lead, hipEventCreateWithFlags(&bg->join[i], hipEventDisableTiming));
-        /* one capture: the lead stream forks into every other handle's stream and joins them again */
-        HIPCHK(lead, hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
+        auto discard = [&]() { delete lead->batches[slot]; lead->batches[slot] = nullptr; };
         int rc = PPP_OK;
         const char *where = "";
-        hipError_t e = hipEventRecord(bg->fork, lead->stream);
-        if (e != hipSuccess) where = "fork record";
-        for (size_t i = 1; i < count && e == hipSuccess; ++i) {
-            e = hipStreamWaitEvent(hs[i]->stream, bg->fork, 0);
-            if (e != hipSuccess) where = "fork wait";
-        }
-        for (size_t i = 0; i < count && e == hipSuccess && rc == PPP_OK; ++i) {
-            ppp_handle h = hs[i];
-            h->chain_calls = true;
-            rc = ppp_gen_path_async(h);
-            h->chain_calls = false;
-            if (dst_dev) { h->out2 = dst_dev + 6 * offset_rows[i]; h->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
-            if (rc == PPP_OK) rc = ppp_get_path_async(h); /* the emitting launch also writes the list to its place in dst_dev */
-            h->out2 = nullptr; h->out2_cap = 0;
-            if (rc != PPP_OK) lead->err = "batch member " + std::to_string(i) + ": " + h->err;
-            if (i && e == hipSuccess && rc == PPP_OK) {
-                e = hipEventRecord(bg->join[i], h->stream);
-                if (e != hipSuccess) where = "join record";
-                if (e == hipSuccess) { e = hipStreamWaitEvent(lead->stream, bg->join[i], 0); if (e != hipSuccess) where = "join wait"; }
+        hipError_t e = hipSuccess;
+        if (batched) {
+            /* ONE launch per stage over all members.  Records and meta array first, outside the capture. */
+            hipError_t ea = bg->members.ensure(count);
+            if (ea == hipSuccess) ea = bg->metas.ensure(count);
+            bg->hmetas = std::make_shared<BatchMetas>();
+            if (ea == hipSuccess) ea = hipHostMalloc((void **)&bg->hmetas->pinned, sizeof(DevMeta) * count, hipHostMallocDefault);
+            if (ea != hipSuccess) { discard(); return fail(lead, PPP_ERR_HIP, std::string("batch buffers: ") + hipGetErrorString(ea)); }
+            rc = upload_members(lead, bg, dst_dev, offset_rows, cap_rows);
+            if (rc != PPP_OK) { discard(); return rc; }
+            if (!eager) {
+                HIPCHK(lead, hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_batched(lead, bg);
+            }
+        } else {
+            HIPCHK(lead, hipEventCreateWithFlags(&bg->fork, hipEventDisableTiming));
+            bg->join.resize(count, nullptr);
+            for (size_t i = 1; i < count; ++i) HIPCHK(lead, hipEventCreateWithFlags(&bg->join[i], hipEventDisableTiming));
+            /* one capture: the lead stream forks into every other handle's stream and joins them again */
+            HIPCHK(lead, hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
+            e = hipEventRecord(bg->fork, lead->stream);
+            if (e != hipSuccess) where = "fork record";
+            for (size_t i = 1; i < count && e == hipSuccess; ++i) {
+                e = hipStreamWaitEvent(hs[i]->stream, bg->fork, 0);
+                if (e != hipSuccess) where = "fork wait";
+            }
+            for (size_t i = 0; i < count && e == hipSuccess && rc == PPP_OK; ++i) {
+                ppp_handle h = hs[i];
+                h->chain_calls = true;
+                ++h->internal;
+                rc = ppp_gen_path_async(h);
+                h->chain_calls = false;
+                if (dst_dev) { h->out2 = dst_dev + 6 * offset_rows[i]; h->out2_cap = (int)std::min<size_t>(cap_rows[i], 0x7fffffff); }
+                if (rc == PPP_OK) rc = ppp_get_path_async(h); /* the emitting launch also writes the list to its place in dst_dev */
+                h->out2 = nullptr; h->out2_cap = 0;
+                --h->internal;
+                if (rc != PPP_OK) lead->err = "batch member " + std::to_string(i) + ": " + h->err;
+                if (i && e == hipSuccess && rc == PPP_OK) {
+                    e = hipEventRecord(bg->join[i], h->stream);
+                    if (e != hipSuccess) where = "join record";
+                    if (e == hipSuccess) { e = hipStreamWaitEvent(lead->stream, bg->join[i], 0); if (e != hipSuccess) where = "join wait"; }
+                }
             }
         }
-        hipGraph_t g = nullptr;
-        hipError_t e2 = hipStreamEndCapture(lead->stream, &g);
-        if (rc != PPP_OK || e != hipSuccess || e2 != hipSuccess) {
-            if (g) (void)hipGraphDestroy(g);
-            delete lead->batches[slot]; lead->batches[slot] = nullptr;
-            if (rc != PPP_OK) return rc;
-            return fail(lead, PPP_ERR_HIP, std::string("batch capture (") + where + "): " + hipGetErrorString(e != hipSuccess ? e : e2));
+        if (!eager) {
+            hipGraph_t g = nullptr;
+            hipError_t e2 = hipStreamEndCapture(lead->stream, &g);
+            if (rc != PPP_OK || e != hipSuccess || e2 != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                discard();
+                if (rc != PPP_OK) return rc;
+                return fail(lead, PPP_ERR_HIP, std::string("batch capture (") + where + "): " + hipGetErrorString(e != hipSuccess ? e : e2));
+            }
+            bg->g = g;
+            e = hipGraphInstantiate(&bg->ge, bg->g, nullptr, nullptr, 0);
+            if (e != hipSuccess) { discard(); return fail(lead, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         }
-        bg->g = g;
-        e = hipGraphInstantiate(&bg->ge, bg->g, nullptr, nullptr, 0);
-        if (e != hipSuccess) { delete lead->batches[slot]; lead->batches[slot] = nullptr; return fail(lead, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
         bg->epochs.resize(count);
         for (size_t i = 0; i < count; ++i) bg->epochs[i] = hs[i]->epoch;
     }
-    HIPCHK(lead, hipGraphLaunch(bg->ge, lead->stream));
+    if (bg->eager) { int rc = enqueue_batched(lead, bg); if (rc) return rc; }
+    else HIPCHK(lead, hipGraphLaunch(bg->ge, lead->stream));
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = hs[i];
         h->index_built = true; h->gen_done = true; h->path_done = true;
         h->list_final = !h->ranged;
         h->meta_in_flight = true;
+        h->meta_from_batch = bg->batched;
+        if (bg->batched) { h->bmetas = bg->hmetas; h->bslot = i; }
         h->pending_stream = (i == 0) ? nullptr : lead->stream;
+        remember_dst(i);
     }
     return PPP_OK;
 }

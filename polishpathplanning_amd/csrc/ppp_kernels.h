@@ -101,10 +101,12 @@ __device__ inline int slab_of_grid(float x, float x0, float invw, int B)
 #ifndef MM_T
 #define MM_T 512
 #endif
+/* bx / gx: this workgroup's index and the number of workgroups working on THIS cloud (the batched launch runs the
+   workgroups of many clouds side by side: blockIdx.y = cloud) */
 template <bool HIST>
-__global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
-                                                const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
-                                                int B, int *slab_cnt, float xlo, float xhi)
+__device__ __forceinline__ void minmax_body(const float *__restrict__ X, const float *__restrict__ Y,
+                                            const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
+                                            int B, int *slab_cnt, float xlo, float xhi, const int bx, const int gx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     if (HIST) {
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, co
     int cnt = 0;
     const int n4 = n >> 2;
     const float4 *X4 = (const float4 *)X, *Y4 = (const float4 *)Y, *Z4 = (const float4 *)Z;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < n4; i += gx * blockDim.x) {
         float4 x = X4[i], y = Y4[i], z = Z4[i];
         const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w}, zs[4] = {z.x, z.y, z.z, z.w};
         for (int k = 0; k < 4; ++k) {
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, co
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    if (bx == 0 && threadIdx.x < (n & 3)) {
         int i = (n4 << 2) + threadIdx.x;
         float x = X[i];
         if (x == x) {
@@ -163,8 +165,15 @@ __global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, co
             for (int w = 0; w < MM_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
             r.mn[d] = a; r.mx[d] = b;
         }
-        part[blockIdx.x] = r;
+        part[bx] = r;
     }
+}
+template <bool HIST>
+__global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
+                                                const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
+                                                int B, int *slab_cnt, float xlo, float xhi)
+{
+    minmax_body<HIST>(X, Y, Z, n, part, x0, invw, B, slab_cnt, xlo, xhi, blockIdx.x, gridDim.x);
 }
 
 /* Device form of ppp_slice_walk for one thread: identical values, but without a data dependent
@@ -243,9 +252,9 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
 #ifndef SETUP_T
 #define SETUP_T 1024
 #endif
-__global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
-                                               float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
-                                               float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
+__device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const MinMaxPart *__restrict__ part, int nparts,
+                                           float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
+                                           float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
 {
     __shared__ int s_scan[17];
     __shared__ float s_mn[3][SETUP_T / 64], s_mx[3][SETUP_T / 64];
@@ -361,9 +370,9 @@ __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, cons
    which k_slab_sort fixes anyway. */
 /* Every thread keeps its PPT points in registers between the counting and the writing pass: the input is read once. */
 template <int LEVEL, int PPT>
-__global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
-                                                      const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
-                                                      const DevMeta *m, int *cursor, float4 *out4)
+__device__ __forceinline__ void slab_scatter_body(const float *__restrict__ X, const float *__restrict__ Y,
+                                                  const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
+                                                  const DevMeta *m, int *cursor, float4 *out4, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     const int B = LEVEL == 1 ? ((m->B + (1 << SCAT_COARSE_SHIFT) - 1) >> SCAT_COARSE_SHIFT) : m->B;
@@ -372,7 +381,7 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict
     auto bin = [&](float x) { return LEVEL == 1 ? (slab_of(m, x) >> SCAT_COARSE_SHIFT) : slab_of(m, x); };
     STAMP_BEGIN();
     /* this thread's points: i0 + threadIdx.x + k * blockDim.x (coalesced), requested before anything else */
-    const int i0 = blockIdx.x * (PPT * (int)blockDim.x);
+    const int i0 = bx * (PPT * (int)blockDim.x);
     float4 p[PPT];
     int pb[PPT]; /* bin, or -1: not mine / dropped */
 #pragma unroll
@@ -415,15 +424,15 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict
 #define SORT_T 512
 #endif
 template <bool ARENA>
-__global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
-                                                   float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                                   int *big_list, char *arena, unsigned long long arena_cap)
+__device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
+                                               float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
+                                               int *big_list, char *arena, unsigned long long arena_cap, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ float s_mn[SORT_T / 64], s_mx[SORT_T / 64];
     __shared__ int s_scr[17];
     __shared__ unsigned long long s_off;
-    int b = blockIdx.x;
+    int b = bx;
     if (ARENA) {
         if (b >= m->big_slabs) return;
         b = big_list[b];
@@ -1023,21 +1032,21 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
 
 /* ARENA = false: the band lives in LDS (capb points); a slice whose band does not fit is appended
    to a work list.  ARENA = true: second pass over that list, same code on a global arena. */
-template <bool ARENA>
 #ifndef SLICE_KD_T
 #define SLICE_KD_T 1024
 #endif
-__global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
-                                                  DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
-                                                  const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
-                                                  float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
-                                                  char *arena, unsigned long long arena_cap)
+template <bool ARENA>
+__device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+                                              DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
+                                              const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
+                                              float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
+                                              char *arena, unsigned long long arena_cap, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
     __shared__ int s_n, s_plane, s_ner, s_base, s_m;
     __shared__ unsigned long long s_off;
-    int s = blockIdx.x;
+    int s = bx;
     if (ARENA) {
         if (s >= m->big_slices) return;
         s = big_list[s];
@@ -1739,14 +1748,14 @@ struct PoseBack {
     float inv[3][4];
 };
 template <bool ALIGNED>
-__global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
-                                              const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
-                                              const float *__restrict__ slab_xmax, const float *__restrict__ px,
-                                              const float *__restrict__ node_x, const float *__restrict__ node_y,
-                                              const float *__restrict__ node_z,
-                                              const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                              int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
-                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back)
+__device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const float4 *__restrict__ sorted4,
+                                          const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+                                          const float *__restrict__ slab_xmax, const float *__restrict__ px,
+                                          const float *__restrict__ node_x, const float *__restrict__ node_y,
+                                          const float *__restrict__ node_z,
+                                          const int *__restrict__ node_start, const int *__restrict__ node_cnt,
+                                          int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
+                                          float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     float4 *s_pts = (float4 *)s_raw;
@@ -1755,7 +1764,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
     float *s_nx = s_nz + capb;
     __shared__ int s_scan[17];
     __shared__ int s_mycnt, s_myoff, s_run;
-    const int k = blockIdx.x;
+    const int k = bx;
     const int nk = m->nkept;
     if (m->err || k >= nk) return;
     /* work was left for the arena passes but they were not launched: report, the host re-runs */
@@ -2049,34 +2058,32 @@ __device__ inline void finish_list_in_order(DevMeta *m, const DevParams &P, cons
 #define SMF_T 256            /* waypoints (= threads) per tile */
 #endif
 #define SMF_K 32             /* filter half-width: r^33 = 5e-19 */
-#define SMF_END 72           /* r^72 = 1e-40: beyond that many waypoints an end's homogeneous term is exactly absorbed */
+#define SMF_END 128          /* r^128 = 1e-71: beyond that many waypoints from an end its homogeneous term is exactly absorbed */
 #define SMF_M (SMF_T + 2 * SMF_K)
 __host__ __device__ inline int smooth_tiles(int W) { return W > 0 ? (W + SMF_T - 1) / SMF_T : 1; }
 
-/* p of the fixed end `e` (0 or W-1): only the interior neighbours on its one side contribute */
-__device__ inline double smooth_end_p(const float *__restrict__ wp_pre, int W, int e, int j, double r, double c)
+/* r^k by repeated squaring (k < 2^10) */
+__device__ inline double smooth_rpow(double r, int k)
 {
-    const int dir = e == 0 ? 1 : -1;
-    double acc = 0.0;
-    for (int k = SMF_K; k >= 1; --k) {
-        const int g = e + dir * k;
-        const double x = (g >= 1 && g <= W - 2) ? (double)wp_pre[6 * (size_t)g + j] : 0.0;
-        acc = x + r * acc;
-    }
-    return c * (r * acc);
+    double v = 1.0, b = r;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) { if (k & (1 << q)) v *= b; b *= b; }
+    return v;
 }
 
-__global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
-                                                        float *wp_smooth, float *wp_out, const int *__restrict__ tail,
-                                                        float *dst2, int cap2)
+__device__ __forceinline__ void smooth_solve_body(DevMeta *m, const DevParams &P, int W_cap, const float *__restrict__ wp_pre,
+                                                  float *wp_smooth, float *wp_out, const int *__restrict__ tail,
+                                                  float *dst2, int cap2, const int bx)
 {
     __shared__ float s_x[3][SMF_M];
     __shared__ int s_tail[4096];
     __shared__ int s_last;
+    __shared__ double s_rp[SMF_END]; /* r^k */
+    __shared__ double s_e[2][3];     /* x - p at the two fixed ends */
     const int W = m->W;
     if (m->err || W == 0) return;
     const int ntiles = smooth_tiles(W);
-    const int tile = blockIdx.x;
+    const int tile = bx;
     if (tile >= ntiles) return;
     /* weight_data = 0.65, weight_smooth = 1 - weight_data (path_translation_alg.cpp:118): r = 0.27951480..., c = 0.56309250... */
     const double wd = 0.65, ws = 1 - wd, dg = wd + 2 * ws;
@@ -2099,6 +2106,21 @@ __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P,
         for (int i = threadIdx.x; i < m->nkept; i += blockDim.x) s_tail[i] = tail[i];
         tl = s_tail;
     }
+    /* tiles within SMF_END waypoints of an end also need that end's homogeneous term: p at the end is a one-sided sum over
+       its SMF_K interior neighbours, one lane per neighbour (wave j = coordinate j, lanes 0..31 the front end, 32..63 the back
+       end), added by a fixed shuffle tree */
+    const bool near_end = solve && (t0 < SMF_END || t0 + SMF_T - 1 > W - 1 - SMF_END);
+    if (near_end) {
+        if (threadIdx.x < SMF_END) s_rp[threadIdx.x] = smooth_rpow(r, threadIdx.x);
+        const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (j < 3) {
+            const int k = (lane & 31) + 1;
+            const int gq = lane < 32 ? k : W - 1 - k;
+            double v = (gq >= 1 && gq <= W - 2) ? (double)wp_pre[6 * (size_t)gq + j] * smooth_rpow(r, k) : 0.0;
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((lane & 31) == 0) s_e[lane >> 5][j] = (double)wp_pre[6 * (size_t)(lane < 32 ? 0 : W - 1) + j] - c * v;
+        }
+    }
     __syncthreads();
     const int g = t0 + threadIdx.x;
     if (g < W) {
@@ -2114,18 +2136,13 @@ __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P,
                 for (int k = SMF_K - 1; k >= 1; --k) acc = ((double)s_x[j][l - k] + (double)s_x[j][l + k]) + r * acc;
                 y[j] = c * ((double)s_x[j][l] + r * acc);
             }
-            const bool near0 = g <= SMF_END, near1 = (W - 1 - g) <= SMF_END;
-            if (near0 || near1) {
-                double D = 0.0; /* r^(W-1): couples the two ends of a short list */
-                if (W - 1 <= 2 * SMF_END + 16) { D = 1.0; for (int q = 0; q < W - 1; ++q) D *= r; }
-                double r0 = 0.0, r1 = 0.0; /* r^g, r^(W-1-g) */
-                if (near0 || D != 0.0) { r0 = 1.0; for (int q = 0; q < g; ++q) r0 *= r; }
-                if (near1 || D != 0.0) { r1 = 1.0; for (int q = 0; q < W - 1 - g; ++q) r1 *= r; }
+            if (near_end) {
+                const double D = W - 1 < SMF_END ? s_rp[W - 1] : 0.0; /* r^(W-1): couples the two ends of a short list */
+                const double r0 = g < SMF_END ? s_rp[g] : 0.0, r1 = W - 1 - g < SMF_END ? s_rp[W - 1 - g] : 0.0;
                 const double det = 1.0 - D * D;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const double e0 = (double)wp_pre[j] - smooth_end_p(wp_pre, W, 0, j, r, c);
-                    const double e1 = (double)wp_pre[6 * (size_t)(W - 1) + j] - smooth_end_p(wp_pre, W, W - 1, j, r, c);
+                    const double e0 = s_e[0][j], e1 = s_e[1][j];
                     const double A = (e0 - D * e1) / det, B = (e1 - D * e0) / det;
                     y[j] = y[j] + (A * r0 + B * r1);
                 }
@@ -2151,4 +2168,145 @@ __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P,
         }
     }
     if (tile == 0 && threadIdx.x == 0) { m->sweeps = 0; m->smooth_done = 0; }
+}
+
+/* ------------------------------------------------------------------ */
+/* Launch forms of the pipeline kernels.                                 */
+/* Single: one cloud per launch, blockIdx.x = workgroup.                 */
+/* Batched (BASELINE config 3: many small workpieces on ONE GPU): the    */
+/* same bodies over ALL members of a batch in one launch per stage --    */
+/* blockIdx.y = member, blockIdx.x = that member's workgroup; a member   */
+/* with fewer workgroups than the widest one leaves its surplus at once. */
+/* Every member is described by a BatchMember record in device memory    */
+/* (its handle's buffers, sizes and per-stage grids), read through a     */
+/* uniform address (scalar loads).                                       */
+/* ------------------------------------------------------------------ */
+struct BatchMember {
+    DevMeta *m;
+    DevParams P;
+    const float *X, *Y, *Z;
+    int n;
+    MinMaxPart *mm_part;
+    float slab_x0, slab_invw, incl_lo, incl_hi;
+    int B, S_cap, slab_cap, capb, node_cap, W_cap, out2_cap;
+    int g_minmax, g_scatter, g_sort, g_slice, g_pose, g_smooth; /* workgroups of this member per stage */
+    int *slab_cnt, *slab_start, *slab_cursor, *coarse_cursor;
+    float *px, *lo, *hi;
+    float4 *unsorted4, *sorted4;
+    float *slab_xmin, *slab_xmax;
+    int *big_slabs, *big_slices;
+    float *node_x, *node_y, *node_z;
+    int *node_start, *node_cnt, *band_cnt;
+    int *wp_cnt, *wp_off, *tail;
+    float4 *wp_xyz, *wp_normal;
+    int *wp_nn;
+    float *wp_pre, *wp_smooth, *wp_out, *out2;
+};
+
+__global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
+                                               float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
+                                               float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
+{
+    setup_body(m, P, part, nparts, px, lo, hi, S_cap, B, slab_cnt, slab_x0, slab_invw, slab_start, slab_cursor, coarse_cursor);
+}
+template <int LEVEL, int PPT>
+__global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
+                                                      const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
+                                                      const DevMeta *m, int *cursor, float4 *out4)
+{
+    slab_scatter_body<LEVEL, PPT>(X, Y, Z, in4, n, m, cursor, out4, blockIdx.x);
+}
+template <bool ARENA>
+__global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
+                                                   float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
+                                                   int *big_list, char *arena, unsigned long long arena_cap)
+{
+    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, blockIdx.x);
+}
+template <bool ARENA>
+__global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+                                                  DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
+                                                  const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
+                                                  float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
+                                                  char *arena, unsigned long long arena_cap)
+{
+    slice_kd_body<ARENA>(sorted4, slab_start, m, px, lo, hi, capb_lds, node_x, node_y, node_z, node_cap, node_start, node_cnt, band_cnt,
+                         big_list, arena, arena_cap, blockIdx.x);
+}
+template <bool ALIGNED>
+__global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+                                              const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+                                              const float *__restrict__ slab_xmax, const float *__restrict__ px,
+                                              const float *__restrict__ node_x, const float *__restrict__ node_y,
+                                              const float *__restrict__ node_z,
+                                              const int *__restrict__ node_start, const int *__restrict__ node_cnt,
+                                              int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
+                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back)
+{
+    pose_body<ALIGNED>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
+                       tail, W_cap, arena_ran, capb, wp_xyz, wp_nn, wp_normal, wp_pre, back, blockIdx.x);
+}
+__global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
+                                                        float *wp_smooth, float *wp_out, const int *__restrict__ tail,
+                                                        float *dst2, int cap2)
+{
+    smooth_solve_body(m, P, W_cap, wp_pre, wp_smooth, wp_out, tail, dst2, cap2, blockIdx.x);
+}
+
+/* ---- batched forms ---- */
+__global__ void __launch_bounds__(MM_T) k_minmax_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_minmax) return;
+    minmax_body<true>(M.X, M.Y, M.Z, M.n, M.mm_part, M.slab_x0, M.slab_invw, M.B, M.slab_cnt, M.incl_lo, M.incl_hi, blockIdx.x, M.g_minmax);
+}
+__global__ void __launch_bounds__(SETUP_T) k_setup_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    setup_body(M.m, M.P, M.mm_part, M.g_minmax, M.px, M.lo, M.hi, M.S_cap, M.B, M.slab_cnt, M.slab_x0, M.slab_invw, M.slab_start,
+               M.slab_cursor, M.coarse_cursor);
+}
+template <int PPT>
+__global__ void __launch_bounds__(SCAT_T) k_slab_scatter_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_scatter) return;
+    slab_scatter_body<0, PPT>(M.X, M.Y, M.Z, nullptr, M.n, M.m, M.slab_cursor, M.unsorted4, blockIdx.x);
+}
+__global__ void __launch_bounds__(SORT_T) k_slab_sort_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_sort) return;
+    slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, blockIdx.x);
+}
+__global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_slice) return;
+    slice_kd_body<false>(M.sorted4, M.slab_start, M.m, M.px, M.lo, M.hi, M.capb, M.node_x, M.node_y, M.node_z, M.node_cap, M.node_start,
+                         M.node_cnt, M.band_cnt, M.big_slices, nullptr, 0ull, blockIdx.x);
+}
+__global__ void __launch_bounds__(POSE_T) k_pose_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_pose) return;
+    PoseBack none;
+    none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr;
+    pose_body<false>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
+                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.capb, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, blockIdx.x);
+}
+__global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
+{
+    const BatchMember &M = mem[blockIdx.y];
+    if ((int)blockIdx.x >= M.g_smooth) return;
+    smooth_solve_body(M.m, M.P, M.W_cap, M.wp_pre, M.wp_smooth, M.wp_out, M.tail, M.out2, M.out2_cap, blockIdx.x);
+}
+/* the members' meta blocks side by side, so that ONE copy publishes the batch to the host */
+__global__ void __launch_bounds__(64) k_collect_meta(const BatchMember *__restrict__ mem, int count, DevMeta *out)
+{
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int *src = (const int *)mem[i].m;
+    int *dst = (int *)(out + i);
+    for (int q = threadIdx.x; q < (int)(sizeof(DevMeta) / sizeof(int)); q += blockDim.x) dst[q] = src[q];
 }

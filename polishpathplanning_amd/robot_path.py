@@ -3,8 +3,9 @@
 Multi-GPU model: workpieces are independent, so a batch shards one
 workpiece per GPU with no data-path collective.  The only exchange is the variable-length
 gather of the finished W_g x 6 float blocks to rank 0 (the robot controller reads one file).
-Blocks are ~0.6 MB per workpiece: latency-bound on xGMI, so one count exchange plus one padded
-all-gather is used -- no ring reduction exists anywhere on the path.
+Blocks are ~0.6 MB per workpiece: latency-bound on xGMI, so one count exchange (once per batch) plus one
+gather of padded blocks to rank 0 is used -- torch.distributed.gather, which RCCL runs as direct
+send/recv pairs into the root, point to point over xGMI; no ring and no reduction exist anywhere on the path.
 torch.distributed is plumbing here: backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 """
 import numpy as np
@@ -37,10 +38,11 @@ def gather_robot_path(local_wp, dist=None, device=None, counts=None):
     wmax = max(max(counts), 1)
     send = torch.zeros((wmax, 6), dtype=torch.float32, device=dev)
     send[: local_wp.shape[0]] = local_wp
-    recv = torch.empty((world * wmax, 6), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv, send)
     if rank != 0:
+        dist.gather(send, None, dst=0)
         return None
+    recv = torch.empty((world * wmax, 6), dtype=torch.float32, device=dev)
+    dist.gather(send, [recv[r * wmax: (r + 1) * wmax] for r in range(world)], dst=0)
     return [recv[r * wmax: r * wmax + counts[r]] for r in range(world)]
 
 
@@ -67,7 +69,9 @@ class RobotPathGatherer:
         wmax = max(max(self.counts), 1)
         if self.send is None or self.send.shape[0] != wmax:
             self.send = torch.zeros((wmax, 6), dtype=torch.float32, device=self.device)
-            self.recv = torch.empty((self.world * wmax, 6), dtype=torch.float32, device=self.device) if self.dist else None
+            # only the root receives: a true gather (every other rank just sends its block)
+            self.recv = torch.empty((self.world * wmax, 6), dtype=torch.float32, device=self.device) if (self.dist and self.rank == 0) else None
+            self.recv_list = [self.recv[r * wmax: (r + 1) * wmax] for r in range(self.world)] if self.recv is not None else None
         self.wmax = wmax
 
     def gather_async(self, stream=None):
@@ -77,8 +81,8 @@ class RobotPathGatherer:
             return None
         if stream is not None:
             with self.torch.cuda.stream(stream):
-                return self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
-        return self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+                return self.dist.gather(self.send, self.recv_list, dst=0, async_op=True)
+        return self.dist.gather(self.send, self.recv_list, dst=0, async_op=True)
 
     def blocks(self):
         """rank 0: list of per-rank [W_r, 6] views of the receive buffer in rank order; other ranks: None"""
@@ -95,9 +99,9 @@ class RobotPathGatherer:
             return [self.send[: self.w_local]]
         if stream is not None:
             with self.torch.cuda.stream(stream):
-                self.dist.all_gather_into_tensor(self.recv, self.send)
+                self.dist.gather(self.send, self.recv_list, dst=0)
         else:
-            self.dist.all_gather_into_tensor(self.recv, self.send)
+            self.dist.gather(self.send, self.recv_list, dst=0)
         if self.rank != 0:
             return None
         return [self.recv[r * self.wmax: r * self.wmax + self.counts[r]] for r in range(self.world)]

@@ -686,6 +686,69 @@ def test_run_batch_graph_matches_single_handles(engine_mod):
     assert engines[1].num_waypoints() > ws[1] and engines[0].waypoints().tobytes() == want[0].tobytes()
 
 
+def test_batch_of_64_cfg3_workpieces_full_size(engine_mod, oracle_mod):
+    """BASELINE config 3 as stated: 64 distinct 250 k-point workpieces (own seed and dome amplitude each) planned by ONE
+    ppp_run_batch_async call -- one launch per stage over all members -- and every member checked against the oracle."""
+    count = 64
+    rng = np.random.default_rng(3)
+    amps = rng.uniform(10.0, 40.0, count)
+    clouds = [synth.make_config("cfg3_250k_s128", seed=300 + i, amp=float(amps[i]))[0] for i in range(count)]
+    engines = []
+    for pts in clouds:
+        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); engines.append(e)
+    oracles = []
+    for pts in clouds:
+        o = oracle_mod.Oracle(pts, tool_radius=6.0); assert o.gen_path() == 128; o.get_path(); oracles.append(o)
+    ws = [o.num_waypoints() for o in oracles]
+    offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
+    buf = _DeviceBuffer(sum(ws) * 24)
+    for _ in range(3):                                   # capture, then two replays
+        engine_mod.run_batch_async(engines, buf.ptr, offs, ws)
+        engine_mod.sync_batch(engines)
+    got = buf.to_host(sum(ws) * 6)
+    for i, (e, o) in enumerate(zip(engines, oracles)):
+        assert e.num_slices() == 128 and e.num_waypoints() == ws[i], i
+        assert np.array_equal(e.tail_index(), o.tail_index()), i
+        for s in rng.choice(128, 6, replace=False):
+            gy, gx, gz = e.nodes(int(s)); oy, ox, oz = o.nodes(int(s))
+            assert np.array_equal(gy, oy) and np.array_equal(gx, ox) and np.array_equal(gz, oz), (i, s)
+        wp, owp = e.waypoints(), o.waypoints()
+        assert got[offs[i]: offs[i] + ws[i]].tobytes() == wp.tobytes(), i
+        assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M, i
+        d = np.abs(wp[:, 3:] - owp[:, 3:])
+        assert np.minimum(d, np.abs(d - 2 * np.pi)).max() <= TOL_RAD, i
+    # the batched launches and a handle's own launch sequence give the same bytes
+    solo = engine_mod.Engine(0, tool_radius=6.0); solo.set_cloud(clouds[17]); solo.gen_path(); solo.get_path()
+    assert solo.waypoints().tobytes() == engines[17].waypoints().tobytes()
+
+
+def test_batch_member_that_overflows_lds_lands_in_the_batch_buffer(engine_mod, oracle_mod):
+    """A member whose bands do not fit the LDS fast path is re-planned with the arena passes by ppp_sync_batch: the
+    re-planned list must also reach that member's rows of the batch destination (the RCCL send buffer)."""
+    small = synth.make_config("small_40k", seed=42)[0]
+    # the same plate with a 20 mm strip ten times denser: the plan (sized from the mean density) gives bands 1024 LDS slots
+    # and slabs 2048, the strip's bands hold ~2500 points and its slabs ~6000
+    rng = np.random.default_rng(41)
+    x = rng.uniform(290.0, 310.0, 12000); y = rng.uniform(-70.0, 70.0, 12000)
+    z = 20.0 * np.sin(x / 600.0) * np.cos(y / 300.0) + 1500.0
+    dense = np.concatenate([small, (np.stack([x, y, z], axis=1) / 1000).astype(np.float32)])
+    probe = engine_mod.Engine(0, tool_radius=6.0); probe.set_cloud(dense); S = probe.gen_path()
+    assert max(len(probe.slice_indices(s)) for s in range(S)) > 2048
+    want = []
+    for pts in (small, dense, small):
+        f = engine_mod.Engine(0, tool_radius=6.0); f.set_cloud(pts); f.gen_path(); f.get_path(); want.append(f.waypoints())
+    engines = []
+    for pts in (small, dense, small):
+        e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); engines.append(e)
+    ws = [len(w) for w in want]
+    offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
+    buf = _DeviceBuffer(sum(ws) * 24)
+    for _ in range(3):      # first call: batched launches + the re-run of member 1; then its arena plan keeps the batch on the branch graph
+        engine_mod.run_batch_async(engines, buf.ptr, offs, ws)
+        engine_mod.sync_batch(engines)
+        assert buf.to_host(sum(ws) * 6).tobytes() == np.concatenate(want).tobytes()
+
+
 def test_randomised_sweep_against_the_oracle(engine_mod, oracle_mod):
     """tests/tools/fuzz_parity.py, 40 seeded cases: random shape / radius / walk / pairing / dynamic adjustment / duplicates /
     non-finite points; knots bit-exact, waypoints <= 1e-4 m, identical failing slice where the reference would abort,

@@ -382,3 +382,18 @@ def test_pcd_and_config_parsers_under_address_sanitizer(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the form the driver uses for N = 1) must start the two ranks itself,
+    before anything touches the GPU.  On this CPU-only box each rank then stops at the no-GPU check -- which is the proof
+    that both were started with their RANK / WORLD_SIZE set and that the parent hands their failure on."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PPP_BENCH_ECHO_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    out = r.stdout + r.stderr
+    assert "rank 0 of 2" in out and "rank 1 of 2" in out
+    assert "cfg4_2m_s256" in out          # the N > 1 default workload is BASELINE configs[3], one 2 M-point workpiece per GPU
