@@ -32,7 +32,8 @@ public:
     void trans2center() { planner.trans2center(); } /* Path_Generation.cpp:60-92 */
     void smooth() { planner.smooth_mls(15, 3, file_name, true); } /* Path_Generation.cpp:340-360 */
     void Set_kdtree() {}
-    void estimate_normal() {}
+    void estimate_normal() { planner.estimate_normal(); } /* Path_Generation.cpp:323-333 */
+    const std::vector<float> &cloud_normals() const { return planner.cloud_normals(); } /* n x (nx ny nz curvature) */
     void get_coverage() { note("get_coverage"); }
 
     std::vector<int> rangedX_index(int position) { return planner.rangedX_index(position); }

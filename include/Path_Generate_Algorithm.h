@@ -16,6 +16,8 @@
 #ifndef PATH_CONNECT
 #define PATH_CONNECT
 
+#include <chrono>
+#include <fstream>
 #include <string>
 #include <vector>
 #include "Spline.h"
@@ -57,13 +59,20 @@ public:
     void remove_outlier() { planner.remove_outlier(50, 1.0); }
 
     void show() { planner.show_notice(); }
-    void estimate_normal() { /* normals are evaluated where getPath needs them (ppp_normals_at) */ }
+    /* path_slicing_alg.cpp:141-150: the whole-cloud normal field (the reference's GenPath and getPath call it themselves;
+       here they evaluate normals only where getPath needs them, so this runs when the CALLER asks for the field) */
+    void estimate_normal() { planner.estimate_normal(); }
+    const std::vector<float> &cloud_normals() const { return planner.cloud_normals(); } /* n x (nx ny nz curvature) */
     virtual void GenPath()
     {
         printf("Start Path Planning!\n");
+        auto startT = std::chrono::high_resolution_clock::now();
         if (!planner.gen_path()) return;
         build_path_set();
+        auto duration = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - startT).count();
+        printf("Toal Using Time: %ld \n", (long)duration);          /* path_slicing_alg.cpp:337-341 */
         printf("Number of paths: %d\n", (int)Path_set.size());
+        printf("Number of Point Cloud: %ld\n", (long)planner.num_points());
     }
     void getPath()
     {
@@ -135,8 +144,15 @@ public:
     void GenPath() override
     {
         printf("Start Path Planning!\n");
+        auto startT = std::chrono::high_resolution_clock::now();
         if (!planner.gen_path()) return;
         build_path_set();
+        auto duration = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - startT).count();
+        printf("Toal Using Time: %ld \n", (long)duration);          /* path_dynamic_alg.cpp:374-378 */
+        printf("Number of Point Cloud: %ld\n", (long)planner.num_points());
+        std::ofstream outputFile("output.csv", std::ios::app);      /* path_dynamic_alg.cpp:380-388 */
+        if (!outputFile.is_open()) std::cerr << "cannot open output.csv" << std::endl;
+        else outputFile << duration << std::endl;
     }
     typedef enum { left, right } Dir;
 

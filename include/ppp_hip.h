@@ -207,6 +207,25 @@ int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t c
 /* Spline::point(y) of slice s (include/Spline.h:22-25): xyz[3*i..] */
 int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz);
 
+/* ---- class Spline on caller-supplied knots (include/Spline.h:7-51) ----
+ * The planner's own splines live with their slice (ppp_get_nodes / ppp_eval_spline above); these entry points serve callers
+ * that construct a Spline themselves, as the reference's OnePath (path_slicing_alg.cpp:240-267), path_track
+ * (Path_Generation.cpp:659-687) and dynamic_adjust_path (path_dynamic_alg.cpp:297-303, Spline::restart) do.
+ * Knots and evaluation are double, as in GSL; the object owns its device copy of the knots and a HIP stream. */
+typedef struct ppp_spline_s *ppp_spline;
+/* Spline(int number, const double* point_y, const double* point_x, const double* point_z) (Spline.h:10-20): two
+ * gsl_interp_steffen splines y -> x and y -> z.  Where GSL raises GSL_EINVAL and aborts -- fewer than 3 knots
+ * (gsl_spline_alloc, steffen min_size 3) or y not strictly increasing (gsl_interp_init) -- PPP_ERR_ARG comes back. */
+int ppp_spline_create(int device_id, size_t n, const double *y, const double *x, const double *z, ppp_spline *out);
+/* Spline::restart (Spline.h:30-42): re-fit the same object on new knots */
+int ppp_spline_restart(ppp_spline sp, size_t n, const double *y, const double *x, const double *z);
+/* Spline::point(y) for k values (Spline.h:22-25): xyz[3*i..] = (splineYX(y), y, splineYZ(y)); a y outside [miny, bigy]
+ * gives NaNs and PPP_ERR_DOMAIN (GSL_EDOM; GSL's default handler aborts there) */
+int ppp_spline_eval(ppp_spline sp, const double *y, size_t k, double *xyz);
+/* miny() / bigy() (Spline.h:27-28) and the knot count */
+int ppp_spline_range(ppp_spline sp, double *miny, double *bigy, size_t *n);
+int ppp_spline_destroy(ppp_spline sp);
+
 /* ---- single-call mirrors of the reference's public methods ---- */
 /* rangedX_index(int position) (path_slicing_alg.cpp:152-162, Path_Generation.cpp:94-104) */
 int ppp_ranged_x_index(ppp_handle h, int position, int *out, size_t cap, size_t *n);

@@ -134,9 +134,32 @@ public:
         std::vector<int> out(4096);
         size_t n = 0;
         int rc = ppp_ranged_x_index(h_, position, out.data(), out.size(), &n);
+        if (rc == PPP_OK && n > out.size()) { /* the call reports the full count and copies what fits: ask again with room */
+            out.resize(n);
+            rc = ppp_ranged_x_index(h_, position, out.data(), out.size(), &n);
+        }
         if (rc != PPP_OK) { report(rc); n = 0; }
         out.resize(n);
         return out;
+    }
+    /* estimate_normal() (path_slicing_alg.cpp:141-150, Path_Generation.cpp:323-333): pcl::NormalEstimation, radius 2.5,
+       over the whole cloud; the field stays readable as cloud_normals() -- n x (nx ny nz curvature), cloud index order */
+    bool estimate_normal()
+    {
+        if (!ok()) return false;
+        size_t n = 0;
+        ppp_num_points(h_, &n);
+        normals_.assign(4 * n, 0.f);
+        int rc = ppp_estimate_normals(h_, normals_.data());
+        if (rc != PPP_OK) { normals_.clear(); return report(rc); }
+        return true;
+    }
+    const std::vector<float> &cloud_normals() const { return normals_; }
+    size_t num_points() const
+    {
+        size_t n = 0;
+        if (h_) ppp_num_points(h_, &n);
+        return n;
     }
     MAP insert_point(const std::vector<int> &indices, float plane_x)
     {
@@ -189,6 +212,7 @@ private:
     ppp_handle h_ = nullptr;
     ppp_config cfg_;
     bool loaded_ = false;
+    std::vector<float> normals_;
 };
 
 } // namespace ppp

@@ -26,7 +26,8 @@ public:
         planner.open(cloud_name);
     }
     void show() { planner.show_notice(); }
-    void estimate_normal() {}
+    void estimate_normal() { planner.estimate_normal(); } /* path_connect_ex0720.cpp: pcl::NormalEstimation, whole cloud */
+    const std::vector<float> &cloud_normals() const { return planner.cloud_normals(); }
     void GenPath()
     {
         if (!planner.gen_path()) return;

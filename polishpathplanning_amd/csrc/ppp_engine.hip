@@ -285,7 +285,7 @@ int validate_params(ppp_handle h, const ppp_params *p)
     if (p->walk < 0 || p->walk > 4) return fail(h, PPP_ERR_ARG, "walk");
     if (!(p->normal_radius > 0)) return fail(h, PPP_ERR_ARG, "normal_radius");
     if (p->smooth_max_sweeps < 1 || p->smooth_max_sweeps > SM_MAXS) return fail(h, PPP_ERR_ARG, "smooth_max_sweeps must be in [1, 512]");
-    if (p->alignment) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment/Smooth/RemoveOutlier are outside the hot path (SURVEY.md 8f rank 3)");
+    if (p->alignment) return fail(h, PPP_ERR_ARG, "ppp_params.alignment must be 0: Alignment / Smooth / RemoveOutlier are calls on the resident cloud (ppp_trans2center, ppp_smooth_mls, ppp_remove_outlier), not plan parameters");
     if (p->slice_begin < 0 || (p->slice_end > 0 && p->slice_end < p->slice_begin)) return fail(h, PPP_ERR_ARG, "slice_begin / slice_end");
     if ((p->slice_begin > 0 || p->slice_end > 0) && !(p->range_margin >= 2 * p->normal_radius))
         return fail(h, PPP_ERR_ARG, "range_margin must be at least twice the normal radius");
@@ -767,8 +767,8 @@ int ppp_set_params(ppp_handle h, const ppp_params *p)
     int rc = validate_params(h, p);
     if (rc) return rc;
     bool rescale = h->have_cloud && (p->change_range != h->P.change_range);
-    h->P = *p;
     if (rescale) return fail(h, PPP_ERR_ARG, "ChangeRange changed after the cloud was set: set the cloud again");
+    h->P = *p;
     if (h->have_cloud) {
         HIPCHK(h, hipSetDevice(h->device));
         int rcs = settle(h);
@@ -799,7 +799,7 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
 namespace {
 
 /* the slab index of a handle, complete: built, its meta block read back, the arena passes run if a slab overflowed */
-int index_ready(ppp_handle h)
+int index_ready(ppp_handle h, bool strict = true)
 {
     int rc = ensure_index(h);
     if (rc) return rc;
@@ -811,6 +811,9 @@ int index_ready(ppp_handle h)
         rc = enqueue_index(h); if (rc) return rc;
         rc = fetch_meta(h); if (rc) return rc;
     }
+    /* strict: any deferred device error is the caller's (preprocessing replaces the cloud).  The single-call mirrors only
+       read the index: an earlier GenPath's slice error is not theirs, a slab that fits nowhere is */
+    if (!strict && h->hmeta.err != DERR_CAPACITY) return PPP_OK;
     return map_dev_err(h);
 }
 
@@ -1804,14 +1807,14 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
 
 int ppp_ranged_x_index(ppp_handle h, int position, int *out, size_t cap, size_t *n)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     return band_indices(h, (float)(-2 + position), (float)(2 + position), out, cap, n);
 }
 
 int ppp_get_slice_indices(ppp_handle h, int s, int *out, size_t cap, size_t *n)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     rc = fetch_meta(h);
     if (rc) return rc;
@@ -1907,7 +1910,7 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, 
 
 int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     if (!k) return PPP_OK;
     if (!idx || !out4) return fail(h, PPP_ERR_ARG, "bad arguments");
@@ -1925,7 +1928,7 @@ int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4)
 
 int ppp_estimate_normals(ppp_handle h, float *out4)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     if (!h->n) return PPP_OK;
     if (!out4) return fail(h, PPP_ERR_ARG, "bad arguments");
@@ -1947,7 +1950,7 @@ int ppp_estimate_normals(ppp_handle h, float *out4)
 
 int ppp_area2cloud(ppp_handle h, const double *pts_xyz, size_t k, int key, float *out3)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     if (!k) return PPP_OK;
     if (!pts_xyz || !out3 || (key != 0 && key != 1)) return fail(h, PPP_ERR_ARG, "bad arguments");
@@ -1969,7 +1972,7 @@ int ppp_area2cloud(ppp_handle h, const double *pts_xyz, size_t k, int key, float
 
 int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx)
 {
-    int rc = ensure_index(h);
+    int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
     if (!k) return PPP_OK;
     if (!q_xyz || !idx) return fail(h, PPP_ERR_ARG, "bad arguments");
@@ -2012,6 +2015,94 @@ int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *
     default: return fail(h, PPP_ERR_ARG, "unknown stage");
     }
     HIPCHK(h, copy_sync(h, out, src, std::min(cap_bytes, W * elem), hipMemcpyDeviceToHost));
+    return PPP_OK;
+}
+
+/* ---- class Spline on caller-supplied knots (include/Spline.h:7-51) ---- */
+struct ppp_spline_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t n = 0;
+    double miny = 0, bigy = 0;
+    DevBuf<double> knots;   /* y | x | z, n each */
+    DevBuf<double> scratch; /* queries, results */
+    DevBuf<int> flag;
+};
+
+static int spline_fit(ppp_spline sp, size_t n, const double *y, const double *x, const double *z)
+{
+    if (!sp || !y || !x || !z) return PPP_ERR_ARG;
+    if (n < 3 || n > 0x7fffffffu / 8) return PPP_ERR_ARG; /* gsl_spline_alloc: "insufficient number of points for interpolation type" */
+    for (size_t i = 1; i < n; ++i) if (!(y[i - 1] < y[i])) return PPP_ERR_ARG; /* gsl_interp_init: "x values must be strictly increasing" */
+    if (hipSetDevice(sp->device) != hipSuccess) return PPP_ERR_HIP;
+    if (sp->knots.ensure(3 * n) != hipSuccess) return PPP_ERR_HIP;
+    hipError_t e = hipMemcpyAsync(sp->knots.p, y, n * 8, hipMemcpyHostToDevice, sp->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sp->knots.p + n, x, n * 8, hipMemcpyHostToDevice, sp->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sp->knots.p + 2 * n, z, n * 8, hipMemcpyHostToDevice, sp->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(sp->stream); /* the caller's arrays are free again on return, as with GSL */
+    if (e != hipSuccess) return PPP_ERR_HIP;
+    sp->n = n; sp->miny = y[0]; sp->bigy = y[n - 1];
+    return PPP_OK;
+}
+
+int ppp_spline_create(int device_id, size_t n, const double *y, const double *x, const double *z, ppp_spline *out)
+{
+    if (!out) return PPP_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PPP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return PPP_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return PPP_ERR_HIP;
+    ppp_spline sp = new ppp_spline_s();
+    sp->device = device_id;
+    if (hipStreamCreateWithFlags(&sp->stream, hipStreamNonBlocking) != hipSuccess || sp->flag.ensure(1) != hipSuccess) { (void)ppp_spline_destroy(sp); return PPP_ERR_HIP; }
+    int rc = spline_fit(sp, n, y, x, z);
+    if (rc != PPP_OK) { (void)ppp_spline_destroy(sp); return rc; }
+    *out = sp;
+    return PPP_OK;
+}
+
+int ppp_spline_restart(ppp_spline sp, size_t n, const double *y, const double *x, const double *z) { return spline_fit(sp, n, y, x, z); }
+
+int ppp_spline_eval(ppp_spline sp, const double *y, size_t k, double *xyz)
+{
+    if (!sp || sp->n < 3 || (k && (!y || !xyz))) return PPP_ERR_ARG;
+    if (!k) return PPP_OK;
+    if (hipSetDevice(sp->device) != hipSuccess) return PPP_ERR_HIP;
+    if (sp->scratch.ensure(4 * k) != hipSuccess) return PPP_ERR_HIP;
+    double *dq = sp->scratch.p, *dout = dq + k;
+    int flag = 0;
+    hipError_t e = hipMemcpyAsync(dq, y, k * 8, hipMemcpyHostToDevice, sp->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(sp->flag.p, 0, sizeof(int), sp->stream);
+    if (e != hipSuccess) return PPP_ERR_HIP;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_spline_eval_d, dim3((unsigned)((k + 127) / 128)), dim3(128), 0, sp->stream, sp->knots.p, sp->knots.p + sp->n,
+                       sp->knots.p + 2 * sp->n, (int)sp->n, dq, (int)k, dout, sp->flag.p);
+    if (hipGetLastError() != hipSuccess) return PPP_ERR_HIP;
+    e = hipMemcpyAsync(xyz, dout, k * 24, hipMemcpyDeviceToHost, sp->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, sp->flag.p, sizeof(int), hipMemcpyDeviceToHost, sp->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(sp->stream);
+    if (e != hipSuccess) return PPP_ERR_HIP;
+    return flag == DERR_DOMAIN ? PPP_ERR_DOMAIN : PPP_OK;
+}
+
+int ppp_spline_range(ppp_spline sp, double *miny, double *bigy, size_t *n)
+{
+    if (!sp) return PPP_ERR_ARG;
+    if (miny) *miny = sp->miny;
+    if (bigy) *bigy = sp->bigy;
+    if (n) *n = sp->n;
+    return PPP_OK;
+}
+
+int ppp_spline_destroy(ppp_spline sp)
+{
+    if (!sp) return PPP_ERR_ARG;
+    (void)hipSetDevice(sp->device);
+    if (sp->stream) { (void)hipStreamSynchronize(sp->stream); }
+    sp->knots.release(); sp->scratch.release(); sp->flag.release();
+    if (sp->stream) (void)hipStreamDestroy(sp->stream);
+    delete sp;
     return PPP_OK;
 }
 

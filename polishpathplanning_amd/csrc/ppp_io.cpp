@@ -147,13 +147,22 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     f.seekg(data_pos);
     int off = 0, ix = -1, iy = -1, iz = -1;
     for (size_t i = 0; i < fields.size(); ++i) {
+        /* PCL's field sizes are 1, 2, 4 or 8 bytes; a negative or absurd SIZE / COUNT would turn the record offsets below
+           into reads outside the record */
+        const int sz = fields[i].size, cnt = fields[i].count;
+        if (!(sz == 1 || sz == 2 || sz == 4 || sz == 8) || cnt < 0 || cnt > (1 << 20)) return PPP_ERR_IO;
+        const long long step = (long long)sz * std::max(1, cnt);
+        if ((long long)off + step > (1ll << 30)) return PPP_ERR_IO;
         fields[i].offset = off;
-        off += fields[i].size * std::max(1, fields[i].count);
+        off += (int)step;
         if (fields[i].name == "x") ix = (int)i;
         if (fields[i].name == "y") iy = (int)i;
         if (fields[i].name == "z") iz = (int)i;
     }
     if (ix < 0 || iy < 0 || iz < 0) return PPP_ERR_IO;
+    for (int q : {ix, iy, iz}) { /* x, y, z are read as F4 / F8 (or an integer type of their size) from inside the record */
+        if (fields[q].offset < 0 || fields[q].offset + fields[q].size > off) return PPP_ERR_IO;
+    }
     if (data_kind == "binary" && (points > remaining || (size_t)off * points > remaining)) return PPP_ERR_IO;
     if (data_kind == "ascii" && points > remaining) return PPP_ERR_IO; /* a point takes at least one byte */
     uint32_t csize = 0, usize = 0;

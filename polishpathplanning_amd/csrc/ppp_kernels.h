@@ -1369,6 +1369,29 @@ __global__ void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const f
     out[3 * t + 2] = steffen_eval_at(i, mm, y, Yf, Zf);
 }
 
+/* Spline::point(y) on caller-supplied knots (include/Spline.h:10-25: two gsl_interp_steffen splines y->x, y->z over the
+   same strictly increasing y): the same steffen.c restatement as above, on double knots.  Outside [y_0, y_{m-1}] GSL
+   raises GSL_EDOM (and its default handler aborts): NaN + the flag here. */
+__global__ void k_spline_eval_d(const double *__restrict__ ky, const double *__restrict__ kx, const double *__restrict__ kz, int mm,
+                                const double *__restrict__ yq, int kq, double *out, int *flag)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= kq) return;
+    auto Yf = [&](int i) { return ky[i]; };
+    auto Zf = [&](int i) { return kz[i]; };
+    auto Xf = [&](int i) { return kx[i]; };
+    const double y = yq[t];
+    if (mm < 3 || y < ky[0] || y > ky[mm - 1] || !(y == y)) {
+        out[3 * t] = out[3 * t + 1] = out[3 * t + 2] = NAN;
+        *flag = DERR_DOMAIN;
+        return;
+    }
+    const int i = gsl_bsearch(mm, y, Yf);
+    out[3 * t] = steffen_eval_at(i, mm, y, Yf, Xf);
+    out[3 * t + 1] = y;
+    out[3 * t + 2] = steffen_eval_at(i, mm, y, Yf, Zf);
+}
+
 /* ------------------------------------------------------------------ */
 /* a10/a11/a12: nearest cloud point, its normal, pose, hand-eye          */
 /* ------------------------------------------------------------------ */

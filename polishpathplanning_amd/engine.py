@@ -78,6 +78,7 @@ EXPORTS = [
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
+    "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
 ]
 
 
@@ -161,6 +162,11 @@ def lib():
         L.ppp_default_config.restype = None
         L.ppp_read_config.argtypes = [C.c_char_p, C.POINTER(Config)]
         L.ppp_write_path_file.argtypes = [C.c_char_p, fp, sz]
+        L.ppp_spline_create.argtypes = [C.c_int, sz, dp, dp, dp, C.POINTER(vp)]
+        L.ppp_spline_restart.argtypes = [vp, sz, dp, dp, dp]
+        L.ppp_spline_eval.argtypes = [vp, dp, sz, dp]
+        L.ppp_spline_range.argtypes = [vp, dp, dp, szp]
+        L.ppp_spline_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -253,6 +259,51 @@ def sync_batch(engines):
     rc = L.ppp_sync_batch(hs, n, C.byref(bad))
     if rc:
         raise PPPError(rc, "handle %d of the batch: %s" % (bad.value, L.ppp_last_error(engines[bad.value].h).decode()))
+
+
+class Spline:
+    """class Spline of the reference (include/Spline.h:7-51) on caller-supplied knots: two Steffen interpolants y -> x, y -> z
+    evaluated on the device in double (ppp_spline_create / _restart / _eval)."""
+
+    def __init__(self, y, x, z, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        y, x, z = (np.ascontiguousarray(a, np.float64) for a in (y, x, z))
+        rc = self.L.ppp_spline_create(int(device), len(y), _d(y), _d(x), _d(z), C.byref(self.h))
+        if rc:
+            self.h = None
+            raise PPPError(rc, "ppp_spline_create (GSL_EINVAL: fewer than 3 knots or y not strictly increasing)" if rc == ERR_ARG else "ppp_spline_create")
+
+    def restart(self, y, x, z):
+        y, x, z = (np.ascontiguousarray(a, np.float64) for a in (y, x, z))
+        rc = self.L.ppp_spline_restart(self.h, len(y), _d(y), _d(x), _d(z))
+        if rc:
+            raise PPPError(rc, "ppp_spline_restart")
+
+    def point(self, y):
+        """(rc, [k, 3]): Spline::point for every y; rc = ERR_DOMAIN when a y lies outside [miny, bigy] (NaN rows)."""
+        y = np.ascontiguousarray(np.atleast_1d(y), np.float64)
+        out = np.empty((len(y), 3))
+        rc = self.L.ppp_spline_eval(self.h, _d(y), len(y), _d(out))
+        if rc and rc != ERR_DOMAIN:
+            raise PPPError(rc, "ppp_spline_eval")
+        return rc, out
+
+    def range(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_size_t()
+        self.L.ppp_spline_range(self.h, C.byref(a), C.byref(b), C.byref(n))
+        return a.value, b.value, n.value
+
+    def close(self):
+        if self.h:
+            self.L.ppp_spline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:

@@ -59,6 +59,18 @@ for mode in (0, 1, 2):
         else:
             loaded += 1
             assert r.ndim == 2 and r.shape[1] == 3
+# headers whose SIZE / COUNT would move the x, y, z offsets outside the record (negative, zero, huge, overflowing)
+body = pts[:5].tobytes() + b"\0" * 64
+for hdr in ("FIELDS a x y z\nSIZE -8 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n", "FIELDS a x y z\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT -3 1 1 1\n",
+            "FIELDS x y z\nSIZE 0 4 4\nTYPE F F F\nCOUNT 1 1 1\n", "FIELDS a x y z\nSIZE 8 4 4 4\nTYPE F F F F\nCOUNT 2147483647 1 1 1\n",
+            "FIELDS x y z\nSIZE 3 4 4\nTYPE F F F\nCOUNT 1 1 1\n", "FIELDS a x y z\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1073741824 1 1 1\n"):
+    for kind in ("binary", "binary_compressed", "ascii"):
+        payload = body if kind != "ascii" else b"1 2 3 4\n" * 5
+        if kind == "binary_compressed":
+            payload = (60).to_bytes(4, "little") + (60).to_bytes(4, "little") + body
+        open(bad, "wb").write(("VERSION 0.7\n" + hdr + "WIDTH 5\nHEIGHT 1\nPOINTS 5\nDATA " + kind + "\n").encode() + payload)
+        assert load(bad) is None, (hdr, kind)
+        refused += 1
 print("pcd: %d loaded, %d refused" % (loaded, refused))
 
 

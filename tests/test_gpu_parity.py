@@ -180,6 +180,45 @@ def test_eval_spline_api(engine_mod, oracle_mod):
         assert rc == engine_mod.ERR_DOMAIN and np.isnan(got[0]).all() and np.isnan(got[1]).all() and not np.isnan(got[2]).any()
 
 
+def test_spline_class_on_caller_knots(engine_mod, oracle_mod):
+    """include/Spline.h:10-42: Spline(number, y, x, z), point(), miny/bigy, restart() on knots the CALLER supplies (what
+    OnePath / path_track / dynamic_adjust_path do), against the oracle's steffen.c restatement: same doubles."""
+    rng = np.random.default_rng(21)
+    for n in (3, 4, 17, 600):
+        y = np.cumsum(rng.uniform(0.05, 3.0, n)) - 40.0
+        x = 100.0 + np.cumsum(rng.normal(0, 0.3, n)); z = 1500.0 + 30 * np.sin(y / 25.0) + rng.normal(0, 0.2, n)
+        sp = engine_mod.Spline(y, x, z)
+        assert sp.range() == (y[0], y[-1], n)
+        q = np.concatenate([y, np.linspace(y[0], y[-1], 1001), (y[:-1] + y[1:]) / 2])
+        rc, got = sp.point(q)
+        assert rc == 0
+        assert np.array_equal(got[:, 0], oracle_mod.steffen(y, x, q)[1]) and np.array_equal(got[:, 2], oracle_mod.steffen(y, z, q)[1])
+        assert np.array_equal(got[:, 1], q)
+        assert np.array_equal(got[:n, 0], x) and np.array_equal(got[:n, 2], z)          # interpolates its knots
+        rc, got = sp.point([y[0] - 1e-9, y[-1] + 1.0, np.nan, y[1]])                     # GSL_EDOM
+        assert rc == engine_mod.ERR_DOMAIN and np.isnan(got[:3]).all() and not np.isnan(got[3]).any()
+        # restart(): dynamic_adjust_path re-fits the same object on the adjusted knots (path_dynamic_alg.cpp:297-303)
+        y2 = np.cumsum(rng.uniform(0.1, 2.0, n + 5)); x2 = rng.normal(0, 1, n + 5); z2 = rng.normal(0, 1, n + 5)
+        sp.restart(y2, x2, z2)
+        assert sp.range() == (y2[0], y2[-1], n + 5)
+        q2 = np.linspace(y2[0], y2[-1], 333)
+        rc, got = sp.point(q2)
+        assert rc == 0 and np.array_equal(got[:, 0], oracle_mod.steffen(y2, x2, q2)[1]) and np.array_equal(got[:, 2], oracle_mod.steffen(y2, z2, q2)[1])
+        sp.close()
+    # where GSL raises GSL_EINVAL and aborts: fewer than 3 knots, y not strictly increasing
+    for bad_y in ([0.0, 1.0], [0.0, 1.0, 1.0, 2.0], [0.0, 2.0, 1.0]):
+        with pytest.raises(engine_mod.PPPError) as ei:
+            engine_mod.Spline(bad_y, bad_y, bad_y)
+        assert ei.value.code == engine_mod.ERR_ARG
+    # the same knots through a planner slice and through the class give the same curve
+    pts, cfg = synth.make_config("tiny_5k")
+    e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path()
+    ky, kx, kz = e.nodes(3)
+    sp = engine_mod.Spline(ky, kx, kz)
+    q = np.linspace(ky[0], ky[-1], 77)
+    assert np.array_equal(sp.point(q)[1], e.eval_spline(3, q)[1])
+
+
 def test_nearest_and_normals_api(engine_mod, oracle_mod):
     pts, cfg = synth.make_config("small_40k")
     e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
@@ -401,6 +440,49 @@ def test_contour_cli_trims_five_and_uses_its_own_hand_eye(engine_mod, oracle_mod
     o10 = oracle_mod.Oracle(pts, tool_radius=6.0, walk=0)
     o10.gen_path(); o10.get_path()
     assert len(want) > len(o10.waypoints())          # the shorter trim samples more of every path
+
+
+def test_class_surface_in_cpp_dense_band_normals_and_spline(engine_mod, oracle_mod, tmp_path):
+    """examples/api_check: the drop-in C++ classes themselves -- rangedX_index on a band of more than 4096 points (the
+    header's two-call size query), estimate_normal() with the field left readable, and class Spline on caller-supplied
+    knots (constructor, point, restart, copies by value, the GSL error cases)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "api_check"], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(12)
+    x = rng.uniform(0, 70.0, 114000); y = rng.uniform(-78, 78, 114000)      # ~6500 points per 4 mm band
+    pts = (np.stack([x, y, 1500 + 6 * np.sin(x / 30) * np.cos(y / 40)], axis=1) / 1000).astype(np.float32)
+    pcd = str(tmp_path / "dense.pcd")
+    engine_mod.save_pcd(pcd, pts)
+    r = subprocess.run([os.path.join(root, "examples", "api_check"), pcd, "35"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    lines = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln and ln.split()[0] in
+             ("ranged", "normals", "spline", "restart", "copy", "edom", "einval")}
+    e = engine_mod.Engine(0, tool_radius=6.0, pairing=1, walk=3); e.set_cloud(pts)
+    idx = e.ranged_x_index(35)
+    assert len(idx) > 4096 and np.array_equal(idx, oracle_mod.Oracle(pts, tool_radius=6.0).ranged_x_index(35))
+    assert [int(v) for v in lines["ranged"]] == [35, len(idx), int(idx.astype(np.int64).sum()), 1, int(idx[0]), int(idx[-1])]
+    nrm = e.estimate_normals()
+    ok = ~np.isnan(nrm[:, 0])
+    assert int(lines["normals"][0]) == len(pts) and int(lines["normals"][1]) == int((~ok).sum())
+    want = float(np.sum(nrm[ok, 2].astype(np.float64) + 0.5 * nrm[ok, 3].astype(np.float64)))
+    assert abs(float(lines["normals"][2]) - want) <= 1e-6 * max(1.0, abs(want))
+    n = 9
+    i = np.arange(n)
+    ky = -3.0 + 1.25 * i + 0.01 * i * i; kx = 100.0 + 0.5 * i * (i % 3); kz = 1500.0 - 0.75 * i + (i % 2)
+    q = ky[0] + (ky[-1] - ky[0]) * np.arange(17) / 16.0
+    got = np.array([float(v) for v in lines["spline"]])
+    assert got[0] == n and got[1] == ky[0] and got[2] == ky[-1]
+    want = np.stack([oracle_mod.steffen(ky, kx, q)[1], q, oracle_mod.steffen(ky, kz, q)[1]], axis=1).ravel()
+    assert np.array_equal(got[3:], want)
+    y2 = np.array([0.0, 1.0, 2.5, 4.0]); x2 = np.array([1.0, 3.0, 2.0, 5.0]); z2 = np.array([0.0, -1.0, -1.5, 2.0])
+    q2 = 0.5 * np.arange(9)
+    got = np.array([float(v) for v in lines["restart"]])
+    assert got[0] == 4 and got[1] == 0.0 and got[2] == 4.0
+    assert np.array_equal(got[3:], np.stack([oracle_mod.steffen(y2, x2, q2)[1], oracle_mod.steffen(y2, z2, q2)[1]], axis=1).ravel())
+    assert [float(v) for v in lines["copy"]] == [kx[3], kz[3]]                # the copy still holds the first fit
+    assert lines["edom"] == ["1"] and lines["einval"] == ["0"]
+    assert "interpolation error" in r.stderr and "at least 3 knots" in r.stderr
 
 
 @pytest.mark.parametrize("walk", [0, 1, 2, 3, 4])
@@ -696,10 +778,9 @@ def test_batch_of_64_cfg3_workpieces_full_size(engine_mod, oracle_mod):
     engines = []
     for pts in clouds:
         e = engine_mod.Engine(0, tool_radius=6.0); e.set_cloud(pts); engines.append(e)
-    oracles = []
+    oracles, ws = [], []
     for pts in clouds:
-        o = oracle_mod.Oracle(pts, tool_radius=6.0); assert o.gen_path() == 128; o.get_path(); oracles.append(o)
-    ws = [o.num_waypoints() for o in oracles]
+        o = oracle_mod.Oracle(pts, tool_radius=6.0); assert o.gen_path() == 128; ws.append(o.get_path()); oracles.append(o)
     offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
     buf = _DeviceBuffer(sum(ws) * 24)
     for _ in range(3):                                   # capture, then two replays

@@ -332,6 +332,13 @@ def test_hostile_pcd_header_is_an_error_not_a_crash(engine_mod, tmp_path):
         f.write(b"\xff\xff\xff\x7f\x3c\x00\x00\x00" + b"\x00" * 16)      # claims a 2 GiB stream
     with pytest.raises(engine_mod.PPPError):
         engine_mod.load_pcd(str(p))
+    # SIZE / COUNT that would put x, y, z outside the record
+    for hdr in ("FIELDS a x y z\nSIZE -8 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n", "FIELDS a x y z\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT -3 1 1 1\n",
+                "FIELDS x y z\nSIZE 0 4 4\nTYPE F F F\nCOUNT 1 1 1\n", "FIELDS a x y z\nSIZE 8 4 4 4\nTYPE F F F F\nCOUNT 2147483647 1 1 1\n"):
+        p.write_bytes(("VERSION 0.7\n" + hdr + "WIDTH 5\nHEIGHT 1\nPOINTS 5\nDATA binary\n").encode() + b"\0" * 200)
+        with pytest.raises(engine_mod.PPPError) as ei:
+            engine_mod.load_pcd(str(p))
+        assert ei.value.code == engine_mod.ERR_IO
 
 
 def test_read_config_follows_the_reference_parser(engine_mod, tmp_path):
