@@ -33,7 +33,7 @@ int main(int argc, char **argv)
     Spline copy = sp; // by value, like the reference's Path_set.push_back(Spline)
     std::printf("spline %d %.17g %.17g", copy.nodes(), copy.miny(), copy.bigy());
     for (int q = 0; q <= 16; ++q) {
-        const double yq = y[0] + (y[n - 1] - y[0]) * q / 16.0;
+        const double yq = q == 16 ? y[n - 1] : y[0] + (y[n - 1] - y[0]) * q / 16.0; /* (the last sum may round above bigy: GSL_EDOM) */
         Eigen::Vector3d p = copy.point(yq);
         std::printf(" %.17g %.17g %.17g", p[0], p[1], p[2]);
     }

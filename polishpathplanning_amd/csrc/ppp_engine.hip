@@ -81,6 +81,8 @@ struct ppp_handle_s {
 
     /* plan */
     int B = 1, slab_cap = 4096, S_cap = 1, capb = 2048, W_cap = 1, node_cap = 1;
+    int knot_cap = 2048, stage_cap = POSE_STAGE_CAP, pose_threads = POSE_T, cnt_est = 1; /* launch geometry of k_pose (make_plan) */
+    float pose_pad = 8.f;
     float h_mn[3] = {0, 0, 0}, h_mx[3] = {0, 0, 0};
     int h_nvalid = 0;
     /* slice-range handles (SURVEY.md 8e case ii) */
@@ -96,8 +98,14 @@ struct ppp_handle_s {
     bool list_final = false;      /* wp_out holds a finished WayPointsList */
 
     DevBuf<float> X, Y, Z;
+    /* slice-range handles: the points of [incl_lo, incl_hi] in cloud order with their cloud indices (built by make_plan):
+       the hot path streams these instead of the whole cloud */
+    DevBuf<float> Xp, Yp, Zp;
+    DevBuf<int> part_idx;
+    int n_part = 0;
+    bool use_part = false;
     DevBuf<float4> unsorted4, sorted4;
-    DevBuf<int> slab_cnt, slab_start, slab_cursor, coarse_cursor;
+    DevBuf<int> slab_cnt, slab_start, slab_cursor, coarse_cursor, slab_ytab;
     bool two_pass_scatter = false; /* large clouds: coarse bins first (see k_slab_scatter) */
     DevBuf<float> slab_xmin, slab_xmax;
     DevBuf<DevMeta> meta;
@@ -155,8 +163,8 @@ struct ppp_handle_s {
     ~ppp_handle_s()
     {
         (void)hipSetDevice(device);
-        X.release(); Y.release(); Z.release(); unsorted4.release(); sorted4.release();
-        slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_xmin.release(); slab_xmax.release();
+        X.release(); Y.release(); Z.release(); Xp.release(); Yp.release(); Zp.release(); part_idx.release(); unsorted4.release(); sorted4.release();
+        slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_ytab.release(); slab_xmin.release(); slab_xmax.release();
         meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
         normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
@@ -188,6 +196,8 @@ struct BatchGraph {
     /* batched form (one launch per stage over all members): the members' records and meta blocks */
     bool batched = false, eager = false; /* eager: launched directly every time (kernel timing), no graph */
     int maxB = 1, max_slab_cap = 2048, max_capb = 1024; /* launch geometry over all members */
+    int pose_threads = 256, slice_thr = SLICE_KD_T;
+    size_t pose_lds = 0;
     int gx_mm = 1, gx_scat = 1, gx_sort = 1, gx_slice = 1, gx_pose = 1, gx_smooth = 1;
     bool full_slabs = false, ppt8 = false;
     DevBuf<BatchMember> members;
@@ -233,6 +243,8 @@ DevParams dev_params(const ppp_handle h)
     D.smooth = h->P.smooth; D.smooth_max_sweeps = h->P.smooth_max_sweeps;
     D.slice_begin = h->P.slice_begin; D.slice_end = h->P.slice_end; D.ranged = h->ranged ? 1 : 0;
     D.incl_lo = h->incl_lo; D.incl_hi = h->incl_hi;
+    D.bounds_given = h->use_part ? 1 : 0; D.g_nvalid = h->h_nvalid;
+    for (int d = 0; d < 3; ++d) { D.g_mn[d] = h->h_mn[d]; D.g_mx[d] = h->h_mx[d]; }
     {   /* mean spacing of a sheet-like cloud from its bounding rectangle; only a search hint, never a cut-off */
         const double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
         const double spacing = (area > 0 && h->h_nvalid > 0) ? std::sqrt(area / h->h_nvalid) : 1.0;
@@ -373,6 +385,36 @@ int make_plan(ppp_handle h)
             h->n_range = range > 0 ? (int)std::min((double)h->h_nvalid, std::max(0.0, part / range) * h->h_nvalid * 1.05 + 64) : h->h_nvalid;
         }
     }
+    h->use_part = false; h->n_part = 0;
+    if (h->ranged && h->sb < h->se && n > 0) {
+        /* the range's own points, once per plan: the hot path then streams n_part instead of n points (the bounds, the
+           walk and the slab grid stay the whole cloud's: they come from the values cached with the cloud) */
+        const int nblocks = (n + VOX_CHUNK - 1) / VOX_CHUNK;
+        DevBuf<int> bcnt;
+        DevBuf<VoxStats> st;
+        hipError_t e = bcnt.ensure(nblocks);
+        if (e == hipSuccess) e = st.ensure(1);
+        if (e != hipSuccess) { bcnt.release(); st.release(); return fail(h, PPP_ERR_HIP, std::string("range part: ") + hipGetErrorString(e)); }
+        VoxStats hst{0};
+        auto run = [&]() -> int {
+            LAUNCH(h, "k_part_count", k_part_count, nblocks, 256, 0, h->X.p, n, h->incl_lo, h->incl_hi, bcnt.p);
+            LAUNCH(h, "k_vox_scan", k_vox_scan, 1, 1024, 0, bcnt.p, nblocks, st.p);
+            HIPCHK(h, hipMemcpyAsync(&hst, st.p, sizeof(VoxStats), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const size_t np = (size_t)std::max(hst.n_out, 1);
+            HIPCHK(h, h->Xp.ensure(np)); HIPCHK(h, h->Yp.ensure(np)); HIPCHK(h, h->Zp.ensure(np)); HIPCHK(h, h->part_idx.ensure(np));
+            LAUNCH(h, "k_part_compact", k_part_compact, nblocks, 256, 0, h->X.p, h->Y.p, h->Z.p, n, h->incl_lo, h->incl_hi, bcnt.p, h->Xp.p,
+                   h->Yp.p, h->Zp.p, h->part_idx.p);
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            return PPP_OK;
+        };
+        const int rcp = run();
+        bcnt.release(); st.release();
+        if (rcp != PPP_OK) return rcp;
+        h->n_part = hst.n_out;
+        h->n_range = hst.n_out;
+        h->use_part = true;
+    }
     /* x-slabs: the histogram must fit LDS.  A slice-range handle
        keeps the WHOLE cloud's slab grid and just leaves the slabs outside its interval empty: its slabs then hold
        the same points in the same order as a whole-cloud handle's, so every sum over neighbours (normals) adds
@@ -390,7 +432,7 @@ int make_plan(ppp_handle h)
         h->slab_cap = cap;
     }
     HIPCHK(h, h->big_slabs.ensure(B));
-    h->mm_grid = std::max(1, std::min((n / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
+    h->mm_grid = std::max(1, std::min(((h->use_part ? h->n_part : n) / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
     HIPCHK(h, h->mm_part.ensure(h->mm_grid));
     h->S_cap = std::max(1, S);
     HIPCHK(h, h->big_slices.ensure(h->S_cap));
@@ -406,6 +448,21 @@ int make_plan(ppp_handle h)
     /* waypoints: every kept slice samples at most (yrange - 2 trim)/res + 1 points */
     double yr = (double)h->h_mx[1] - (double)h->h_mn[1];
     double per = std::max(0.0, (yr - 2 * h->P.trim)) / h->P.path_resolution + 2.0;
+    {   /* k_pose: what a workgroup stages in LDS.  Knots: a slice has at most one per left band point (half the band, twice
+           over).  Points: the slabs that overlap [Px - pad, Px + pad] span at most 2 pad + 2 slab widths; pad covers the
+           nearest point (within a grid spacing of the plane) plus the normal's radius -- more when the dynamic adjustment
+           moves knots off their plane.  Both are capacities of a fast path: what does not fit is read from global memory. */
+        h->knot_cap = std::max(256, capb / 2);
+        h->pose_pad = h->P.dynamic_adjustment ? 8.f : std::max(5.f, 2.f * h->P.normal_radius);
+        const double slab_w = range > 0 ? range / B : 0.0;
+        const double rho = range > 0 ? (double)h->h_nvalid / range : (double)h->h_nvalid;
+        const double want = 1.1 * rho * (2.0 * h->pose_pad + 2.0 * slab_w) + 128;
+        h->stage_cap = (int)std::min<double>(POSE_STAGE_CAP, std::max(512.0, 256.0 * std::ceil(want / 256.0)));
+        h->cnt_est = (int)std::min(1.0e6, per);
+        int t = 256;
+        while (t < POSE_T && t < h->cnt_est * pose_lanes(h->cnt_est)) t <<= 1;
+        h->pose_threads = t;
+    }
     double wc = per * (double)h->S_cap;
     if (wc > 2.0e8) return fail(h, PPP_ERR_CAPACITY, "waypoint bound too large");
     h->W_cap = std::max(1, (int)wc);
@@ -417,6 +474,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->unsorted4.ensure(n)); HIPCHK(h, h->sorted4.ensure(n));
     HIPCHK(h, h->slab_cnt.ensure(B)); HIPCHK(h, h->slab_start.ensure(B + 1)); HIPCHK(h, h->slab_cursor.ensure(B));
     HIPCHK(h, h->coarse_cursor.ensure((B >> SCAT_COARSE_SHIFT) + 2));
+    HIPCHK(h, h->slab_ytab.ensure((size_t)B * (YTB + 1)));
     /* one scatter pass leaves runs of chunk / B points: below ~4 points per run the second pass pays for itself */
     h->two_pass_scatter = B >= 4096 && h->n_range >= 3000000;
     HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream)); /* every run leaves it cleared again */
@@ -443,10 +501,23 @@ int make_plan(ppp_handle h)
     return PPP_OK;
 }
 
+/* Threads of a k_slice_kd workgroup.  One workgroup per slice with the band in LDS: 1024 threads finish a slice soonest
+   (one round of nearest-neighbour queries for bands of up to 2048 points), and that is what counts while the slices of a
+   launch fit the GPU in one go.  With several times more slices than CUs (batches of workpieces) two 512-thread
+   workgroups per CU get more slices through -- if two bands fit the CU's LDS. */
+int slice_threads(const ppp_handle h, long long slices_in_launch)
+{
+    const bool two_fit = 2 * (slice_kd_bytes(h->capb) + 1024) <= (size_t)h->max_lds;
+    return (two_fit && slices_in_launch >= 2LL * h->num_cus) ? 512 : SLICE_KD_T;
+}
+
 /* a2 + a3 + the x-slab index (generalised slice binning) */
 int enqueue_index(ppp_handle h)
 {
-    const int n = (int)h->n;
+    /* a slice-range handle streams its own part of the cloud (make_plan), everything else the whole cloud */
+    const int n = h->use_part ? h->n_part : (int)h->n;
+    const float *sX = h->use_part ? h->Xp.p : h->X.p, *sY = h->use_part ? h->Yp.p : h->Y.p, *sZ = h->use_part ? h->Zp.p : h->Z.p;
+    const int *idmap = h->use_part ? h->part_idx.p : nullptr;
     DevParams D = dev_params(h);
     size_t hist_lds = sizeof(int) * (size_t)h->B;
     /* slab grid from the bounds cached when the cloud was set (identical to what k_minmax finds) */
@@ -457,7 +528,7 @@ int enqueue_index(ppp_handle h)
            cloud).  At most PPP_MM_GRID_MAX workgroups: each flushes its LDS histogram with one global atomic per non-empty slab, and
            that flush, not the streaming, is what grows with the grid. */
         const int gf = std::max(1, std::min(h->mm_grid, PPP_MM_GRID_MAX));
-        LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, h->X.p, h->Y.p, h->Z.p, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
+        LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, sX, sY, sZ, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
                h->incl_lo, h->incl_hi);
         h->mm_grid_used = gf;
     }
@@ -472,28 +543,28 @@ int enqueue_index(ppp_handle h)
     const int gs = std::max(1, (n + chunk - 1) / chunk);
     if (!h->two_pass_scatter) {
         if (ppt8)
-            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 8>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
-                   h->slab_cursor.p, h->unsorted4.p);
+            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 8>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
+                   h->slab_cursor.p, h->unsorted4.p, idmap);
         else
-            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 4>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
-                   h->slab_cursor.p, h->unsorted4.p);
+            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 4>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
+                   h->slab_cursor.p, h->unsorted4.p, idmap);
     } else {
         /* coarse bins into sorted4 (free until k_slab_sort writes it), then from there into the slabs */
-        LAUNCH(h, "k_slab_scatter", (k_slab_scatter<1, 8>), gs, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)nullptr, n, h->meta.p,
-               h->coarse_cursor.p, h->sorted4.p);
+        LAUNCH(h, "k_slab_scatter", (k_slab_scatter<1, 8>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
+               h->coarse_cursor.p, h->sorted4.p, idmap);
         const int gs2 = std::max(1, (n + 4 * SCAT_T - 1) / (4 * SCAT_T));
-        LAUNCH(h, "k_slab_scatter2", (k_slab_scatter<2, 4>), gs2, SCAT_T, hist_lds, h->X.p, h->Y.p, h->Z.p, (const float4 *)h->sorted4.p, n,
-               h->meta.p, h->slab_cursor.p, h->unsorted4.p);
+        LAUNCH(h, "k_slab_scatter2", (k_slab_scatter<2, 4>), gs2, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)h->sorted4.p, n,
+               h->meta.p, h->slab_cursor.p, h->unsorted4.p, (const int *)nullptr);
     }
     size_t sort_lds = (size_t)h->slab_cap * 12 + 16;
     /* threads per slab: 256 while a slab holds the planned 832 points on average (more slabs in flight per CU: cfg 2 sorts in
        15.3 us against 17.0), SORT_T for the fuller slabs of clouds beyond the 8192-slab cap (cfg 5: 125 us against 157) */
     const int sort_threads = (h->B > 0 && h->h_nvalid / h->B > 1000) ? SORT_T : 256;
     LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, sort_threads, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
+           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p);
     if (h->big_path)
         LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, SORT_T, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap);
+               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p);
     h->index_built = true;
     return PPP_OK;
 }
@@ -1171,7 +1242,7 @@ int ppp_gen_path_async(ppp_handle h)
     int rc = enqueue_index(h);
     if (rc) return rc;
     if (h->P.pairing == PPP_PAIR_KD) {
-        LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, SLICE_KD_T, slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
+        LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, slice_threads(h, h->S_cap), slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
                h->px.p, h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
         if (h->big_path)
@@ -1221,17 +1292,17 @@ int ppp_get_path_async(ppp_handle h)
         if (h->ranged) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment with a slice range");
         if (!h->back || !h->back->index_built) return fail(h, PPP_ERR_ARG, "aligned cloud without its sensor-frame index");
         PB.sorted4 = h->back->sorted4.p; PB.slab_start = h->back->slab_start.p; PB.slab_xmin = h->back->slab_xmin.p; PB.slab_xmax = h->back->slab_xmax.p;
-        PB.m = h->back->meta.p;
+        PB.m = h->back->meta.p; PB.ytab = h->back->slab_ytab.p;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) PB.inv[r][c] = h->invTA[r][c];
-        LAUNCH(h, "k_pose<aligned>", k_pose<true>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+        LAUNCH(h, "k_pose<aligned>", k_pose<true>, nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
                h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
-               h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
-               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB);
+               h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad,
+               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
     } else
-    LAUNCH(h, "k_pose", k_pose<false>, nk, POSE_T, pose_lds_bytes(h->capb), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+    LAUNCH(h, "k_pose", k_pose<false>, nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
-           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->capb,
-           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB);
+           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad,
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
     h->path_done = true;
     h->list_final = false;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
@@ -1331,6 +1402,8 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
     int &gx_mm = bg->gx_mm, &gx_scat = bg->gx_scat, &gx_sort = bg->gx_sort, &gx_slice = bg->gx_slice, &gx_pose = bg->gx_pose, &gx_smooth = bg->gx_smooth;
     bool &full_slabs = bg->full_slabs, &ppt8 = bg->ppt8;
     int max_n = 0;
+    long long slices_total = 0;
+    bg->pose_threads = 256; bg->pose_lds = 0;
     for (size_t i = 0; i < count; ++i) max_n = std::max(max_n, (int)bg->hs[i]->n);
     ppt8 = max_n > PPP_PPT8_FROM;
     const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
@@ -1348,6 +1421,10 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
         M.slab_x0 = h->h_mn[0]; M.slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f; /* as enqueue_index */
         M.incl_lo = h->incl_lo; M.incl_hi = h->incl_hi;
         M.B = h->B; M.S_cap = h->S_cap; M.slab_cap = h->slab_cap; M.capb = h->capb; M.node_cap = h->node_cap; M.W_cap = h->W_cap;
+        M.knot_cap = h->knot_cap; M.stage_cap = h->stage_cap; M.pose_pad = h->pose_pad;
+        bg->pose_threads = std::max(bg->pose_threads, h->pose_threads);
+        bg->pose_lds = std::max(bg->pose_lds, pose_lds_bytes(h->knot_cap, h->stage_cap));
+        slices_total += h->S_cap;
         M.out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
         M.out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
         M.g_minmax = std::max(1, std::min(std::min(h->mm_grid, PPP_MM_GRID_MAX), mm_share));
@@ -1361,12 +1438,17 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
         M.node_start = h->node_start.p; M.node_cnt = h->node_cnt.p; M.band_cnt = h->band_cnt.p;
         M.wp_cnt = h->wp_cnt.p; M.wp_off = h->wp_off.p; M.tail = h->tail.p;
         M.wp_xyz = h->wp_xyz.p; M.wp_normal = h->wp_normal.p; M.wp_nn = h->wp_nn.p;
-        M.wp_pre = h->wp_pre.p; M.wp_smooth = h->wp_smooth.p; M.wp_out = h->wp_out.p;
+        M.wp_pre = h->wp_pre.p; M.wp_smooth = h->wp_smooth.p; M.wp_out = h->wp_out.p; M.ytab = h->slab_ytab.p;
         h->mm_grid_used = M.g_minmax;
         maxB = std::max(maxB, h->B); max_slab_cap = std::max(max_slab_cap, h->slab_cap); max_capb = std::max(max_capb, h->capb);
         full_slabs = full_slabs || (h->B > 0 && h->h_nvalid / h->B > 1000);
         gx_mm = std::max(gx_mm, M.g_minmax); gx_scat = std::max(gx_scat, M.g_scatter); gx_sort = std::max(gx_sort, M.g_sort);
         gx_slice = std::max(gx_slice, M.g_slice); gx_pose = std::max(gx_pose, M.g_pose); gx_smooth = std::max(gx_smooth, M.g_smooth);
+    }
+    {   /* two 512-thread slice workgroups per CU when every member's band leaves room for two (see slice_threads) */
+        bool two_fit = true;
+        for (size_t i = 0; i < count; ++i) two_fit = two_fit && 2 * (slice_kd_bytes(bg->hs[i]->capb) + 1024) <= (size_t)lead->max_lds;
+        bg->slice_thr = (two_fit && slices_total >= 2LL * lead->num_cus) ? 512 : SLICE_KD_T;
     }
     HIPCHK(lead, copy_sync(lead, bg->members.p, mem.data(), sizeof(BatchMember) * count, hipMemcpyHostToDevice));
     return PPP_OK;
@@ -1386,9 +1468,13 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
     if (ppt8) LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
     else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
     LAUNCHB(lead, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, bg->members.p);
-    LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), SLICE_KD_T, slice_kd_bytes(max_capb), bg->members.p);
-    LAUNCHB(lead, "k_pose_b", k_pose_b, dim3(gx_pose, gy), POSE_T, pose_lds_bytes(max_capb), bg->members.p);
+    LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), bg->members.p);
+    LAUNCHB(lead, "k_pose_b", k_pose_b, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
     LAUNCHB(lead, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, bg->members.p);
+    if (count == 1) { /* nothing to collect: the one meta block goes straight to the host */
+        HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->hs[0]->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, lead->stream));
+        return PPP_OK;
+    }
     LAUNCHB(lead, "k_collect_meta", k_collect_meta, dim3(gy), 64, 0, bg->members.p, (int)count, bg->metas.p);
     HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->metas.p, sizeof(DevMeta) * count, hipMemcpyDeviceToHost, lead->stream));
     return PPP_OK;

@@ -33,6 +33,7 @@ struct DevMeta {
     int sb, se;              /* slice range of this handle: [sb, se) */
     float incl_lo, incl_hi;  /* x interval of the points this handle indexes */
     int n_sorted;            /* points in the slab index */
+    float ytab_scale;        /* y-bucket table of the slabs: bucket(y) = (int)((y - mn[1]) * ytab_scale), clamped to [0, YTB) */
 };
 
 struct DevParams {
@@ -44,6 +45,10 @@ struct DevParams {
     int slice_begin, slice_end, ranged;
     float incl_lo, incl_hi;
     float nn_hint2; /* (a few mean point spacings)^2: first search bound of the waypoints' 1-NN queries */
+    /* a slice-range handle streams only its part of the cloud: the whole cloud's bounds and point count (what getMinMax3D
+       gives the reference, and what the walk and the slab grid are built from) come with the plan */
+    int bounds_given, g_nvalid;
+    float g_mn[3], g_mx[3];
 };
 
 #define SCAT_COARSE_SHIFT 6 /* two-pass scatter of large clouds: 64 neighbouring slabs form a coarse bin */
@@ -62,6 +67,19 @@ __device__ inline int slab_of(const DevMeta *m, float x)
     return b >= m->B ? m->B - 1 : b;
 }
 __device__ inline int idx_of(const float4 &p) { return __float_as_int(p.w); }
+
+/* Per-slab y-bucket table (k_slab_sort writes it, the waypoint searches of k_pose read it): entry q of slab b is the number
+   of the slab's points -- sorted by (y, index) -- whose bucket is below q, for YTB uniform buckets over the cloud's y range;
+   entry YTB is the slab's population.  bucket() is monotone in y, so the lower bound of any y lies inside its own bucket:
+   a search is one table look-up plus a binary search over that bucket's few points instead of over the whole slab
+   (ten dependent reads become three).  Exactness never depends on the table: it only narrows the first interval. */
+#define YTB 128
+__device__ inline int ytab_bucket(const DevMeta *m, float y)
+{
+    int q = (int)((y - m->mn[1]) * m->ytab_scale);
+    q = q < 0 ? 0 : q;
+    return q >= YTB ? YTB - 1 : q;
+}
 
 /* ------------------------------------------------------------------ */
 /* a1: constructor scaling (path_slicing_alg.cpp:14-24).  Non-finite   */
@@ -262,6 +280,7 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
     __shared__ int s_S, s_total, s_nfront, s_c;
     __shared__ float s_mid;
     __shared__ float s_front[4096];
+    __shared__ int s_cnts[8192]; /* the slab histogram (make_plan caps B at 8192) */
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
     STAMP_BEGIN();
@@ -276,22 +295,26 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
     if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
     STAMP(5, 0); /* partials */
     /* exclusive scan of the slab histogram (k_minmax<true> filled it) -> CSR offsets + scatter
-       cursors; the histogram is cleared for the next run */
+       cursors; the histogram is cleared for the next run.  The counts come into LDS with coalesced loads (B <= 8192), are
+       scanned there, and go out coalesced: a thread reading its own run of counts from global one after the other was 80 %
+       of this kernel at 8192 slabs. */
     {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) { s_cnts[i] = slab_cnt[i]; slab_cnt[i] = 0; }
+        __syncthreads();
         const int per = (B + blockDim.x - 1) / blockDim.x;
         const int b0 = threadIdx.x * per;
         int sum = 0;
-        for (int k = 0; k < per; ++k) if (b0 + k < B) sum += slab_cnt[b0 + k];
+        for (int k = 0; k < per; ++k) if (b0 + k < B) sum += s_cnts[b0 + k];
         int total;
         int pre = block_exscan(sum, s_scan, &total);
         for (int k = 0; k < per; ++k) {
-            if (b0 + k < B) {
-                int c = slab_cnt[b0 + k];
-                slab_start[b0 + k] = pre; slab_cursor[b0 + k] = pre;
-                if (coarse_cursor && ((b0 + k) & ((1 << SCAT_COARSE_SHIFT) - 1)) == 0) coarse_cursor[(b0 + k) >> SCAT_COARSE_SHIFT] = pre;
-                pre += c;
-                slab_cnt[b0 + k] = 0;
-            }
+            if (b0 + k < B) { const int c = s_cnts[b0 + k]; s_cnts[b0 + k] = pre; pre += c; }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < B; i += blockDim.x) {
+            const int v = s_cnts[i];
+            slab_start[i] = v; slab_cursor[i] = v;
+            if (coarse_cursor && (i & ((1 << SCAT_COARSE_SHIFT) - 1)) == 0) coarse_cursor[i >> SCAT_COARSE_SHIFT] = v;
         }
         if (threadIdx.x == 0) { slab_start[B] = total; s_total = total; }
     }
@@ -307,8 +330,10 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
             /* getMinMax3D starts from +-FLT_MAX */
             r.mn[d] = c ? a : 3.402823466e+38f;
             r.mx[d] = c ? b : -3.402823466e+38f;
+            if (P.bounds_given) { r.mn[d] = P.g_mn[d]; r.mx[d] = P.g_mx[d]; } /* this launch saw the handle's part only */
             r.mn_ord[d] = f2ord(r.mn[d]); r.mx_ord[d] = f2ord(r.mx[d]);
         }
+        if (P.bounds_given) c = P.g_nvalid;
         r.n_valid = c;
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
         r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1; r.emit_ticket = 0;
@@ -339,6 +364,7 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
         r.se = (P.slice_end <= 0 || P.slice_end > S) ? S : P.slice_end;
         r.incl_lo = P.incl_lo; r.incl_hi = P.incl_hi;
         r.n_sorted = s_total;
+        { const float yr = r.mx[1] - r.mn[1]; r.ytab_scale = (c && yr > 0.f) ? (float)YTB / yr : 0.f; }
         *m = r;
         s_S = S;
     }
@@ -372,7 +398,7 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
 template <int LEVEL, int PPT>
 __device__ __forceinline__ void slab_scatter_body(const float *__restrict__ X, const float *__restrict__ Y,
                                                   const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
-                                                  const DevMeta *m, int *cursor, float4 *out4, const int bx)
+                                                  const DevMeta *m, int *cursor, float4 *out4, const int *__restrict__ idmap, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     const int B = LEVEL == 1 ? ((m->B + (1 << SCAT_COARSE_SHIFT) - 1) >> SCAT_COARSE_SHIFT) : m->B;
@@ -390,7 +416,7 @@ __device__ __forceinline__ void slab_scatter_body(const float *__restrict__ X, c
         pb[k] = -1;
         if (i < n) {
             if (LEVEL == 2) p[k] = in4[i];
-            else p[k] = make_float4(X[i], Y[i], Z[i], __int_as_float(i));
+            else p[k] = make_float4(X[i], Y[i], Z[i], __int_as_float(idmap ? idmap[i] : i)); /* idmap: cloud indices of a part */
         } else p[k] = make_float4(NAN, 0.f, 0.f, 0.f);
     }
     for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
@@ -426,7 +452,7 @@ __device__ __forceinline__ void slab_scatter_body(const float *__restrict__ X, c
 template <bool ARENA>
 __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                               int *big_list, char *arena, unsigned long long arena_cap, const int bx)
+                                               int *big_list, char *arena, unsigned long long arena_cap, int *ytab, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ float s_mn[SORT_T / 64], s_mx[SORT_T / 64];
@@ -475,11 +501,20 @@ __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsort
             return idx_of(src[YK_POS(a)]) < idx_of(src[YK_POS(bb)]); /* equal y: cloud index */
         };
         block_bucket_sort(key, c, hist, NB, s_scr, gen, bucket, less);
+        int *tab = ytab ? ytab + (size_t)b * (YTB + 1) : nullptr;
         for (int i = threadIdx.x; i < c; i += blockDim.x) {
             float4 p = src[YK_POS(key[i])];
             sorted4[s0 + i] = p;
             mn = fminf(mn, p.x); mx = fmaxf(mx, p.x);
+            if (tab) { /* the table entries between the previous point's bucket and this point's: i points lie below them */
+                const int bi = ytab_bucket(m, p.y);
+                const int bp = i > 0 ? ytab_bucket(m, ord2f(YK_Y(key[i - 1]))) : -1;
+                for (int q = bp + 1; q <= bi; ++q) tab[q] = i;
+                if (i == c - 1) for (int q = bi + 1; q <= YTB; ++q) tab[q] = c;
+            }
         }
+    } else if (ytab) {
+        for (int q = threadIdx.x; q <= YTB; q += blockDim.x) ytab[(size_t)b * (YTB + 1) + q] = 0;
     }
     mn = wave_min(mn); mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
@@ -1403,7 +1438,21 @@ struct SlabView {
     /* optional LDS copy of sorted4[lds_lo, lds_hi) (the slabs around one slice) */
     const float4 *lds;
     int lds_lo, lds_hi;
+    /* optional y-bucket table of the slabs (YTB + 1 ints per slab) and an LDS copy of the rows of slabs [tab_lo, tab_hi) */
+    const int *ytab = nullptr;
+    const int *lds_tab = nullptr;
+    int tab_lo = 0, tab_hi = 0;
     __device__ inline float4 at(int i) const { return (i >= lds_lo && i < lds_hi) ? lds[i - lds_lo] : sorted4[i]; }
+    /* [lo, hi) inside slab bb = [s0, s1) that holds the lower bound of qy */
+    __device__ inline void narrow(int bb, int s0, int s1, float qy, int &lo, int &hi) const
+    {
+        lo = s0; hi = s1;
+        if (ytab) {
+            const int *T = (bb >= tab_lo && bb < tab_hi) ? lds_tab + (bb - tab_lo) * (YTB + 1) : ytab + (size_t)bb * (YTB + 1);
+            const int q = ytab_bucket(m, qy);
+            lo = s0 + T[q]; hi = s0 + T[q + 1];
+        }
+    }
 };
 
 /* first position in [s0,s1) whose y >= qy */
@@ -1611,7 +1660,8 @@ __device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, flo
                         /* the staged window covers this slab almost always: then every read is an LDS read and the
                            per-access "LDS or global?" test of SlabView::at leaves the loops */
                         auto scan = [&](auto at) {
-                            int lo = s0, hi = s1;
+                            int lo, hi;
+                            V.narrow(bb, s0, s1, qy, lo, hi);
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < qy) lo = mid + 1; else hi = mid; }
                             const int p = lo;
                             for (int i = p; i < s1; ++i) {
@@ -1678,7 +1728,8 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
                     if (dx > 0.f && dx * dx > r2) { if (so > 0) rc = 1; else lc = 1; }
                     else {
                         auto scan = [&](auto at) { /* LDS-only reads when the staged window covers the slab (see the NN scan) */
-                            int lo = s0, hi = s1;
+                            int lo, hi;
+                            V.narrow(bb, s0, s1, p.y, lo, hi);
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < p.y) lo = mid + 1; else hi = mid; }
                             const int q0 = lo;
                             for (int i = q0; i < s1; ++i) {
@@ -1747,12 +1798,13 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
    round trips; anything outside the staged window falls back to the global copy (exactness
    never depends on the window). */
 #ifndef POSE_STAGE_CAP
-#define POSE_STAGE_CAP 5120
+#define POSE_STAGE_CAP 5120 /* most points a workgroup stages; the plan asks for what the slab grid and the density need */
 #endif
-#ifndef POSE_PAD
-#define POSE_PAD 8.0f
-#endif
-__host__ __device__ inline size_t pose_lds_bytes(int capb) { return (size_t)POSE_STAGE_CAP * 16 + (size_t)capb * 12; }
+#define POSE_TAB_SLABS 12 /* y-bucket rows staged beside the points (more slabs than that: the rows are read from global) */
+__host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap) { return (size_t)stage_cap * 16 + (size_t)knot_cap * 12; }
+/* lanes per waypoint (the two searches walk G slabs side by side): a function of the slice's waypoint count ONLY, so the
+   partial sums of the normals -- and with them the last bits of the list -- do not depend on the launch geometry */
+__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= 512 ? 2 : 1); }
 
 #ifndef POSE_T
 #define POSE_T 1024
@@ -1769,6 +1821,7 @@ struct PoseBack {
     const float *slab_xmin, *slab_xmax;
     const DevMeta *m;
     float inv[3][4];
+    const int *ytab;
 };
 template <bool ALIGNED>
 __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const float4 *__restrict__ sorted4,
@@ -1777,16 +1830,18 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
                                           const float *__restrict__ node_x, const float *__restrict__ node_y,
                                           const float *__restrict__ node_z,
                                           const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                          int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
-                                          float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back, const int bx)
+                                          int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
+                                          float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back,
+                                          const int *__restrict__ ytab, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     float4 *s_pts = (float4 *)s_raw;
-    float *s_ny = (float *)(s_pts + POSE_STAGE_CAP);
-    float *s_nz = s_ny + capb;
-    float *s_nx = s_nz + capb;
+    float *s_ny = (float *)(s_pts + stage_cap);
+    float *s_nz = s_ny + knot_cap;
+    float *s_nx = s_nz + knot_cap;
     __shared__ int s_scan[17];
     __shared__ int s_mycnt, s_myoff, s_run;
+    __shared__ int s_tab[POSE_TAB_SLABS * (YTB + 1)];
     const int k = bx;
     const int nk = m->nkept;
     if (m->err || k >= nk) return;
@@ -1828,20 +1883,28 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     const float Px = px[s];
     STAMP_BEGIN();
     /* slabs to stage: widest symmetric range around the plane's slab that fits */
-    int bL = slab_of(m, Px - POSE_PAD), bR = slab_of(m, Px + POSE_PAD);
-    while (slab_start[bR + 1] - slab_start[bL] > POSE_STAGE_CAP && bL < bR) {
+    int bL = slab_of(m, Px - pad), bR = slab_of(m, Px + pad);
+    while (slab_start[bR + 1] - slab_start[bL] > stage_cap && bL < bR) {
         const int bc = slab_of(m, Px);
         if (bR - bc >= bc - bL) --bR; else ++bL;
     }
     int lds_lo = slab_start[bL], lds_hi = slab_start[bR + 1];
-    if (lds_hi - lds_lo > POSE_STAGE_CAP || ALIGNED) lds_hi = lds_lo; /* one over-full slab: no staging (nor for the other frame's index) */
+    if (lds_hi - lds_lo > stage_cap || ALIGNED) lds_hi = lds_lo; /* one over-full slab: no staging (nor for the other frame's index) */
     for (int i = lds_lo + threadIdx.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
-    const bool nodes_in_lds = mm <= capb;
+    /* ... and the y-bucket rows of the staged slabs */
+    const int *yt = ALIGNED ? back.ytab : ytab;
+    int tab_lo = 0, tab_hi = 0;
+    if (yt && lds_hi > lds_lo && bR - bL + 1 <= POSE_TAB_SLABS) {
+        tab_lo = bL; tab_hi = bR + 1;
+        for (int i = threadIdx.x; i < (tab_hi - tab_lo) * (YTB + 1); i += blockDim.x) s_tab[i] = yt[(size_t)tab_lo * (YTB + 1) + i];
+    }
+    const bool nodes_in_lds = mm <= knot_cap;
     if (nodes_in_lds)
         for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; s_nx[i] = node_x[st + i]; }
     __syncthreads();
     STAMP(1, 0); /* staging */
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
+    V.ytab = yt; V.lds_tab = s_tab; V.tab_lo = tab_lo; V.tab_hi = tab_hi;
     if (ALIGNED) { V.sorted4 = back.sorted4; V.slab_start = back.slab_start; V.slab_xmin = back.slab_xmin; V.slab_xmax = back.slab_xmax; V.m = back.m; }
     const float *ny = nodes_in_lds ? s_ny : node_y + st, *nz = nodes_in_lds ? s_nz : node_z + st;
     const float *nx = nodes_in_lds ? s_nx : node_x + st; /* the plane x, or cloud x after the dynamic adjustment */
@@ -1904,10 +1967,8 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
             STAMP(1, 4); /* pose + hand-eye */
         }
     };
-    int G = 1;
-    while (G < POSE_GMAX && cnt * (2 * G) <= (int)blockDim.x) G *= 2;
-    if (G == 8) run(std::integral_constant<int, 8>{});
-    else if (G == 4) run(std::integral_constant<int, 4>{});
+    const int G = pose_lanes(cnt);
+    if (G == 4) run(std::integral_constant<int, 4>{});
     else if (G == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
 }
@@ -2211,7 +2272,8 @@ struct BatchMember {
     int n;
     MinMaxPart *mm_part;
     float slab_x0, slab_invw, incl_lo, incl_hi;
-    int B, S_cap, slab_cap, capb, node_cap, W_cap, out2_cap;
+    int B, S_cap, slab_cap, capb, node_cap, W_cap, out2_cap, knot_cap, stage_cap;
+    float pose_pad;
     int g_minmax, g_scatter, g_sort, g_slice, g_pose, g_smooth; /* workgroups of this member per stage */
     int *slab_cnt, *slab_start, *slab_cursor, *coarse_cursor;
     float *px, *lo, *hi;
@@ -2224,6 +2286,7 @@ struct BatchMember {
     float4 *wp_xyz, *wp_normal;
     int *wp_nn;
     float *wp_pre, *wp_smooth, *wp_out, *out2;
+    int *ytab;
 };
 
 __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
@@ -2235,16 +2298,16 @@ __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, cons
 template <int LEVEL, int PPT>
 __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
                                                       const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
-                                                      const DevMeta *m, int *cursor, float4 *out4)
+                                                      const DevMeta *m, int *cursor, float4 *out4, const int *idmap)
 {
-    slab_scatter_body<LEVEL, PPT>(X, Y, Z, in4, n, m, cursor, out4, blockIdx.x);
+    slab_scatter_body<LEVEL, PPT>(X, Y, Z, in4, n, m, cursor, out4, idmap, blockIdx.x);
 }
 template <bool ARENA>
 __global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                    float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                                   int *big_list, char *arena, unsigned long long arena_cap)
+                                                   int *big_list, char *arena, unsigned long long arena_cap, int *ytab)
 {
-    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, blockIdx.x);
+    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, ytab, blockIdx.x);
 }
 template <bool ARENA>
 __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
@@ -2263,11 +2326,11 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                                               const float *__restrict__ node_x, const float *__restrict__ node_y,
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
-                                              int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int capb,
-                                              float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back)
+                                              int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
+                                              float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab)
 {
     pose_body<ALIGNED>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
-                       tail, W_cap, arena_ran, capb, wp_xyz, wp_nn, wp_normal, wp_pre, back, blockIdx.x);
+                       tail, W_cap, arena_ran, knot_cap, stage_cap, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
                                                         float *wp_smooth, float *wp_out, const int *__restrict__ tail,
@@ -2294,13 +2357,13 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter_b(const BatchMember *__
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_scatter) return;
-    slab_scatter_body<0, PPT>(M.X, M.Y, M.Z, nullptr, M.n, M.m, M.slab_cursor, M.unsorted4, blockIdx.x);
+    slab_scatter_body<0, PPT>(M.X, M.Y, M.Z, nullptr, M.n, M.m, M.slab_cursor, M.unsorted4, nullptr, blockIdx.x);
 }
 __global__ void __launch_bounds__(SORT_T) k_slab_sort_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_sort) return;
-    slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, blockIdx.x);
+    slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, M.ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__restrict__ mem)
 {
@@ -2314,9 +2377,9 @@ __global__ void __launch_bounds__(POSE_T) k_pose_b(const BatchMember *__restrict
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_pose) return;
     PoseBack none;
-    none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr;
+    none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr; none.ytab = nullptr;
     pose_body<false>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
-                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.capb, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, blockIdx.x);
+                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
 {

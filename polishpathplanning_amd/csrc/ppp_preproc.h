@@ -732,3 +732,47 @@ __global__ void __launch_bounds__(256) k_transform_se3(const float *X, const flo
     }
     X2[i] = o[0]; Y2[i] = o[1]; Z2[i] = o[2];
 }
+
+/* ------------------------------------------------------------------ */
+/* Slice-range handles (SURVEY.md 8e case ii): the points of the cloud   */
+/* whose x lies in [lo, hi] -- the interval a handle indexes --, in the  */
+/* cloud's own order (ties on the cloud index break as in the whole      */
+/* cloud), with their cloud indices.  Built once per plan; the hot path  */
+/* then streams the part only.                                           */
+/* ------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256) k_part_count(const float *__restrict__ X, int n, float lo, float hi, int *block_cnt)
+{
+    __shared__ int s_c[4];
+    int c = 0;
+    for (int i = blockIdx.x * VOX_CHUNK + threadIdx.x; i < min(n, (blockIdx.x + 1) * VOX_CHUNK); i += blockDim.x) {
+        const float x = X[i];
+        c += (x >= lo && x <= hi); /* NaN (a dropped point) fails both */
+    }
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+__global__ void __launch_bounds__(256) k_part_compact(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+                                                      int n, float lo, float hi, const int *__restrict__ block_off, float *X2, float *Y2,
+                                                      float *Z2, int *idx2)
+{
+    __shared__ int s_scr[17];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = block_off[blockIdx.x];
+    __syncthreads();
+    const int i0 = blockIdx.x * VOX_CHUNK, i1 = min(n, i0 + VOX_CHUNK);
+    for (int base = i0; base < i1; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        float x = NAN;
+        if (i < i1) x = X[i];
+        const int keep = (x >= lo && x <= hi);
+        int tot;
+        const int pre = block_exscan(keep, s_scr, &tot);
+        const int run = s_run;
+        if (keep) { X2[run + pre] = x; Y2[run + pre] = Y[i]; Z2[run + pre] = Z[i]; idx2[run + pre] = i; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + tot;
+        __syncthreads();
+    }
+}

@@ -446,7 +446,7 @@ def test_class_surface_in_cpp_dense_band_normals_and_spline(engine_mod, oracle_m
     """examples/api_check: the drop-in C++ classes themselves -- rangedX_index on a band of more than 4096 points (the
     header's two-call size query), estimate_normal() with the field left readable, and class Spline on caller-supplied
     knots (constructor, point, restart, copies by value, the GSL error cases)."""
-    import subprocess
+    import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "api_check"], stdout=subprocess.DEVNULL)
     rng = np.random.default_rng(12)
@@ -470,7 +470,7 @@ def test_class_surface_in_cpp_dense_band_normals_and_spline(engine_mod, oracle_m
     n = 9
     i = np.arange(n)
     ky = -3.0 + 1.25 * i + 0.01 * i * i; kx = 100.0 + 0.5 * i * (i % 3); kz = 1500.0 - 0.75 * i + (i % 2)
-    q = ky[0] + (ky[-1] - ky[0]) * np.arange(17) / 16.0
+    q = ky[0] + (ky[-1] - ky[0]) * np.arange(17) / 16.0; q[-1] = ky[-1]
     got = np.array([float(v) for v in lines["spline"]])
     assert got[0] == n and got[1] == ky[0] and got[2] == ky[-1]
     want = np.stack([oracle_mod.steffen(ky, kx, q)[1], q, oracle_mod.steffen(ky, kz, q)[1]], axis=1).ravel()
