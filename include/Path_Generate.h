@@ -27,7 +27,12 @@ public:
     }
     ~path_generater() {}
 
-    void show() { planner.show_notice(); }
+    /* Path_Generation.cpp:37-51: other_cloud (inserted nodes, blue :196-198) + the cloud with the paths in red (:724) */
+    void show()
+    {
+        const unsigned char node_rgb[3] = {0, 0, 255}, path_rgb[3] = {255, 0, 0};
+        planner.show_dump(node_rgb, path_rgb);
+    }
     void voxel_down(const float x, const float y, const float z) { planner.voxel_down(x, y, z); } /* Path_Generation.cpp:53-59 */
     void trans2center() { planner.trans2center(); } /* Path_Generation.cpp:60-92 */
     void smooth() { planner.smooth_mls(15, 3, file_name, true); } /* Path_Generation.cpp:340-360 */

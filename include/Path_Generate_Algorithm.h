@@ -3,7 +3,8 @@
  * (class SectPath :57-98, class path_generater :102-135), used by src/connect.cpp and
  * src/connect1.cpp.  Same public methods and constructor arguments; the arithmetic runs on the
  * MI355X through include/ppp_hip.h.  Differences a caller can observe:
- *   - show() prints a notice instead of opening a PCL viewer (visualisation is out of scope);
+ *   - show() opens no PCL viewer: with PPP_SHOW_PCD=<file> it writes the cloud the viewer would show (inserted nodes +
+ *     the cloud with the paths painted on it, path_slicing_alg.cpp:69-80, 269-288) as a PointXYZRGB PCD, else a notice;
  *   - Dynamic_adjustment = true runs the curvature-driven re-spacing (path_dynamic_alg.cpp:77-306)
  *     on the GPU, RemoveOutlier = true the statistical outlier removal (path_slicing_alg.cpp:101-108),
  *     Smooth = true the moving-least-squares smoothing (path_slicing_alg.cpp:111-139);
@@ -29,6 +30,9 @@
 #define HANDEYErx -3.1270175
 #define HANDEYEry -0.040124
 #define HANDEYErz -1.6063578
+#endif
+#ifndef PPP_NODE_GB
+#define PPP_NODE_GB 0 /* green / blue of the inserted nodes' colour: red (path_slicing_alg.cpp:228-230); contour_alg.h makes them white */
 #endif
 #ifndef PPP_GETPATH_TRIM
 #define PPP_GETPATH_TRIM 10 /* path_translation_alg.cpp:158-159: dy = miny + 10 ... bigy - 10 */
@@ -58,7 +62,13 @@ public:
     /* path_slicing_alg.cpp:101-108: pcl::StatisticalOutlierRemoval, 50 neighbours, 1 sigma, on the resident cloud */
     void remove_outlier() { planner.remove_outlier(50, 1.0); }
 
-    void show() { planner.show_notice(); }
+    /* path_slicing_alg.cpp:69-80: other_cloud (the inserted nodes, red -- white in contour_alg.cpp:228-230) + the cloud with
+       the paths drawn on it (drawpath: red for SectPath::GenPath :315,326, blue for the derived planner, path_dynamic_alg.cpp:330,354) */
+    void show()
+    {
+        const unsigned char node_rgb[3] = {255, PPP_NODE_GB, PPP_NODE_GB}, path_rgb[3] = {(unsigned char)(blue_paths ? 0 : 255), 0, (unsigned char)(blue_paths ? 255 : 0)};
+        planner.show_dump(node_rgb, path_rgb);
+    }
     /* path_slicing_alg.cpp:141-150: the whole-cloud normal field (the reference's GenPath and getPath call it themselves;
        here they evaluate normals only where getPath needs them, so this runs when the CALLER asks for the field) */
     void estimate_normal() { planner.estimate_normal(); }
@@ -120,6 +130,7 @@ protected:
     std::vector<Spline> Path_set;
     std::string cloud_name, pathFile;
     std::vector<std::vector<float>> WayPointsList;
+    bool blue_paths = false;
 };
 
 /* Derived class of the reference: dynamic adjustment (path_dynamic_alg.cpp / dynamic_alg_sdir.cpp) */
@@ -129,6 +140,7 @@ public:
     path_generater(std::string configName, std::string CloudFileName)
     {
         cloud_name = CloudFileName;
+        blue_paths = true;
         read_config(configName);
 #ifdef PPP_SDIR
         planner.config().params.walk = PPP_WALK_SDIR_INT;   /* dynamic_alg_sdir.cpp:349-374 */

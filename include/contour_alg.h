@@ -3,8 +3,8 @@
  * self-contained copy of the equal-spacing planner that src/contour.cpp builds on (src/contour_alg.cpp; not in the
  * reference's CMakeLists.txt).  It is SectPath of Path_Generate_Algorithm.h with two differences, both parameters of the
  * same kernels: getPath samples from miny + 5 to bigy - 5 (contour_alg.cpp:496-497) and the hand-eye calibration is
- * the one of contour_alg.h:37-42.  (The inserted points' colour and the millisecond printout of GenPath are viewer /
- * console matters.)  Do not include it together with Path_Generate_Algorithm.h in one translation unit -- the
+ * the one of contour_alg.h:37-42.  (The inserted points are white instead of red in show()'s cloud, contour_alg.cpp:228-230; the millisecond
+ * printout of GenPath is a console matter.)  Do not include it together with Path_Generate_Algorithm.h in one translation unit -- the
  * reference's two headers define the same class name as well.
  */
 #ifndef PATH_CONTOUR
@@ -17,6 +17,7 @@
 #define HANDEYEry -0.0405313
 #define HANDEYErz -1.5707969
 #define PPP_GETPATH_TRIM 5
+#define PPP_NODE_GB 255 /* inserted points are white here (contour_alg.cpp:228-230) */
 
 #include "Path_Generate_Algorithm.h"
 

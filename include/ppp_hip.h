@@ -265,6 +265,9 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
 int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7]);
 /* binary: 0 = ascii (pcl::io::savePCDFileASCII, path_slicing_alg.cpp:138), 1 = binary, 2 = binary_compressed */
 int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary);
+/* a pcl::PointXYZRGB cloud (FIELDS x y z rgb, colour packed 0x00RRGGBB): what show() would hand to the viewer
+ * (path_slicing_alg.cpp:69-80); xyz = n x 3 packed floats, rgb = n x 3 bytes; binary: 0 = ascii, 1 = binary */
+int ppp_save_pcd_rgb(const char *path, const float *xyz, const unsigned char *rgb, size_t n, const float viewpoint[7], int binary);
 void ppp_free(void *p);
 /* SectPath::read_config / path_generater::read_config (path_slicing_alg.cpp:32-67,
  * path_dynamic_alg.cpp:34-75): same key set and parsing rules; absent keys keep config.txt's values */

@@ -198,9 +198,59 @@ public:
         ppp_num_slices(h_, &S);
         return S;
     }
-    void show_notice() const
-    {   /* show() opens a VTK window in the reference (visualisation: outside the hot path) */
-        std::printf("show(): viewer not built; the cloud stays resident on the GPU\n");
+    /* show() (path_slicing_alg.cpp:69-80, Path_Generation.cpp:37-51) opens a PCLVisualizer on `other_cloud + cloud`: the
+       spline knots insert_point added (coloured node_rgb: red, white in contour_alg.cpp:228-230) followed by the cloud itself,
+       white, with the cloud point nearest to every millimetre of every path recoloured path_rgb (drawpath,
+       path_slicing_alg.cpp:269-288).  No viewer here: with PPP_SHOW_PCD=<file> in the environment that very cloud is written
+       as a PointXYZRGB PCD (binary) for any viewer; without it a notice is printed.  The boundary curves drawpath also paints
+       while the dynamic adjustment runs (0,255,0) are not kept by the engine and are not in the dump. */
+    void show_dump(const unsigned char node_rgb[3], const unsigned char path_rgb[3])
+    {
+        const char *out = std::getenv("PPP_SHOW_PCD");
+        if (!out || !out[0] || !ok()) {
+            std::printf("show(): viewer not built; the cloud stays resident on the GPU (PPP_SHOW_PCD=<file> writes what the viewer would show)\n");
+            return;
+        }
+        size_t n = 0;
+        if (ppp_get_cloud(h_, nullptr, 0, &n) != PPP_OK) { report(PPP_ERR_ARG); return; }
+        std::vector<float> cloud(3 * (n ? n : 1));
+        if (n && ppp_get_cloud(h_, cloud.data(), n, &n) != PPP_OK) { report(PPP_ERR_HIP); return; }
+        std::vector<unsigned char> crgb(3 * (n ? n : 1), 255);
+        std::vector<float> nodes;
+        int S = 0;
+        if (ppp_num_slices(h_, &S) != PPP_OK) S = 0; /* show() before GenPath: the bare cloud */
+        for (int s = 0; s < S; ++s) {
+            size_t m = 0;
+            if (ppp_get_nodes(h_, s, nullptr, nullptr, nullptr, 0, &m) != PPP_OK || m < 3) continue;
+            std::vector<double> y(m), x(m), z(m);
+            ppp_get_nodes(h_, s, y.data(), x.data(), z.data(), m, &m);
+            for (size_t i = 0; i < m; ++i) { nodes.push_back((float)x[i]); nodes.push_back((float)y[i]); nodes.push_back((float)z[i]); }
+            /* drawpath: dy = miny; while (dy < maxy) { nearest cloud point of path.point(dy) takes the path colour; dy += 1; } */
+            std::vector<double> q;
+            for (double dy = y.front(); dy < y.back(); dy += 1) q.push_back(dy);
+            if (q.empty()) continue;
+            std::vector<double> xyz(3 * q.size());
+            if (ppp_eval_spline(h_, s, q.data(), q.size(), xyz.data()) != PPP_OK) continue;
+            std::vector<float> qf(xyz.begin(), xyz.end());
+            std::vector<int> nn(q.size(), -1);
+            if (ppp_nearest(h_, qf.data(), q.size(), nn.data()) != PPP_OK) continue;
+            for (int id : nn) if (id >= 0 && (size_t)id < n) for (int c = 0; c < 3; ++c) crgb[3 * (size_t)id + c] = path_rgb[c];
+        }
+        const size_t nn_ = nodes.size() / 3;
+        std::vector<float> all(nodes);
+        all.insert(all.end(), cloud.begin(), cloud.begin() + 3 * n);
+        std::vector<unsigned char> rgb(3 * nn_);
+        for (size_t i = 0; i < nn_; ++i) for (int c = 0; c < 3; ++c) rgb[3 * i + c] = node_rgb[c];
+        rgb.insert(rgb.end(), crgb.begin(), crgb.begin() + 3 * n);
+        const float vp[7] = {0, 0, 0, 1, 0, 0, 0};
+        if (ppp_save_pcd_rgb(out, all.data(), rgb.data(), nn_ + n, vp, 1) == PPP_OK)
+            std::printf("show(): %zu inserted nodes + %zu cloud points written to %s\n", nn_, n, out);
+        else std::fprintf(stderr, "ppp: could not write %s\n", out);
+    }
+    void show_notice()
+    {   /* the classes without a colour scheme of their own */
+        const unsigned char red[3] = {255, 0, 0};
+        show_dump(red, red);
     }
     static int device_from_env()
     {

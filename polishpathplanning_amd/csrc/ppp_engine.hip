@@ -442,8 +442,10 @@ int make_plan(ppp_handle h)
     int capb = 1024;
     while (capb < 4096 && capb < 2.0 * expect) capb <<= 1;
     h->capb = capb;
-    /* slabs or bands that may not fit LDS: also run the arena passes (a later overflow turns them on too) */
-    if (2.0 * expect > 4096 || 1.5 * (double)h->h_nvalid / B > 4096) h->big_path = true;
+    /* slabs or bands that will hardly fit LDS: run the arena passes from the start.  (Anything else that overflows turns them
+       on by itself -- the pass re-runs once --; launching them for nothing costs two empty launches per pass, 13 us of cfg 5's
+       600.) */
+    if (1.2 * expect > 4096 || 1.2 * (double)h->h_nvalid / B > 4096) h->big_path = true;
     if (h->big_path) HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max(n, 1) + (1u << 20)));
     /* waypoints: every kept slice samples at most (yrange - 2 trim)/res + 1 points */
     double yr = (double)h->h_mx[1] - (double)h->h_mn[1];
@@ -560,11 +562,19 @@ int enqueue_index(ppp_handle h)
     /* threads per slab: 256 while a slab holds the planned 832 points on average (more slabs in flight per CU: cfg 2 sorts in
        15.3 us against 17.0), SORT_T for the fuller slabs of clouds beyond the 8192-slab cap (cfg 5: 125 us against 157) */
     const int sort_threads = (h->B > 0 && h->h_nvalid / h->B > 1000) ? SORT_T : 256;
-    LAUNCH(h, "k_slab_sort", k_slab_sort<false>, h->B, sort_threads, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p);
+    /* a slice-range handle sorts the slabs of its interval only (the others are empty and are never looked at) */
+    int first_slab = 0, nslabs = h->B;
+    if (h->use_part && slab_invw > 0.f) {
+        auto slab_of_host = [&](float x) { int b = (int)((x - slab_x0) * slab_invw); b = b < 0 ? 0 : b; return b >= h->B ? h->B - 1 : b; };
+        first_slab = slab_of_host(h->incl_lo);
+        nslabs = slab_of_host(h->incl_hi) - first_slab + 1;
+    }
+    LAUNCH(h, "k_slab_sort", k_slab_sort<false>, nslabs, sort_threads, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
+           h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p,
+           first_slab);
     if (h->big_path)
         LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, SORT_T, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p);
+               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p, 0);
     h->index_built = true;
     return PPP_OK;
 }
@@ -810,13 +820,16 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_pose_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_pose_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
+    (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    /* none of the opt-ins above is fatal (the launches check for themselves): leave no stale error behind for the next HIP
+       user of this thread (a framework that reads hipGetLastError after its own calls would trip over it) */
+    (void)hipGetLastError();
     *out = h;
     return PPP_OK;
 }

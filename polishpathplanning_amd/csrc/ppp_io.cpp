@@ -263,6 +263,27 @@ static int save_pcd_impl(const char *path, const float *xyz, size_t n, size_t st
     return PPP_OK;
 }
 
+/* pcl::PointXYZRGB cloud as PCL writes it: FIELDS x y z rgb, the colour packed 0x00RRGGBB in one 4-byte field */
+static int save_pcd_rgb_impl(const char *path, const float *xyz, const unsigned char *rgb, size_t n, const float viewpoint[7], int binary)
+{
+    if (!path || ((!xyz || !rgb) && n) || binary < 0 || binary > 1) return PPP_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return PPP_ERR_IO;
+    const float dvp[7] = {0, 0, 0, 1, 0, 0, 0};
+    const float *vp = viewpoint ? viewpoint : dvp;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n");
+    fprintf(f, "WIDTH %zu\nHEIGHT 1\nVIEWPOINT %g %g %g %g %g %g %g\nPOINTS %zu\nDATA %s\n", n, vp[0], vp[1], vp[2], vp[3], vp[4], vp[5],
+            vp[6], n, binary ? "binary" : "ascii");
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = xyz + 3 * i;
+        const uint32_t c = ((uint32_t)rgb[3 * i] << 16) | ((uint32_t)rgb[3 * i + 1] << 8) | (uint32_t)rgb[3 * i + 2];
+        if (binary) { fwrite(p, 4, 3, f); fwrite(&c, 4, 1, f); }
+        else fprintf(f, "%.9g %.9g %.9g %u\n", p[0], p[1], p[2], c);
+    }
+    fclose(f);
+    return PPP_OK;
+}
+
 void ppp_default_config(ppp_config *c)
 {   /* config.txt:1-13 */
     memset(c, 0, sizeof(*c));
@@ -345,6 +366,10 @@ int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
 int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
 {
     try { return save_pcd_impl(path, xyz, n, stride_floats, viewpoint, binary); } catch (...) { return PPP_ERR_IO; }
+}
+int ppp_save_pcd_rgb(const char *path, const float *xyz, const unsigned char *rgb, size_t n, const float viewpoint[7], int binary)
+{
+    try { return save_pcd_rgb_impl(path, xyz, rgb, n, viewpoint, binary); } catch (...) { return PPP_ERR_IO; }
 }
 int ppp_read_config(const char *path, ppp_config *c)
 {

@@ -299,7 +299,8 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
        scanned there, and go out coalesced: a thread reading its own run of counts from global one after the other was 80 %
        of this kernel at 8192 slabs. */
     {
-        for (int i = threadIdx.x; i < B; i += blockDim.x) { s_cnts[i] = slab_cnt[i]; slab_cnt[i] = 0; }
+        for (int i = threadIdx.x; i < B; i += blockDim.x) s_cnts[i] = slab_cnt[i]; /* (loads only: they pipeline) */
+        for (int i = threadIdx.x; i < B; i += blockDim.x) slab_cnt[i] = 0;
         __syncthreads();
         const int per = (B + blockDim.x - 1) / blockDim.x;
         const int b0 = threadIdx.x * per;
@@ -453,7 +454,7 @@ template <bool ARENA>
 __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
                                                int *big_list, char *arena, unsigned long long arena_cap, int *ytab, const int bx)
-{
+{   /* (bx: slab number; a slice-range handle launches only the slabs of its interval, offset by the first one) */
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ float s_mn[SORT_T / 64], s_mx[SORT_T / 64];
     __shared__ int s_scr[17];
@@ -2305,9 +2306,10 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict
 template <bool ARENA>
 __global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                    float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                                   int *big_list, char *arena, unsigned long long arena_cap, int *ytab)
+                                                   int *big_list, char *arena, unsigned long long arena_cap, int *ytab, int first_slab)
 {
-    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, ytab, blockIdx.x);
+    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, ytab,
+                          ARENA ? (int)blockIdx.x : first_slab + (int)blockIdx.x);
 }
 template <bool ARENA>
 __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,

@@ -78,7 +78,7 @@ EXPORTS = [
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
-    "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
+    "ppp_save_pcd_rgb", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
 ]
 
 

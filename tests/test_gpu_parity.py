@@ -387,6 +387,57 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
             assert os.path.exists(str(tmp_path / "smooth_workpiece.pcd"))
 
 
+def _read_rgb_pcd(path):
+    raw = open(path, "rb").read()
+    k = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    hdr = raw[:k].decode()
+    assert "FIELDS x y z rgb" in hdr and "SIZE 4 4 4 4" in hdr
+    n = int([ln for ln in hdr.splitlines() if ln.startswith("POINTS")][0].split()[1])
+    rec = np.frombuffer(raw[k:], dtype=np.dtype([("xyz", "<f4", 3), ("rgb", "<u4")]), count=n)
+    return rec["xyz"].copy(), rec["rgb"].copy()
+
+
+def test_show_dump_and_timing_csv_of_the_connect_planner(engine_mod, oracle_mod, tmp_path):
+    """show() (path_slicing_alg.cpp:69-80) without a viewer: PPP_SHOW_PCD=<file> receives other_cloud + cloud -- the inserted
+    nodes in red, then the cloud in white with the cloud point nearest to every millimetre of every path painted blue
+    (drawpath, path_dynamic_alg.cpp:330,354) --; and GenPath of the derived planner appends its microseconds to output.csv
+    (path_dynamic_alg.cpp:380-388)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("tiny_5k")
+    pcd = str(tmp_path / "w.pcd")
+    engine_mod.save_pcd(pcd, pts)
+    out = str(tmp_path / "wp.txt")
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\nSmooth = false\n"
+                    "Alignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n" % out)
+    dump = str(tmp_path / "show.pcd")
+    for rep in range(2):
+        r = subprocess.run([os.path.join(root, "examples", "connect"), pcd], env=dict(os.environ, PPP_CONFIG=str(conf), PPP_SHOW_PCD=dump),
+                           capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+    assert "Toal Using Time:" in r.stdout and "Number of Point Cloud: %d" % len(pts) in r.stdout
+    csv = open(str(tmp_path / "output.csv")).read().split()
+    assert len(csv) == 2 and all(int(v) > 0 for v in csv)               # one line per run, appended
+    xyz, rgb = _read_rgb_pcd(dump)
+    e = engine_mod.Engine(0, tool_radius=6.0, walk=1); e.set_cloud(pts); S = e.gen_path()
+    knots = np.concatenate([np.stack([kx, ky, kz], axis=1) for ky, kx, kz in (e.nodes(s) for s in range(S))]).astype(np.float32)
+    assert len(xyz) == len(knots) + len(pts)
+    assert np.array_equal(xyz[:len(knots)], knots) and np.all(rgb[:len(knots)] == 0xFF0000)
+    assert np.array_equal(xyz[len(knots):], e.cloud())
+    crgb = rgb[len(knots):]
+    painted = np.nonzero(crgb != 0xFFFFFF)[0]
+    assert np.all(crgb[painted] == 0x0000FF) and len(painted) > 0
+    want = set()
+    for s in range(S):
+        ky = e.nodes(s)[0]
+        q = np.arange(ky[0], ky[-1], 1.0)                                # dy = miny; while (dy < maxy) ...; dy += 1
+        rc, p = e.eval_spline(s, q)
+        want.update(e.nearest(p.astype(np.float32)).tolist())
+    assert set(painted.tolist()) == want
+
+
 def test_robot_path_class_end_to_end(engine_mod, oracle_mod, tmp_path):
     """include/robot_path.h (class RobotPath, robot_path.h:58-98; behaviour of the July snapshot path_connect_ex0720.cpp): the
     three-argument constructor, single-direction float walk from min.x + Radius, +-5 trim, no first/last drop, no

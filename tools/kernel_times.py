@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times of one pass (GenPath + getPath) and the hipGraph replay time.
-usage: python tools/kernel_times.py [--lib libppp_hip_x.so] config [config ...]"""
+usage: python tools/kernel_times.py [--lib libppp_hip_x.so] [--range begin:end] config [config ...]"""
 import hashlib
 import os
 import sys
@@ -13,9 +13,14 @@ args = sys.argv[1:]
 if args and args[0] == "--lib":
     engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), args[1])
     args = args[2:]
+rng_kw = {}
+if args and args[0] == "--range":          # one slice-range handle: --range begin:end
+    b, e_ = args[1].split(":")
+    rng_kw = dict(slice_begin=int(b), slice_end=int(e_))
+    args = args[2:]
 for name in args or ["cfg2_1m_s256"]:
     pts, cfg = synth.make_config(name)
-    e = engine.Engine(0, tool_radius=cfg["tool_radius"])
+    e = engine.Engine(0, tool_radius=cfg["tool_radius"], **rng_kw)
     e.set_cloud(pts)
     e.run_async(); e.sync()
     W = e.num_waypoints()
@@ -34,5 +39,5 @@ for name in args or ["cfg2_1m_s256"]:
         for k, v in kt.items():
             acc[k] = acc.get(k, 0.0) + v / 10
     print("%s %s: W %d, graph replay %.4f ms, list md5 %s" % (os.path.basename(engine.LIB_PATH), name, W, min(ts) * 1e3,
-                                                             hashlib.md5(e.waypoints().tobytes()).hexdigest()[:8]))
+                                                             "-" if rng_kw else hashlib.md5(e.waypoints().tobytes()).hexdigest()[:8]))
     print("   " + "  ".join("%s %.1f(x%d)" % (k, v * 1e3, kl[k]) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])) + "  [us]")
