@@ -443,7 +443,7 @@ __device__ inline void pcl_eigen33_smallest(const float cov[9], float *eigenvalu
 
 /* Eigen: Quaternionf from AngleAxisf about a unit axis, product, toRotationMatrix */
 struct Quatf { float w, x, y, z; };
-__device__ inline Quatf quat_axis(float angle, int axis)
+__device__ __forceinline__ Quatf quat_axis(float angle, int axis)
 {
     float ha = 0.5f * angle;
     float s = sinf(ha);
@@ -452,7 +452,7 @@ __device__ inline Quatf quat_axis(float angle, int axis)
     if (axis == 0) q.x = s; else if (axis == 1) q.y = s; else q.z = s;
     return q;
 }
-__device__ inline Quatf quat_mul(const Quatf &a, const Quatf &b)
+__device__ __forceinline__ Quatf quat_mul(const Quatf &a, const Quatf &b)
 {
     Quatf r;
     r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
@@ -461,7 +461,7 @@ __device__ inline Quatf quat_mul(const Quatf &a, const Quatf &b)
     r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
     return r;
 }
-__device__ inline void quat_to_mat(const Quatf &q, float R[3][3])
+__device__ __forceinline__ void quat_to_mat(const Quatf &q, float R[3][3])
 {
     const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
     const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
@@ -472,13 +472,13 @@ __device__ inline void quat_to_mat(const Quatf &q, float R[3][3])
     R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1.f - (txx + tyy);
 }
 /* AngleAxisf(rz,Z) * AngleAxisf(ry,Y) * AngleAxisf(rx,X) -> Matrix3f */
-__device__ inline void rot_zyx(float rx, float ry, float rz, float R[3][3])
+__device__ __forceinline__ void rot_zyx(float rx, float ry, float rz, float R[3][3])
 {
     Quatf q = quat_mul(quat_mul(quat_axis(rz, 2), quat_axis(ry, 1)), quat_axis(rx, 0));
     quat_to_mat(q, R);
 }
 /* Matrix3f::eulerAngles(2,1,0) -> (yaw, pitch, roll) */
-__device__ inline void euler_zyx(const float m[3][3], float e[3])
+__device__ __forceinline__ void euler_zyx(const float m[3][3], float e[3])
 {
     const float kPi = 3.14159265358979323846f;
     e[0] = atan2f(m[1][0], m[0][0]);
@@ -494,7 +494,7 @@ __device__ inline void euler_zyx(const float m[3][3], float e[3])
     e[2] = atan2f(s1 * m[0][2] - c1 * m[1][2], c1 * m[1][1] - s1 * m[0][1]);
 }
 /* SectPath::HandEyeTransform, path_translation_alg.cpp:3-35 */
-__device__ inline void handeye_transform(const float he[6], float wp[6])
+__device__ __forceinline__ void handeye_transform(const float he[6], float wp[6])
 {
     float HE[3][3], P[3][3];
     rot_zyx(he[3], he[4], he[5], HE);
@@ -511,7 +511,7 @@ __device__ inline void handeye_transform(const float he[6], float wp[6])
     wp[3] = e[2]; wp[4] = e[1]; wp[5] = e[0];
 }
 /* Approach / Orientation / Normal frame, path_translation_alg.cpp:192-202 */
-__device__ inline void pose_from_normal(const float n[3], float rpy[3])
+__device__ __forceinline__ void pose_from_normal(const float n[3], float rpy[3])
 {
     float A[3] = {-n[0], -n[1], -n[2]};
     const float X[3] = {1.f, 0.f, 0.f};

@@ -243,6 +243,7 @@ DevParams dev_params(const ppp_handle h)
     D.smooth = h->P.smooth; D.smooth_max_sweeps = h->P.smooth_max_sweeps;
     D.slice_begin = h->P.slice_begin; D.slice_end = h->P.slice_end; D.ranged = h->ranged ? 1 : 0;
     D.incl_lo = h->incl_lo; D.incl_hi = h->incl_hi;
+    D.knots_on_plane = h->P.dynamic_adjustment ? 0 : 1;
     D.bounds_given = h->use_part ? 1 : 0; D.g_nvalid = h->h_nvalid;
     for (int d = 0; d < 3; ++d) { D.g_mn[d] = h->h_mn[d]; D.g_mx[d] = h->h_mx[d]; }
     {   /* mean spacing of a sheet-like cloud from its bounding rectangle; only a search hint, never a cut-off */
@@ -820,9 +821,13 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
-    (void)hipFuncSetAttribute((const void *)k_pose_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
-    (void)hipFuncSetAttribute((const void *)k_pose<false>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
-    (void)hipFuncSetAttribute((const void *)k_pose<true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
+    (void)hipFuncSetAttribute((const void *)k_pose_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose_b<POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<false, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<true, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
@@ -1307,15 +1312,21 @@ int ppp_get_path_async(ppp_handle h)
         PB.sorted4 = h->back->sorted4.p; PB.slab_start = h->back->slab_start.p; PB.slab_xmin = h->back->slab_xmin.p; PB.slab_xmax = h->back->slab_xmax.p;
         PB.m = h->back->meta.p; PB.ytab = h->back->slab_ytab.p;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) PB.inv[r][c] = h->invTA[r][c];
-        LAUNCH(h, "k_pose<aligned>", k_pose<true>, nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+        LAUNCH(h, "k_pose<aligned>", (k_pose<true, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
                h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
                h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad,
                h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
     } else
-    LAUNCH(h, "k_pose", k_pose<false>, nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
-           h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
-           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad,
-           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
+    {
+#define PPP_POSE_ARGS h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, \
+           h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p, \
+           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad, \
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p
+        if (h->pose_threads <= 256) LAUNCH(h, "k_pose", (k_pose<false, 256>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
+        else if (h->pose_threads <= 512) LAUNCH(h, "k_pose", (k_pose<false, 512>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
+        else LAUNCH(h, "k_pose", (k_pose<false, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
+#undef PPP_POSE_ARGS
+    }
     h->path_done = true;
     h->list_final = false;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
@@ -1482,7 +1493,9 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
     else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
     LAUNCHB(lead, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, bg->members.p);
     LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), bg->members.p);
-    LAUNCHB(lead, "k_pose_b", k_pose_b, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
+    if (bg->pose_threads <= 256) LAUNCHB(lead, "k_pose_b", k_pose_b<256>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
+    else if (bg->pose_threads <= 512) LAUNCHB(lead, "k_pose_b", k_pose_b<512>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
+    else LAUNCHB(lead, "k_pose_b", k_pose_b<POSE_T>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
     LAUNCHB(lead, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, bg->members.p);
     if (count == 1) { /* nothing to collect: the one meta block goes straight to the host */
         HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->hs[0]->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, lead->stream));

@@ -45,6 +45,7 @@ struct DevParams {
     int slice_begin, slice_end, ranged;
     float incl_lo, incl_hi;
     float nn_hint2; /* (a few mean point spacings)^2: first search bound of the waypoints' 1-NN queries */
+    int knots_on_plane; /* every knot's x is its plane's x (no dynamic adjustment): the y -> x spline is that constant */
     /* a slice-range handle streams only its part of the cloud: the whole cloud's bounds and point count (what getMinMax3D
        gives the reference, and what the walk and the slab grid are built from) come with the plan */
     int bounds_given, g_nvalid;
@@ -1047,21 +1048,33 @@ __device__ inline int nn_sorted_side(const u64 *keys, const float4 *a4, int a, i
     }
     float best = INFINITY;
     int bidx = 0x7fffffff, bj = a;
-    for (int i = lo; i < b; ++i) {
-        const float4 c = a4[YK_POS(keys[i])];
-        float dy = q.y - c.y;
-        if (dy * dy > best) break;
-        float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
-        int id = idx_of(c);
+    /* candidates in order, four at a time: key -> point is two dependent LDS reads per candidate, eight such chains in a row
+       per walk when taken one by one; the four keys and then the four points are independent reads (one past the candidate
+       that ends the walk is harmless) */
+    auto visit = [&](const float4 &c, int i) {
+        const float dy = q.y - c.y;
+        if (dy * dy > best) return false;
+        const float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
+        const int id = idx_of(c);
         if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
+        return true;
+    };
+    for (int i = lo; i < b; i += 4) {
+        const int e = b - 1;
+        const u64 k0 = keys[i], k1 = keys[min(i + 1, e)], k2 = keys[min(i + 2, e)], k3 = keys[min(i + 3, e)];
+        const float4 c0 = a4[YK_POS(k0)], c1 = a4[YK_POS(k1)], c2 = a4[YK_POS(k2)], c3 = a4[YK_POS(k3)];
+        if (!visit(c0, i)) break;
+        if (i + 1 > e || !visit(c1, i + 1)) break;
+        if (i + 2 > e || !visit(c2, i + 2)) break;
+        if (i + 3 > e || !visit(c3, i + 3)) break;
     }
-    for (int i = lo - 1; i >= a; --i) {
-        const float4 c = a4[YK_POS(keys[i])];
-        float dy = q.y - c.y;
-        if (dy * dy > best) break;
-        float d = dist2_flann(q.x, q.y, q.z, c.x, c.y, c.z);
-        int id = idx_of(c);
-        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
+    for (int i = lo - 1; i >= a; i -= 4) {
+        const u64 k0 = keys[i], k1 = keys[max(i - 1, a)], k2 = keys[max(i - 2, a)], k3 = keys[max(i - 3, a)];
+        const float4 c0 = a4[YK_POS(k0)], c1 = a4[YK_POS(k1)], c2 = a4[YK_POS(k2)], c3 = a4[YK_POS(k3)];
+        if (!visit(c0, i)) break;
+        if (i - 1 < a || !visit(c1, i - 1)) break;
+        if (i - 2 < a || !visit(c2, i - 2)) break;
+        if (i - 3 < a || !visit(c3, i - 3)) break;
     }
     return bj;
 }
@@ -1197,13 +1210,36 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     STAMP(0, 3); /* candidate sort */
     /* std::map semantics: one node per distinct y.  Node[y] = ... is overwritten by every later
        writer and El is walked in ascending cloud index, so the value kept is the one written by
-       the candidate with the highest cloud index inside the run of equal keys. */
-    int mcount = 0;
-    for (int j = threadIdx.x; j < nEl; j += blockDim.x)
-        mcount += (j == nEl - 1) || (YK_Y(L.ckeys[j + 1]) != YK_Y(L.ckeys[j]));
-    int tot;
-    block_exscan(mcount, s_scr, &tot);
+       the candidate with the highest cloud index inside the run of equal keys.  One scan over the "last of its run" flags
+       gives every kept candidate its place; the slice's segment of the knot arrays is reserved once the total is known. */
+    if (threadIdx.x == 0) s_m = 0;
+    __syncthreads();
+    for (int base = 0; base < nEl; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        int keep = 0;
+        u64 k = 0;
+        if (j < nEl) {
+            k = L.ckeys[j];
+            keep = (j == nEl - 1) || (YK_Y(L.ckeys[j + 1]) != YK_Y(k));
+        }
+        int t2;
+        const int pre = block_exscan(keep, s_scr, &t2);
+        const int o = s_m;
+        if (keep) { /* parked in LDS until the segment is known: which candidate supplies the knot (every member of the run has its y) */
+            int best_i = YK_POS(k);
+            int best_idx = L.cidx[best_i];
+            for (int q = j - 1; q >= 0 && YK_Y(L.ckeys[q]) == YK_Y(k); --q) {
+                const int ci = YK_POS(L.ckeys[q]);
+                if (L.cidx[ci] > best_idx) { best_idx = L.cidx[ci]; best_i = ci; }
+            }
+            L.hist_cand[o + pre] = best_i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_m = o + t2;
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
+        int tot = s_m;
         int base = atomicAdd(&m->node_cursor, tot);
         if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
         s_base = base;
@@ -1215,32 +1251,11 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     __syncthreads();
     const int nknots = s_plane;
     if (nknots == 0) return;
-    float *oy = node_y + s_base, *oz = node_z + s_base;
-    for (int i = threadIdx.x; i < nknots; i += blockDim.x) node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
-    for (int base = 0; base < nEl; base += blockDim.x) {
-        int j = base + threadIdx.x;
-        int keep = 0;
-        u64 k = 0;
-        if (j < nEl) {
-            k = L.ckeys[j];
-            keep = (j == nEl - 1) || (YK_Y(L.ckeys[j + 1]) != YK_Y(k));
-        }
-        int t2;
-        int pre = block_exscan(keep, s_scr, &t2);
-        int o = s_m;
-        if (keep) {
-            int best_i = YK_POS(k);
-            int best_idx = L.cidx[best_i];
-            for (int q = j - 1; q >= 0 && YK_Y(L.ckeys[q]) == YK_Y(k); --q) {
-                int ci = YK_POS(L.ckeys[q]);
-                if (L.cidx[ci] > best_idx) { best_idx = L.cidx[ci]; best_i = ci; }
-            }
-            oy[o + pre] = ord2f(YK_Y(k));
-            oz[o + pre] = L.cz[best_i];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_m = o + t2;
-        __syncthreads();
+    for (int i = threadIdx.x; i < nknots; i += blockDim.x) {
+        const int ci = L.hist_cand[i];
+        node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
+        node_y[s_base + i] = L.cy[ci];
+        node_z[s_base + i] = L.cz[ci];
     }
     STAMP(0, 4); /* map flattening + node write */
 }
@@ -1665,21 +1680,30 @@ __device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, flo
                             V.narrow(bb, s0, s1, qy, lo, hi);
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < qy) lo = mid + 1; else hi = mid; }
                             const int p = lo;
-                            for (int i = p; i < s1; ++i) {
-                                const float4 c = at(i);
+                            /* candidates in the reference's order, read four at a time (the reads are independent; a read past
+                               the one that ends the walk is harmless): the walk is a chain of dependent LDS round trips otherwise */
+                            auto visit = [&](const float4 &c) {
                                 const float dy = qy - c.y;
-                                if (dy * dy > best) break;
+                                if (dy * dy > best) return false;
                                 const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
                                 const int id = idx_of(c);
                                 if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                                return true;
+                            };
+                            for (int i = p; i < s1; i += 4) {
+                                const int e = s1 - 1;
+                                const float4 c0 = at(i), c1 = at(min(i + 1, e)), c2 = at(min(i + 2, e)), c3 = at(min(i + 3, e));
+                                if (!visit(c0)) break;
+                                if (i + 1 > e || !visit(c1)) break;
+                                if (i + 2 > e || !visit(c2)) break;
+                                if (i + 3 > e || !visit(c3)) break;
                             }
-                            for (int i = p - 1; i >= s0; --i) {
-                                const float4 c = at(i);
-                                const float dy = qy - c.y;
-                                if (dy * dy > best) break;
-                                const float d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
-                                const int id = idx_of(c);
-                                if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = c; }
+                            for (int i = p - 1; i >= s0; i -= 4) {
+                                const float4 c0 = at(i), c1 = at(max(i - 1, s0)), c2 = at(max(i - 2, s0)), c3 = at(max(i - 3, s0));
+                                if (!visit(c0)) break;
+                                if (i - 1 < s0 || !visit(c1)) break;
+                                if (i - 2 < s0 || !visit(c2)) break;
+                                if (i - 3 < s0 || !visit(c3)) break;
                             }
                         };
                         if (s0 >= V.lds_lo && s1 <= V.lds_hi) { const float4 *L = V.lds - V.lds_lo; scan([&](int i) { return L[i]; }); }
@@ -1733,10 +1757,9 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
                             V.narrow(bb, s0, s1, p.y, lo, hi);
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (at(mid).y < p.y) lo = mid + 1; else hi = mid; }
                             const int q0 = lo;
-                            for (int i = q0; i < s1; ++i) {
-                                const float4 c = at(i);
+                            auto visit = [&](const float4 &c) { /* same order of additions as one point after the other */
                                 const float dy = p.y - c.y;
-                                if (dy * dy > r2) break;
+                                if (dy * dy > r2) return false;
                                 if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
                                     const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
                                     accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
@@ -1744,18 +1767,22 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
                                     accu[6] += x; accu[7] += y; accu[8] += z;
                                     count++;
                                 }
+                                return true;
+                            };
+                            for (int i = q0; i < s1; i += 4) { /* four independent reads in flight (see the NN scan) */
+                                const int e = s1 - 1;
+                                const float4 c0 = at(i), c1 = at(min(i + 1, e)), c2 = at(min(i + 2, e)), c3 = at(min(i + 3, e));
+                                if (!visit(c0)) break;
+                                if (i + 1 > e || !visit(c1)) break;
+                                if (i + 2 > e || !visit(c2)) break;
+                                if (i + 3 > e || !visit(c3)) break;
                             }
-                            for (int i = q0 - 1; i >= s0; --i) {
-                                const float4 c = at(i);
-                                const float dy = p.y - c.y;
-                                if (dy * dy > r2) break;
-                                if (dist2_flann(p.x, p.y, p.z, c.x, c.y, c.z) <= r2) {
-                                    const float x = c.x - p.x, y = c.y - p.y, z = c.z - p.z;
-                                    accu[0] += x * x; accu[1] += x * y; accu[2] += x * z;
-                                    accu[3] += y * y; accu[4] += y * z; accu[5] += z * z;
-                                    accu[6] += x; accu[7] += y; accu[8] += z;
-                                    count++;
-                                }
+                            for (int i = q0 - 1; i >= s0; i -= 4) {
+                                const float4 c0 = at(i), c1 = at(max(i - 1, s0)), c2 = at(max(i - 2, s0)), c3 = at(max(i - 3, s0));
+                                if (!visit(c0)) break;
+                                if (i - 1 < s0 || !visit(c1)) break;
+                                if (i - 2 < s0 || !visit(c2)) break;
+                                if (i - 3 < s0 || !visit(c3)) break;
                             }
                         };
                         if (s0 >= V.lds_lo && s1 <= V.lds_hi) { const float4 *L = V.lds - V.lds_lo; scan([&](int i) { return L[i]; }); }
@@ -1801,11 +1828,12 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
 #ifndef POSE_STAGE_CAP
 #define POSE_STAGE_CAP 5120 /* most points a workgroup stages; the plan asks for what the slab grid and the density need */
 #endif
+#define POSE_PRE 6        /* staged points a thread requests before the bookkeeping (registers; none in the 1024-thread form, which is short of them) */
 #define POSE_TAB_SLABS 12 /* y-bucket rows staged beside the points (more slabs than that: the rows are read from global) */
 __host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap) { return (size_t)stage_cap * 16 + (size_t)knot_cap * 12; }
 /* lanes per waypoint (the two searches walk G slabs side by side): a function of the slice's waypoint count ONLY, so the
    partial sums of the normals -- and with them the last bits of the list -- do not depend on the launch geometry */
-__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= 512 ? 2 : 1); }
+__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= 256 ? 2 : 1); }
 
 #ifndef POSE_T
 #define POSE_T 1024
@@ -1824,7 +1852,7 @@ struct PoseBack {
     float inv[3][4];
     const int *ytab;
 };
-template <bool ALIGNED>
+template <bool ALIGNED, int PRE>
 __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const float4 *__restrict__ sorted4,
                                           const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                           const float *__restrict__ slab_xmax, const float *__restrict__ px,
@@ -1848,6 +1876,23 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     if (m->err || k >= nk) return;
     /* work was left for the arena passes but they were not launched: report, the host re-runs */
     if (!arena_ran && (m->big_slabs > 0 || m->big_slices > 0)) { if (threadIdx.x == 0) atomicCAS(&m->err, 0, DERR_CAPACITY); return; }
+    /* the slabs to stage (widest symmetric range around the plane's slab that fits) -- and the first POSE_PRE points per
+       thread requested at once, into registers: their trip from memory runs beside the bookkeeping below */
+    const int s = k + m->first_kept;
+    const float Px = px[s];
+    int bL = slab_of(m, Px - pad), bR = slab_of(m, Px + pad);
+    while (slab_start[bR + 1] - slab_start[bL] > stage_cap && bL < bR) {
+        const int bc = slab_of(m, Px);
+        if (bR - bc >= bc - bL) --bR; else ++bL;
+    }
+    int lds_lo = slab_start[bL], lds_hi = slab_start[bR + 1];
+    if (lds_hi - lds_lo > stage_cap || ALIGNED) lds_hi = lds_lo; /* one over-full slab: no staging (nor for the other frame's index) */
+    float4 pre4[PRE > 0 ? PRE : 1];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int i = lds_lo + (int)threadIdx.x + q * (int)blockDim.x;
+        pre4[q] = i < lds_hi ? sorted4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     /* a9 bookkeeping (the former k_count launch): the waypoint count of EVERY kept slice is recomputed in every
        workgroup -- two knots and a closed form each -- so each workgroup knows its own offset in the list and W */
     if (threadIdx.x == 0) s_run = 0;
@@ -1879,19 +1924,14 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
         if (k == 0) { m->W = W; wp_off[nk] = W; }
     }
     if (W == 0 || cnt == 0) return;
-    const int s = k + m->first_kept;
     const int st = node_start[s], mm = node_cnt[s];
-    const float Px = px[s];
     STAMP_BEGIN();
-    /* slabs to stage: widest symmetric range around the plane's slab that fits */
-    int bL = slab_of(m, Px - pad), bR = slab_of(m, Px + pad);
-    while (slab_start[bR + 1] - slab_start[bL] > stage_cap && bL < bR) {
-        const int bc = slab_of(m, Px);
-        if (bR - bc >= bc - bL) --bR; else ++bL;
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const int i = lds_lo + (int)threadIdx.x + q * (int)blockDim.x;
+        if (i < lds_hi) s_pts[i - lds_lo] = pre4[q];
     }
-    int lds_lo = slab_start[bL], lds_hi = slab_start[bR + 1];
-    if (lds_hi - lds_lo > stage_cap || ALIGNED) lds_hi = lds_lo; /* one over-full slab: no staging (nor for the other frame's index) */
-    for (int i = lds_lo + threadIdx.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
+    for (int i = lds_lo + (int)threadIdx.x + PRE * (int)blockDim.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
     /* ... and the y-bucket rows of the staged slabs */
     const int *yt = ALIGNED ? back.ytab : ytab;
     int tab_lo = 0, tab_hi = 0;
@@ -1925,7 +1965,9 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
             if (dy_closed_form) dy = start + (double)(act ? t : 0) * P.path_resolution; /* every partial sum is exact: same bits */
             else for (int r = 0; r < (act ? t : 0); ++r) dy += P.path_resolution;       /* the reference accumulates */
             const int iv = gsl_bsearch(mm, dy, Yf);
-            const double xd = steffen_eval_at(iv, mm, dy, Yf, Xf);
+            /* x: with every knot on the plane all slopes are zero and Steffen's cubic is d + delta * (0 + delta * (0 + delta * 0))
+               = the knot value, exactly -- the evaluation (a dozen f64 divisions) is only needed after a dynamic adjustment */
+            const double xd = P.knots_on_plane ? Xf(iv) : steffen_eval_at(iv, mm, dy, Yf, Xf);
             const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
             /* Vector4f(point) then invTransAlign (identity: Alignment=false); std::reverse on every second slice */
             const int w = off + ((k & 1) ? (cnt - 1 - t) : t);
@@ -2054,7 +2096,7 @@ __device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int
    never modified, so every interval is independent --, then the -180..180 limit (:81-85) and TransFlangeposition
    (:89-112).  p: the waypoint after smoothing (xyz smoothed, rpy as computed); src: any list holding the computed rpy
    of every waypoint (reduceRPY reads the key waypoints' angles).  Valid unless a slice is shorter than RPYres + 1. */
-__device__ inline void finish_one_waypoint(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
+__device__ __forceinline__ void finish_one_waypoint(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
                                            const float *__restrict__ src, int w, float p[6])
 {
     const bool reduce = P.rpy_resolution > 2;
@@ -2321,8 +2363,10 @@ __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restric
     slice_kd_body<ARENA>(sorted4, slab_start, m, px, lo, hi, capb_lds, node_x, node_y, node_z, node_cap, node_start, node_cnt, band_cnt,
                          big_list, arena, arena_cap, blockIdx.x);
 }
-template <bool ALIGNED>
-__global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+/* TMAX: the most threads a launch uses (256, 512 or POSE_T): the register budget follows from it -- the 1024-thread form is
+   held to 128 VGPRs and spills a few values, the smaller forms are not */
+template <bool ALIGNED, int TMAX>
+__global__ void __launch_bounds__(TMAX) k_pose(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
                                               const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                               const float *__restrict__ slab_xmax, const float *__restrict__ px,
                                               const float *__restrict__ node_x, const float *__restrict__ node_y,
@@ -2331,7 +2375,7 @@ __global__ void __launch_bounds__(POSE_T) k_pose(DevMeta *m, DevParams P, const 
                                               int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
                                               float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab)
 {
-    pose_body<ALIGNED>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
+    pose_body<ALIGNED, (TMAX <= 512 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
                        tail, W_cap, arena_ran, knot_cap, stage_cap, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
@@ -2374,13 +2418,14 @@ __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__
     slice_kd_body<false>(M.sorted4, M.slab_start, M.m, M.px, M.lo, M.hi, M.capb, M.node_x, M.node_y, M.node_z, M.node_cap, M.node_start,
                          M.node_cnt, M.band_cnt, M.big_slices, nullptr, 0ull, blockIdx.x);
 }
-__global__ void __launch_bounds__(POSE_T) k_pose_b(const BatchMember *__restrict__ mem)
+template <int TMAX>
+__global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_pose) return;
     PoseBack none;
     none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr; none.ytab = nullptr;
-    pose_body<false>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
+    pose_body<false, (TMAX <= 512 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
                      M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
