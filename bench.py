@@ -105,7 +105,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29571"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    if args.mode == "slices" and world > 1:
+    if args.mode == "slices" and (world > 1 or force_dist):
         return bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
 
     # ---- synthetic workpiece of this rank (untimed: generation + H2D) ----
@@ -368,25 +368,41 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
     """One cloud, slices sharded over the GPUs (no data-path collective until the gather); rank 0 finishes the list."""
     from polishpathplanning_amd.robot_path import exchange_counts, gather_robot_path, slice_ranges
     base_seed = sorted(synth.CONFIGS).index(args.config) + 1
-    pts, cfg = synth.make_config(args.config, seed=base_seed)      # every rank: the same cloud
+    pts, cfg = synth.make_config(args.config, seed=base_seed)      # every rank generates the same cloud (a stand-in for the scan file)
+    # The ranks agree on the whole cloud's bounds and point count with ONE all-reduce each of 3 minima, 3 maxima and a count over
+    # the share of the file each of them read (here: a contiguous 1/N of the point array), in the planner's units (x 1000 in float)
+    n_all = int(pts.shape[0])
+    share = (pts[rank * n_all // world:(rank + 1) * n_all // world] * np.float32(1000)).astype(np.float32)
+    fin = np.isfinite(share).all(axis=1)
+    t_mn = torch.from_numpy(share[fin].min(axis=0) if fin.any() else np.full(3, np.inf, np.float32)).to(dev)
+    t_mx = torch.from_numpy(share[fin].max(axis=0) if fin.any() else np.full(3, -np.inf, np.float32)).to(dev)
+    t_n = torch.tensor([int(fin.sum())], dtype=torch.int64, device=dev)
+    dist.all_reduce(t_mn, op=dist.ReduceOp.MIN); dist.all_reduce(t_mx, op=dist.ReduceOp.MAX); dist.all_reduce(t_n, op=dist.ReduceOp.SUM)
+    g_mn, g_mx, g_n = t_mn.cpu().numpy(), t_mx.cpu().numpy(), int(t_n.item())
     probe = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
-    probe.set_cloud(pts)
-    S = len(probe.slice_positions())
+    S = probe.range_interval(g_mn[0], g_mx[0])[2]
     probe.close()
     b, e = slice_ranges(S, world)[rank]
+    if b >= e and rank == 0:  # more GPUs than slices: rank 0 still needs a handle, it finishes the list
+        b, e = 0, 1
     eng = None
     nkept = max(S - 2, 0)
     counts_local = np.zeros(nkept, np.int32)
     w_local = 0
+    n_part = 0
     if b < e:
+        # this rank's part: the points of its slices' x interval (the pre-partition a real pipeline does while loading), with
+        # their cloud indices; the handle never sees the rest of the cloud
         eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], slice_begin=b, slice_end=e)
-        eng.set_cloud(pts)
-        eng.gen_path()
-        w_local = eng.get_path()
-        counts_local = eng.waypoint_counts()
-    elif rank == 0:          # more GPUs than slices: rank 0 still needs a handle, it finishes the list
-        eng = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], slice_begin=0, slice_end=1)
-        eng.set_cloud(pts)
+        lo, hi, _ = eng.range_interval(g_mn[0], g_mx[0])
+        sx = (pts[:, 0] * np.float32(1000)).astype(np.float32)
+        keep = np.nonzero((sx >= lo) & (sx <= hi))[0]
+        n_part = int(len(keep))
+        eng.set_cloud_part(pts[keep], keep, g_mn, g_mx, g_n, lo, hi)
+        if slice_ranges(S, world)[rank][0] < slice_ranges(S, world)[rank][1]:
+            eng.gen_path()
+            w_local = eng.get_path()
+            counts_local = eng.waypoint_counts()
     cnt = torch.from_numpy(counts_local.astype(np.int64)).to(dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     counts_all = cnt.cpu().numpy().astype(np.int32)                  # fixed workload: exchanged once
@@ -397,7 +413,7 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
 
     def step():
         w = 0
-        if eng is not None and b < e:
+        if eng is not None and w_local > 0:
             eng.run_async()                                          # a2..a12 of this rank's slices, one hipGraph launch
             w = eng.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, send.data_ptr(), send.shape[0])
         blocks = gather_robot_path(send[:w], dist, dev, w_ranks)
@@ -441,11 +457,12 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "points_per_workpiece": n_points, "slices": S, "waypoints_per_workpiece": W,
-                       "workpieces": 1, "parallelism": "slice ranges of one cloud, one range per GPU; RCCL gather of the pre-smoothing "
-                       "blocks; postion_smooth/reduceRPY/flange once on rank 0", "tool_radius_mm": cfg["tool_radius"]},
+                       "workpieces": 1, "parallelism": "slice ranges of one cloud, one range per GPU, every GPU holding only its own part "
+                       "of the cloud (bounds and count agreed by all-reduce); RCCL gather of the pre-smoothing blocks; "
+                       "postion_smooth/reduceRPY/flange once on rank 0", "points_on_rank0": n_part, "tool_radius_mm": cfg["tool_radius"]},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": alg_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "whole pipeline, every rank reads the whole cloud once (k_minmax) and indexes its own x interval"},
+                         "note": "whole pipeline; every rank streams and indexes its own x interval of the cloud only"},
             "cpu_baseline": None,
             "assembled_path": {"sharded_list_equals_unsharded_handle": sharded_equals_whole, "rows": W},
         }

@@ -102,6 +102,21 @@ int ppp_set_params(ppp_handle h, const ppp_params *p);
 int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_bytes, const float *viewpoint);
 /* same, the buffer already lives on this handle's device */
 int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
+/* Slice-range sharding without the whole cloud on every GPU (SURVEY.md 8e case ii, pre-partitioned by x).
+ * ppp_range_interval: the x interval [lo, hi] -- planner units: the file's values x 1000 (as floats) when ChangeRange -- whose
+ * points a handle with p->slice_begin / slice_end / range_margin indexes, for a cloud with the given x bounds (host arithmetic
+ * only: the slice walk of path_slicing_alg.cpp:308-330 etc.; +-INFINITY for the whole walk, lo > hi for an empty range);
+ * *num_slices (optional) receives S.
+ * ppp_set_cloud_part: like ppp_set_cloud, but xyz holds only the n_part points of the cloud whose planner-unit x lies in
+ * [part_lo, part_hi], in the cloud's own order (index ties then break as in the whole cloud); cloud_index (optional) = their
+ * indices in the whole cloud, so that every index the engine reports is the cloud's; mn / mx / n_valid_total = pcl::getMinMax3D
+ * and the number of finite points of the WHOLE cloud in planner units (ranks agree on them with one all-reduce of 3 minima,
+ * 3 maxima and a count).  The handle must be given a slice range whose interval lies inside [part_lo, part_hi]; it then plans
+ * exactly what a whole-cloud handle with that range plans (same slab grid, bit-identical list).  Calls that address points by
+ * whole-cloud index or replace the cloud (ppp_insert_point, ppp_normals_at, ppp_estimate_normals, the preprocessing) are refused. */
+int ppp_range_interval(const ppp_params *p, float min_x, float max_x, float *lo, float *hi, int *num_slices);
+int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_t stride_bytes, const float *viewpoint,
+                       const int *cloud_index, const float mn[3], const float mx[3], size_t n_valid_total, float part_lo, float part_hi);
 int ppp_num_points(ppp_handle h, size_t *n);
 /* the resident cloud (after the x1000 and any preprocessing) as n x 3 packed floats in index order */
 int ppp_get_cloud(ppp_handle h, float *xyz, size_t cap, size_t *n);

@@ -104,6 +104,11 @@ struct ppp_handle_s {
     DevBuf<int> part_idx;
     int n_part = 0;
     bool use_part = false;
+    /* ppp_set_cloud_part: the resident cloud IS a part (every point with x in [part_lo, part_hi], cloud order); the whole
+       cloud's bounds and point count came with it, part_idx (optional) holds the points' cloud indices */
+    bool part_given = false;
+    bool part_has_idx = false;
+    float part_lo = 0.f, part_hi = 0.f;
     DevBuf<float4> unsorted4, sorted4;
     DevBuf<int> slab_cnt, slab_start, slab_cursor, coarse_cursor, slab_ytab;
     bool two_pass_scatter = false; /* large clouds: coarse bins first (see k_slab_scatter) */
@@ -244,7 +249,7 @@ DevParams dev_params(const ppp_handle h)
     D.slice_begin = h->P.slice_begin; D.slice_end = h->P.slice_end; D.ranged = h->ranged ? 1 : 0;
     D.incl_lo = h->incl_lo; D.incl_hi = h->incl_hi;
     D.knots_on_plane = h->P.dynamic_adjustment ? 0 : 1;
-    D.bounds_given = h->use_part ? 1 : 0; D.g_nvalid = h->h_nvalid;
+    D.bounds_given = (h->use_part || h->part_given) ? 1 : 0; D.g_nvalid = h->h_nvalid;
     for (int d = 0; d < 3; ++d) { D.g_mn[d] = h->h_mn[d]; D.g_mx[d] = h->h_mx[d]; }
     {   /* mean spacing of a sheet-like cloud from its bounding rectangle; only a search hint, never a cut-off */
         const double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
@@ -387,7 +392,13 @@ int make_plan(ppp_handle h)
         }
     }
     h->use_part = false; h->n_part = 0;
-    if (h->ranged && h->sb < h->se && n > 0) {
+    if (h->part_given) {
+        if (!h->ranged && !(h->part_lo == -INFINITY && h->part_hi == INFINITY))
+            return fail(h, PPP_ERR_ARG, "a part-only cloud (ppp_set_cloud_part) needs a slice range: set slice_begin / slice_end");
+        if (h->sb < h->se && !(h->incl_lo >= h->part_lo && h->incl_hi <= h->part_hi))
+            return fail(h, PPP_ERR_ARG, "the slice range with its margin reaches beyond the part this handle was given (ppp_range_interval tells what it needs)");
+        h->n_range = n;
+    } else if (h->ranged && h->sb < h->se && n > 0) {
         /* the range's own points, once per plan: the hot path then streams n_part instead of n points (the bounds, the
            walk and the slab grid stay the whole cloud's: they come from the values cached with the cloud) */
         const int nblocks = (n + VOX_CHUNK - 1) / VOX_CHUNK;
@@ -520,7 +531,7 @@ int enqueue_index(ppp_handle h)
     /* a slice-range handle streams its own part of the cloud (make_plan), everything else the whole cloud */
     const int n = h->use_part ? h->n_part : (int)h->n;
     const float *sX = h->use_part ? h->Xp.p : h->X.p, *sY = h->use_part ? h->Yp.p : h->Y.p, *sZ = h->use_part ? h->Zp.p : h->Z.p;
-    const int *idmap = h->use_part ? h->part_idx.p : nullptr;
+    const int *idmap = h->use_part ? h->part_idx.p : ((h->part_given && h->part_has_idx) ? h->part_idx.p : nullptr);
     DevParams D = dev_params(h);
     size_t hist_lds = sizeof(int) * (size_t)h->B;
     /* slab grid from the bounds cached when the cloud was set (identical to what k_minmax finds) */
@@ -753,6 +764,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
 {
     if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
     h->n = n;
+    h->part_given = false; h->part_has_idx = false;
     h->aligned = false; /* a new cloud: TransAlign = identity (path_slicing_alg.cpp:25) */
     if (h->back) { delete h->back; h->back = nullptr; }
     if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
@@ -885,6 +897,62 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
     return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
 }
 
+int ppp_range_interval(const ppp_params *p, float min_x, float max_x, float *lo, float *hi, int *num_slices)
+{
+    if (!p || !lo || !hi) return PPP_ERR_ARG;
+    const int S = ppp_slice_walk(p->walk, min_x, max_x, p->tool_radius, nullptr, 0);
+    if (num_slices) *num_slices = S;
+    if (S <= 0 || S >= PPP_WALK_HARD_MAX) return PPP_ERR_ARG;
+    const int sb = std::min(std::max(0, p->slice_begin), S);
+    const int se = (p->slice_end <= 0 || p->slice_end > S) ? S : p->slice_end;
+    if (sb >= se) { *lo = INFINITY; *hi = -INFINITY; return PPP_OK; } /* an empty range needs no point */
+    if (sb == 0 && se == S) { *lo = -INFINITY; *hi = INFINITY; return PPP_OK; }
+    std::vector<float> px((size_t)S);
+    ppp_slice_walk(p->walk, min_x, max_x, p->tool_radius, px.data(), S);
+    *lo = (float)((int)px[sb] - 2) - p->range_margin;       /* as make_plan: band of slice s = [int(px) - 2, int(px) + 2] */
+    *hi = (float)((int)px[se - 1] + 2) + p->range_margin;
+    return PPP_OK;
+}
+
+int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_t stride_bytes, const float *viewpoint,
+                       const int *cloud_index, const float mn[3], const float mx[3], size_t n_valid_total, float part_lo, float part_hi)
+{
+    if (!h || (!xyz_host && n_part) || stride_bytes < 12 || (stride_bytes & 3) || !mn || !mx) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
+    if (!(part_lo <= part_hi) || n_valid_total < n_part || n_valid_total > 0x7fffffffu / 8) return fail(h, PPP_ERR_ARG, "bad part interval / point count");
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    const size_t bytes = n_part * stride_bytes;
+    HIPCHK(h, h->scratch.ensure(bytes));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(h->scratch.p, xyz_host, bytes, hipMemcpyHostToDevice, h->stream));
+    h->n = n_part;
+    h->aligned = false;
+    if (h->back) { delete h->back; h->back = nullptr; }
+    if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
+    HIPCHK(h, h->X.ensure(n_part)); HIPCHK(h, h->Y.ensure(n_part)); HIPCHK(h, h->Z.ensure(n_part));
+    if (n_part) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n_part + 255) / 256)), dim3(256), 0, h->stream, h->scratch.p, stride_bytes, (int)n_part,
+                           h->P.change_range, h->X.p, h->Y.p, h->Z.p);
+        HIPCHK(h, hipGetLastError());
+    }
+    h->part_has_idx = cloud_index != nullptr;
+    if (cloud_index) {
+        HIPCHK(h, h->part_idx.ensure(std::max<size_t>(n_part, 1)));
+        if (n_part) HIPCHK(h, hipMemcpyAsync(h->part_idx.p, cloud_index, n_part * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    /* the whole cloud's bounds and count, in the planner's units (what refresh_bounds_and_plan measures on a whole cloud) */
+    for (int d = 0; d < 3; ++d) { h->h_mn[d] = mn[d]; h->h_mx[d] = mx[d]; }
+    h->h_nvalid = (int)n_valid_total;
+    if (!h->h_nvalid) for (int d = 0; d < 3; ++d) { h->h_mn[d] = 3.402823466e+38f; h->h_mx[d] = -3.402823466e+38f; }
+    h->part_given = true; h->part_lo = part_lo; h->part_hi = part_hi;
+    h->have_cloud = true;
+    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->normals_valid = false;
+    h->drop_graph();
+    return make_plan(h);
+}
+
 namespace {
 
 /* the slab index of a handle, complete: built, its meta block read back, the arena passes run if a slab overflowed */
@@ -950,7 +1018,7 @@ int ppp_trans2center(ppp_handle h, float *trans_align16, float *centroid3, float
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
-    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (h->ranged || h->part_given) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
     if (h->aligned) return fail(h, PPP_ERR_ARG, "the cloud is aligned already (TransAlign would be overwritten): set the cloud again");
     const int n = (int)h->n;
     if (n == 0 || h->h_nvalid == 0) return fail(h, PPP_ERR_ARG, "no finite point to align");
@@ -1020,7 +1088,7 @@ int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_ke
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (mean_k < 1 || mean_k > 63) return fail(h, PPP_ERR_ARG, "mean_k must be in [1, 63]");
-    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (h->ranged || h->part_given) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
     int rc = ensure_index(h);
     if (rc) return rc;
     rc = fetch_meta(h);
@@ -1082,7 +1150,7 @@ int ppp_voxel_down(ppp_handle h, float lx, float ly, float lz, size_t *n_out, in
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
-    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (h->ranged || h->part_given) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
     if (!(lx > 0.f) || !(ly > 0.f) || !(lz > 0.f) || !std::isfinite(lx) || !std::isfinite(ly) || !std::isfinite(lz))
         return fail(h, PPP_ERR_ARG, "leaf sizes must be positive and finite");
     if (overflow) *overflow = 0;
@@ -1168,7 +1236,7 @@ int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out)
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
-    if (h->ranged) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
+    if (h->ranged || h->part_given) return fail(h, PPP_ERR_ARG, "preprocess the cloud on a whole-cloud handle");
     if (!(search_radius > 0) || !std::isfinite(search_radius)) return fail(h, PPP_ERR_ARG, "search radius must be positive"); /* mls.hpp: "Invalid search radius" */
     if (order < 0 || order > 3) return fail(h, PPP_ERR_ARG, "polynomial order must be in [0, 3]");
     int rc = ensure_index(h);
@@ -1990,6 +2058,7 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, 
     if (!h || (!indices && n)) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    if (h->part_given) return fail(h, PPP_ERR_UNSUPPORTED, "cloud indices address the whole cloud: this handle holds a part (ppp_set_cloud_part)");
     int capb = 4096;
     if (n > (size_t)capb) return fail(h, PPP_ERR_CAPACITY, "insert_point: more than 4096 indices in one band");
     if (!slice_lds_ok(h, capb)) return fail(h, PPP_ERR_CAPACITY, "LDS too small");
@@ -2024,6 +2093,7 @@ int ppp_normals_at(ppp_handle h, const int *idx, size_t k, float *out4)
 {
     int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
+    if (h->part_given) return fail(h, PPP_ERR_UNSUPPORTED, "cloud indices address the whole cloud: this handle holds a part (ppp_set_cloud_part)");
     if (!k) return PPP_OK;
     if (!idx || !out4) return fail(h, PPP_ERR_ARG, "bad arguments");
     HIPCHK(h, h->scratch.ensure(k * 20));
@@ -2042,6 +2112,7 @@ int ppp_estimate_normals(ppp_handle h, float *out4)
 {
     int rc = index_ready(h, false); /* complete index: slabs beyond the LDS capacity go through the arena pass first */
     if (rc) return rc;
+    if (h->part_given) return fail(h, PPP_ERR_UNSUPPORTED, "the normal field is indexed by the whole cloud: this handle holds a part (ppp_set_cloud_part)");
     if (!h->n) return PPP_OK;
     if (!out4) return fail(h, PPP_ERR_ARG, "bad arguments");
     rc = fetch_meta(h);

@@ -78,7 +78,7 @@ EXPORTS = [
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
-    "ppp_save_pcd_rgb", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
+    "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
 ]
 
 
@@ -116,6 +116,8 @@ def lib():
         L.ppp_set_cloud.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_num_points.argtypes = [vp, szp]
+        L.ppp_range_interval.argtypes = [C.POINTER(Params), C.c_float, C.c_float, fp, fp, ip]
+        L.ppp_set_cloud_part.argtypes = [vp, vp, sz, sz, fp, ip, fp, fp, sz, C.c_float, C.c_float]
         L.ppp_gen_path_async.argtypes = [vp]
         L.ppp_get_path_async.argtypes = [vp]
         L.ppp_run_async.argtypes = [vp]
@@ -349,6 +351,23 @@ class Engine:
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
         vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
         self._chk(self.L.ppp_set_cloud(self.h, xyz.ctypes.data, xyz.shape[0], xyz.shape[1] * 4, vp))
+        self.n = xyz.shape[0]
+
+    def range_interval(self, min_x, max_x):
+        """(lo, hi, S): the planner-unit x interval this handle's slice range indexes for a cloud with these x bounds."""
+        lo, hi, S = C.c_float(), C.c_float(), C.c_int()
+        self._chk(self.L.ppp_range_interval(C.byref(self.params), float(min_x), float(max_x), C.byref(lo), C.byref(hi), C.byref(S)))
+        return lo.value, hi.value, S.value
+
+    def set_cloud_part(self, xyz, cloud_index, mn, mx, n_valid_total, part_lo, part_hi, viewpoint=None):
+        """ppp_set_cloud_part: only this handle's part of the cloud + the whole cloud's bounds / count (planner units)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+        idx = None if cloud_index is None else _i(np.ascontiguousarray(cloud_index, np.int32))
+        mn = np.ascontiguousarray(mn, np.float32); mx = np.ascontiguousarray(mx, np.float32)
+        self._keep = (xyz, cloud_index)
+        self._chk(self.L.ppp_set_cloud_part(self.h, xyz.ctypes.data, xyz.shape[0], xyz.shape[1] * 4, vp, idx, _f(mn), _f(mx),
+                                            int(n_valid_total), float(part_lo), float(part_hi)))
         self.n = xyz.shape[0]
 
     def set_cloud_device(self, dptr, n, stride_bytes, viewpoint=None):
