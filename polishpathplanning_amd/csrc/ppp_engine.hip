@@ -543,25 +543,27 @@ int enqueue_index(ppp_handle h)
            that flush, not the streaming, is what grows with the grid. */
         const int gf = std::max(1, std::min(h->mm_grid, PPP_MM_GRID_MAX));
         LAUNCH(h, "k_minmax", k_minmax<true>, gf, MM_T, hist_lds, sX, sY, sZ, n, h->mm_part.p, slab_x0, slab_invw, h->B, h->slab_cnt.p,
-               h->incl_lo, h->incl_hi);
+               h->incl_lo, h->incl_hi, h->slab_cursor.p);
         h->mm_grid_used = gf;
     }
-    LAUNCH(h, "k_setup", k_setup, 1, SETUP_T, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
-           h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p, h->coarse_cursor.p);
-    /* points per scatter workgroup: every workgroup reserves its share of each slab with one global
-       atomic per non-empty (workgroup, slab) pair, so large clouds use larger chunks */
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global atomic per
        non-empty (workgroup, slab) pair, so larger clouds use 8 instead of 4 points per thread */
     const bool ppt8 = n > PPP_PPT8_FROM;
     const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
     const int gs = std::max(1, (n + chunk - 1) / chunk);
+    if (h->two_pass_scatter)
+        LAUNCH(h, "k_setup", k_setup, 1, SETUP_T, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
+               h->slab_cnt.p, slab_x0, slab_invw, h->slab_start.p, h->slab_cursor.p, h->coarse_cursor.p);
     if (!h->two_pass_scatter) {
+        /* one level: the set-up rides in the scatter's launch as its last workgroup (k_scatter_setup) */
+        ScatGrid G;
+        G.x0 = slab_x0; G.invw = slab_invw; G.xlo = h->incl_lo; G.xhi = h->incl_hi; G.B = h->B;
         if (ppt8)
-            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 8>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
-                   h->slab_cursor.p, h->unsorted4.p, idmap);
+            LAUNCH(h, "k_slab_scatter", k_scatter_setup<8>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
+                   h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
         else
-            LAUNCH(h, "k_slab_scatter", (k_slab_scatter<0, 4>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
-                   h->slab_cursor.p, h->unsorted4.p, idmap);
+            LAUNCH(h, "k_slab_scatter", k_scatter_setup<4>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
+                   h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
     } else {
         /* coarse bins into sorted4 (free until k_slab_sort writes it), then from there into the slabs */
         LAUNCH(h, "k_slab_scatter", (k_slab_scatter<1, 8>), gs, SCAT_T, hist_lds, sX, sY, sZ, (const float4 *)nullptr, n, h->meta.p,
@@ -583,10 +585,10 @@ int enqueue_index(ppp_handle h)
     }
     LAUNCH(h, "k_slab_sort", k_slab_sort<false>, nslabs, sort_threads, sort_lds, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
            h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p,
-           first_slab);
+           first_slab, h->slab_cnt.p);
     if (h->big_path)
         LAUNCH(h, "k_slab_sort_arena", k_slab_sort<true>, h->B, SORT_T, 0, h->unsorted4.p, h->slab_start.p, h->sorted4.p,
-               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p, 0);
+               h->slab_xmin.p, h->slab_xmax.p, h->meta.p, h->slab_cap, h->big_slabs.p, h->arena.p, (unsigned long long)h->arena.cap, h->slab_ytab.p, 0, (int *)nullptr);
     h->index_built = true;
     return PPP_OK;
 }
@@ -741,7 +743,7 @@ int refresh_bounds_and_plan(ppp_handle h)
         HIPCHK(h, h->mm_part.ensure(g));
         (void)hipGetLastError();
         hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
-                           (int *)nullptr, 0.f, 0.f);
+                           (int *)nullptr, 0.f, 0.f, (int *)nullptr);
         HIPCHK(h, hipGetLastError());
         std::vector<MinMaxPart> parts(g);
         HIPCHK(h, hipMemcpyAsync(parts.data(), h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));
@@ -832,6 +834,8 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_minmax_b, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_scatter_setup<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_scatter_setup<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
     (void)hipFuncSetAttribute((const void *)k_pose_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
@@ -1556,9 +1560,9 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
     const unsigned gy = (unsigned)count;
     const size_t hist_lds = sizeof(int) * (size_t)maxB;
     LAUNCHB(lead, "k_minmax_b", k_minmax_b, dim3(gx_mm, gy), MM_T, hist_lds, bg->members.p);
-    LAUNCHB(lead, "k_setup_b", k_setup_b, dim3(1, gy), SETUP_T, 0, bg->members.p);
-    if (ppt8) LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
-    else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat, gy), SCAT_T, hist_lds, bg->members.p);
+    /* (the set-up of every member rides in the scatter launch as that member's last workgroup) */
+    if (ppt8) LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, bg->members.p);
+    else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, bg->members.p);
     LAUNCHB(lead, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, bg->members.p);
     LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), bg->members.p);
     if (bg->pose_threads <= 256) LAUNCHB(lead, "k_pose_b", k_pose_b<256>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);

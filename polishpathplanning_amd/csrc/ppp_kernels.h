@@ -125,11 +125,13 @@ __device__ inline int slab_of_grid(float x, float x0, float invw, int B)
 template <bool HIST>
 __device__ __forceinline__ void minmax_body(const float *__restrict__ X, const float *__restrict__ Y,
                                             const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
-                                            int B, int *slab_cnt, float xlo, float xhi, const int bx, const int gx)
+                                            int B, int *slab_cnt, float xlo, float xhi, int *cursor, const int bx, const int gx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_hist[];
     if (HIST) {
         for (int b = threadIdx.x; b < B; b += blockDim.x) s_hist[b] = 0;
+        /* the one-level scatter reserves its runs on zero-based per-slab cursors: cleared here, a launch ahead */
+        if (cursor) for (int b = bx * (int)blockDim.x + (int)threadIdx.x; b < B; b += gx * (int)blockDim.x) cursor[b] = 0;
         __syncthreads();
     }
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -190,9 +192,9 @@ __device__ __forceinline__ void minmax_body(const float *__restrict__ X, const f
 template <bool HIST>
 __global__ void __launch_bounds__(MM_T) k_minmax(const float *__restrict__ X, const float *__restrict__ Y,
                                                 const float *__restrict__ Z, int n, MinMaxPart *part, float x0, float invw,
-                                                int B, int *slab_cnt, float xlo, float xhi)
+                                                int B, int *slab_cnt, float xlo, float xhi, int *cursor)
 {
-    minmax_body<HIST>(X, Y, Z, n, part, x0, invw, B, slab_cnt, xlo, xhi, blockIdx.x, gridDim.x);
+    minmax_body<HIST>(X, Y, Z, n, part, x0, invw, B, slab_cnt, xlo, xhi, cursor, blockIdx.x, gridDim.x);
 }
 
 /* Device form of ppp_slice_walk for one thread: identical values, but without a data dependent
@@ -273,8 +275,9 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
 #endif
 __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const MinMaxPart *__restrict__ part, int nparts,
                                            float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
-                                           float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
-{
+                                           float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor, const bool own_launch = true)
+{   /* own_launch = false: this is the extra workgroup of the one-level scatter launch -- the scatter workgroups beside it read
+       the histogram too (each scans it for itself), so it is left alone (k_slab_sort clears it), and they keep their own cursors */
     __shared__ int s_scan[17];
     __shared__ float s_mn[3][SETUP_T / 64], s_mx[3][SETUP_T / 64];
     __shared__ int s_cnt[SETUP_T / 64];
@@ -301,7 +304,7 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
        of this kernel at 8192 slabs. */
     {
         for (int i = threadIdx.x; i < B; i += blockDim.x) s_cnts[i] = slab_cnt[i]; /* (loads only: they pipeline) */
-        for (int i = threadIdx.x; i < B; i += blockDim.x) slab_cnt[i] = 0;
+        if (own_launch) for (int i = threadIdx.x; i < B; i += blockDim.x) slab_cnt[i] = 0;
         __syncthreads();
         const int per = (B + blockDim.x - 1) / blockDim.x;
         const int b0 = threadIdx.x * per;
@@ -315,7 +318,8 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
         __syncthreads();
         for (int i = threadIdx.x; i < B; i += blockDim.x) {
             const int v = s_cnts[i];
-            slab_start[i] = v; slab_cursor[i] = v;
+            slab_start[i] = v;
+            if (own_launch) slab_cursor[i] = v;
             if (coarse_cursor && (i & ((1 << SCAT_COARSE_SHIFT) - 1)) == 0) coarse_cursor[i >> SCAT_COARSE_SHIFT] = v;
         }
         if (threadIdx.x == 0) { slab_start[B] = total; s_total = total; }
@@ -454,7 +458,7 @@ __device__ __forceinline__ void slab_scatter_body(const float *__restrict__ X, c
 template <bool ARENA>
 __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                               int *big_list, char *arena, unsigned long long arena_cap, int *ytab, const int bx)
+                                               int *big_list, char *arena, unsigned long long arena_cap, int *ytab, int *slab_cnt, const int bx)
 {   /* (bx: slab number; a slice-range handle launches only the slabs of its interval, offset by the first one) */
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ float s_mn[SORT_T / 64], s_mx[SORT_T / 64];
@@ -466,6 +470,7 @@ __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsort
         b = big_list[b];
     }
     const int s0 = slab_start[b], c = slab_start[b + 1] - s0;
+    if (!ARENA && slab_cnt && threadIdx.x == 0) slab_cnt[b] = 0; /* the histogram is used up (k_setup clears it itself when it has its own launch) */
     u64 *key;
     int *hist;
     int NB;
@@ -2338,6 +2343,71 @@ __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, cons
 {
     setup_body(m, P, part, nparts, px, lo, hi, S_cap, B, slab_cnt, slab_x0, slab_invw, slab_start, slab_cursor, coarse_cursor);
 }
+/* The one-level scatter with k_setup folded into its launch (clouds below the two-pass size: one launch and ~7 us less per
+   pass).  Workgroup `nscat` (one past the scatter workgroups) is the set-up workgroup: bounds, walk, band limits, CSR offsets
+   and the meta block for the kernels that follow.  The scatter workgroups do not wait for it: each scans the slab histogram
+   for itself in LDS (B <= 4096 counts: a microsecond) and reserves its runs on zero-based per-slab cursors (cleared by
+   k_minmax); the slab grid and the kept interval come as arguments instead of from the meta block. */
+struct ScatGrid { float x0, invw, xlo, xhi; int B; };
+template <int PPT>
+__device__ __forceinline__ void slab_scatter_fused_body(const float *__restrict__ X, const float *__restrict__ Y,
+                                                        const float *__restrict__ Z, int n, const ScatGrid &G,
+                                                        const int *__restrict__ slab_cnt, int *cursor, float4 *out4,
+                                                        const int *__restrict__ idmap, const int bx)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_hist[];
+    __shared__ int s_scan[17];
+    const int B = G.B;
+    int *s_start = s_hist + B;
+    const int i0 = bx * (PPT * (int)blockDim.x);
+    float4 p[PPT];
+    int pb[PPT]; /* slab, or -1: not mine / dropped */
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = i0 + threadIdx.x + k * (int)blockDim.x;
+        pb[k] = -1;
+        if (i < n) p[k] = make_float4(X[i], Y[i], Z[i], __int_as_float(idmap ? idmap[i] : i));
+        else p[k] = make_float4(NAN, 0.f, 0.f, 0.f);
+    }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { s_hist[b] = 0; s_start[b] = slab_cnt[b]; }
+    __syncthreads();
+    {   /* exclusive scan of the histogram: this workgroup's own copy of slab_start */
+        const int per = (B + blockDim.x - 1) / blockDim.x;
+        const int b0 = threadIdx.x * per;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) if (b0 + k < B) sum += s_start[b0 + k];
+        int total;
+        int pre = block_exscan(sum, s_scan, &total);
+        for (int k = 0; k < per; ++k) if (b0 + k < B) { const int c = s_start[b0 + k]; s_start[b0 + k] = pre; pre += c; }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const float x = p[k].x;
+        if (x >= G.xlo && x <= G.xhi) { pb[k] = slab_of_grid(x, G.x0, G.invw, B); atomicAdd(&s_hist[pb[k]], 1); } /* NaN fails both */
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int c = s_hist[b];
+        if (c) s_hist[b] = s_start[b] + atomicAdd(&cursor[b], c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (pb[k] >= 0) out4[atomicAdd(&s_hist[pb[k]], 1)] = p[k];
+}
+template <int PPT>
+__global__ void __launch_bounds__(SCAT_T) k_scatter_setup(const float *__restrict__ X, const float *__restrict__ Y,
+                                                          const float *__restrict__ Z, int n, ScatGrid G, int *slab_cnt, int *cursor,
+                                                          float4 *out4, const int *idmap, int nscat,
+                                                          DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts, float *px,
+                                                          float *lo, float *hi, int S_cap, int *slab_start)
+{
+    if ((int)blockIdx.x == nscat) {
+        setup_body(m, P, part, nparts, px, lo, hi, S_cap, G.B, slab_cnt, G.x0, G.invw, slab_start, nullptr, nullptr, false);
+        return;
+    }
+    slab_scatter_fused_body<PPT>(X, Y, Z, n, G, slab_cnt, cursor, out4, idmap, blockIdx.x);
+}
 template <int LEVEL, int PPT>
 __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict__ X, const float *__restrict__ Y,
                                                       const float *__restrict__ Z, const float4 *__restrict__ in4, int n,
@@ -2348,9 +2418,10 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter(const float *__restrict
 template <bool ARENA>
 __global__ void __launch_bounds__(SORT_T) k_slab_sort(const float4 *__restrict__ unsorted4, const int *__restrict__ slab_start,
                                                    float4 *sorted4, float *slab_xmin, float *slab_xmax, DevMeta *m, int cap,
-                                                   int *big_list, char *arena, unsigned long long arena_cap, int *ytab, int first_slab)
+                                                   int *big_list, char *arena, unsigned long long arena_cap, int *ytab, int first_slab,
+                                                   int *slab_cnt)
 {
-    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, ytab,
+    slab_sort_body<ARENA>(unsorted4, slab_start, sorted4, slab_xmin, slab_xmax, m, cap, big_list, arena, arena_cap, ytab, slab_cnt,
                           ARENA ? (int)blockIdx.x : first_slab + (int)blockIdx.x);
 }
 template <bool ARENA>
@@ -2390,7 +2461,7 @@ __global__ void __launch_bounds__(MM_T) k_minmax_b(const BatchMember *__restrict
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_minmax) return;
-    minmax_body<true>(M.X, M.Y, M.Z, M.n, M.mm_part, M.slab_x0, M.slab_invw, M.B, M.slab_cnt, M.incl_lo, M.incl_hi, blockIdx.x, M.g_minmax);
+    minmax_body<true>(M.X, M.Y, M.Z, M.n, M.mm_part, M.slab_x0, M.slab_invw, M.B, M.slab_cnt, M.incl_lo, M.incl_hi, M.slab_cursor, blockIdx.x, M.g_minmax);
 }
 __global__ void __launch_bounds__(SETUP_T) k_setup_b(const BatchMember *__restrict__ mem)
 {
@@ -2400,16 +2471,23 @@ __global__ void __launch_bounds__(SETUP_T) k_setup_b(const BatchMember *__restri
 }
 template <int PPT>
 __global__ void __launch_bounds__(SCAT_T) k_slab_scatter_b(const BatchMember *__restrict__ mem)
-{
+{   /* the fused form (k_scatter_setup): workgroup g_scatter of every member is its set-up workgroup */
     const BatchMember &M = mem[blockIdx.y];
-    if ((int)blockIdx.x >= M.g_scatter) return;
-    slab_scatter_body<0, PPT>(M.X, M.Y, M.Z, nullptr, M.n, M.m, M.slab_cursor, M.unsorted4, nullptr, blockIdx.x);
+    if ((int)blockIdx.x > M.g_scatter) return;
+    ScatGrid G;
+    G.x0 = M.slab_x0; G.invw = M.slab_invw; G.xlo = M.incl_lo; G.xhi = M.incl_hi; G.B = M.B;
+    if ((int)blockIdx.x == M.g_scatter) {
+        setup_body(M.m, M.P, M.mm_part, M.g_minmax, M.px, M.lo, M.hi, M.S_cap, M.B, M.slab_cnt, M.slab_x0, M.slab_invw, M.slab_start,
+                   nullptr, nullptr, false);
+        return;
+    }
+    slab_scatter_fused_body<PPT>(M.X, M.Y, M.Z, M.n, G, M.slab_cnt, M.slab_cursor, M.unsorted4, nullptr, blockIdx.x);
 }
 __global__ void __launch_bounds__(SORT_T) k_slab_sort_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_sort) return;
-    slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, M.ytab, blockIdx.x);
+    slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, M.ytab, M.slab_cnt, blockIdx.x);
 }
 __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__restrict__ mem)
 {
