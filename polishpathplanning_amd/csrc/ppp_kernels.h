@@ -1831,7 +1831,7 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
    round trips; anything outside the staged window falls back to the global copy (exactness
    never depends on the window). */
 #ifndef POSE_STAGE_CAP
-#define POSE_STAGE_CAP 5120 /* most points a workgroup stages; the plan asks for what the slab grid and the density need */
+#define POSE_STAGE_CAP 7680 /* most points a workgroup stages (120 KiB of the CU's 160); the plan asks for what the slab grid and the density need */
 #endif
 #define POSE_PRE 6        /* staged points a thread requests before the bookkeeping (registers; none in the 1024-thread form, which is short of them) */
 #define POSE_TAB_SLABS 12 /* y-bucket rows staged beside the points (more slabs than that: the rows are read from global) */
