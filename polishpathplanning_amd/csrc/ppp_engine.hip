@@ -150,6 +150,7 @@ struct ppp_handle_s {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned epoch = 0;                 /* bumped whenever the launch sequence of this handle changes */
+    unsigned graph_epoch_seen = ~0u;    /* ppp_run_async: the plan epoch of the last call (the first call of a plan runs eagerly) */
     hipStream_t pending_stream = nullptr; /* a batch graph launched on another handle's stream carries this handle's work */
     struct BatchGraph *batches[2] = {nullptr, nullptr}; /* cached batch graphs (lead handle only): two, so a caller can
                                                            alternate between two destination buffers (double buffering) */
@@ -1442,6 +1443,19 @@ int ppp_run_async(ppp_handle h)
     if (h->timing) {
         int rc = ppp_gen_path_async(h);
         return rc ? rc : ppp_get_path_async(h);
+    }
+    if (!h->graph_exec && h->graph_epoch_seen != h->epoch) {
+        /* the first pass of a plan (a new cloud, new parameters) is enqueued directly: six launches cost the host less than
+           capturing and instantiating a graph does (~0.1 ms), and a planner fed with a new cloud every time never replays.
+           The second call of the same plan captures. */
+        h->graph_epoch_seen = h->epoch;
+        h->chain_calls = true;
+        ++h->internal;
+        int rc = ppp_gen_path_async(h);
+        h->chain_calls = false;
+        if (rc == PPP_OK) rc = ppp_get_path_async(h);
+        --h->internal;
+        return rc;
     }
     if (!h->graph_exec) {
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));

@@ -404,3 +404,30 @@ def test_bench_gpus_n_starts_its_own_ranks():
     out = r.stdout + r.stderr
     assert "rank 0 of 2" in out and "rank 1 of 2" in out
     assert "cfg4_2m_s256" in out          # the N > 1 default workload is BASELINE configs[3], one 2 M-point workpiece per GPU
+
+
+@pytest.mark.parametrize("walk", [0, 1, 2, 3, 4])
+def test_range_interval_is_the_walk_of_the_oracle(engine_mod, oracle_mod, walk):
+    """ppp_range_interval (host arithmetic, no device): the x interval a slice-range handle indexes = the PassThrough bands of
+    its first and last slice (rangedX_index(int): [int(Px) - 2, int(Px) + 2]) widened by range_margin, for the walk the
+    oracle runs on a cloud with the same bounds."""
+    import ctypes as C
+    from polishpathplanning_amd import synth
+    pts = synth.make_plate(300, 8, seed=5, x0_mm=-41.3)
+    o = oracle_mod.Oracle(pts, tool_radius=7.5, walk=walk)
+    mn, mx = o.minmax()
+    px = o.slice_positions()
+    L = engine_mod.lib()
+    for b, e, margin in [(0, 0, 24.0), (3, 9, 24.0), (len(px) - 4, 0, 5.0), (2, 3, 30.0), (7, 7, 24.0)]:
+        p = engine_mod.default_params(tool_radius=7.5, walk=walk, slice_begin=b, slice_end=e, range_margin=margin)
+        lo, hi, S = C.c_float(), C.c_float(), C.c_int()
+        assert L.ppp_range_interval(C.byref(p), float(mn[0]), float(mx[0]), C.byref(lo), C.byref(hi), C.byref(S)) == 0
+        assert S.value == len(px)
+        se = len(px) if e <= 0 else e
+        if b == 0 and se == len(px):
+            assert lo.value == -np.inf and hi.value == np.inf          # the whole walk: every point
+        elif b >= se:
+            assert lo.value > hi.value                                  # an empty range: no point
+        else:
+            assert lo.value == np.float32(int(px[b]) - 2) - np.float32(margin)
+            assert hi.value == np.float32(int(px[se - 1]) + 2) + np.float32(margin)
