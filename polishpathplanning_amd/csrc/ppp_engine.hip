@@ -81,7 +81,7 @@ struct ppp_handle_s {
 
     /* plan */
     int B = 1, slab_cap = 4096, S_cap = 1, capb = 2048, W_cap = 1, node_cap = 1;
-    int knot_cap = 2048, stage_cap = POSE_STAGE_CAP, pose_threads = POSE_T, cnt_est = 1; /* launch geometry of k_pose (make_plan) */
+    int knot_cap = 2048, stage_cap = POSE_STAGE_CAP, tab_slabs = 8, pose_threads = POSE_T, cnt_est = 1; /* launch geometry of k_pose (make_plan) */
     float pose_pad = 8.f;
     float h_mn[3] = {0, 0, 0}, h_mx[3] = {0, 0, 0};
     int h_nvalid = 0;
@@ -440,20 +440,20 @@ int make_plan(ppp_handle h)
     h->B = B;
     {
         double mean = (double)h->h_nvalid / B;
-        int cap = 2048; /* 24 KiB of LDS per workgroup: still 6 workgroups per CU */
-        while (cap < 4096 && cap < PPP_SLAB_CAP_FACTOR * mean) cap <<= 1;
-        h->slab_cap = cap;
+        /* LDS slots of a slab's sort workgroup: PPP_SLAB_CAP_FACTOR x the mean population in steps of 128 (12 B a slot: 1408
+           slots = 16.5 KiB let eight 256-thread workgroups share a CU); a denser slab goes through the arena pass */
+        h->slab_cap = (int)std::min(4096.0, std::max(1024.0, 128.0 * std::ceil(PPP_SLAB_CAP_FACTOR * mean / 128.0)));
     }
     HIPCHK(h, h->big_slabs.ensure(B));
     h->mm_grid = std::max(1, std::min(((h->use_part ? h->n_part : n) / 4 + 255) / 256, 2048)); /* 8 workgroups per CU keep enough loads in flight */
     HIPCHK(h, h->mm_part.ensure(h->mm_grid));
     h->S_cap = std::max(1, S);
     HIPCHK(h, h->big_slices.ensure(h->S_cap));
-    /* band capacity: expected points in a 4 mm band, x2 margin, power of two in [1024, 4096] */
+    /* band capacity: expected points in a 4 mm band, x2 margin, in [1024, 4096] */
     double range = (double)h->h_mx[0] - (double)h->h_mn[0];
     double expect = range > 0 ? (double)h->h_nvalid * 4.0 / range : (double)h->h_nvalid;
-    int capb = 1024;
-    while (capb < 4096 && capb < 2.0 * expect) capb <<= 1;
+    /* (twice the mean band, in steps of 128 points: at 36 B a point every step decides how many slice workgroups share a CU) */
+    int capb = (int)std::min(4096.0, std::max(1024.0, 128.0 * std::ceil(2.0 * expect / 128.0)));
     h->capb = capb;
     /* slabs or bands that will hardly fit LDS: run the arena passes from the start.  (Anything else that overflows turns them
        on by itself -- the pass re-runs once --; launching them for nothing costs two empty launches per pass, 13 us of cfg 5's
@@ -467,12 +467,22 @@ int make_plan(ppp_handle h)
            over).  Points: the slabs that overlap [Px - pad, Px + pad] span at most 2 pad + 2 slab widths; pad covers the
            nearest point (within a grid spacing of the plane) plus the normal's radius -- more when the dynamic adjustment
            moves knots off their plane.  Both are capacities of a fast path: what does not fit is read from global memory. */
-        h->knot_cap = std::max(256, capb / 2);
+        {   /* knots: about half the band's points are left points, at most one knot each -- 1.5 x that, a power of two */
+            int kc = 256;
+            while (kc < capb && kc < 0.75 * expect) kc <<= 1;
+            h->knot_cap = kc;
+        }
         h->pose_pad = h->P.dynamic_adjustment ? 8.f : std::max(5.f, 2.f * h->P.normal_radius);
+        /* points: an interval of 2 pad overlaps at most floor(2 pad / w) + 2 slabs of width w; mean population + 5 %.  Every
+           KiB counts: at 250 k points this is what lets three pose workgroups share a CU's LDS instead of two */
         const double slab_w = range > 0 ? range / B : 0.0;
-        const double rho = range > 0 ? (double)h->h_nvalid / range : (double)h->h_nvalid;
-        const double want = 1.1 * rho * (2.0 * h->pose_pad + 2.0 * slab_w) + 128;
-        h->stage_cap = (int)std::min<double>(POSE_STAGE_CAP, std::max(512.0, 256.0 * std::ceil(want / 256.0)));
+        const double slabs = slab_w > 0 ? std::floor(2.0 * h->pose_pad / slab_w) + 2.0 : 1.0;
+        const double want = 1.05 * slabs * ((double)h->h_nvalid / B) + 64;
+        h->stage_cap = (int)std::min<double>(POSE_STAGE_CAP, std::max(512.0, 128.0 * std::ceil(want / 128.0)));
+        h->tab_slabs = (int)std::min(16.0, slabs);
+        /* all of it must fit beside the kernel's static LDS: knots give way first (a slice with more reads them from memory) */
+        while (pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs) > (size_t)h->max_lds - 8192 && h->knot_cap > 256) h->knot_cap >>= 1;
+        while (pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs) > (size_t)h->max_lds - 8192 && h->stage_cap > 512) h->stage_cap -= 128;
         h->cnt_est = (int)std::min(1.0e6, per);
         int t = 256;
         while (t < POSE_T && t < h->cnt_est * pose_lanes(h->cnt_est)) t <<= 1;
@@ -1385,19 +1395,19 @@ int ppp_get_path_async(ppp_handle h)
         PB.sorted4 = h->back->sorted4.p; PB.slab_start = h->back->slab_start.p; PB.slab_xmin = h->back->slab_xmin.p; PB.slab_xmax = h->back->slab_xmax.p;
         PB.m = h->back->meta.p; PB.ytab = h->back->slab_ytab.p;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) PB.inv[r][c] = h->invTA[r][c];
-        LAUNCH(h, "k_pose<aligned>", (k_pose<true, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
+        LAUNCH(h, "k_pose<aligned>", (k_pose<true, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
                h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
-               h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad,
+               h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->tab_slabs, h->pose_pad,
                h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
     } else
     {
 #define PPP_POSE_ARGS h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, \
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p, \
-           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->pose_pad, \
+           h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->tab_slabs, h->pose_pad, \
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p
-        if (h->pose_threads <= 256) LAUNCH(h, "k_pose", (k_pose<false, 256>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
-        else if (h->pose_threads <= 512) LAUNCH(h, "k_pose", (k_pose<false, 512>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
-        else LAUNCH(h, "k_pose", (k_pose<false, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap), PPP_POSE_ARGS);
+        if (h->pose_threads <= 256) LAUNCH(h, "k_pose", (k_pose<false, 256>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
+        else if (h->pose_threads <= 512) LAUNCH(h, "k_pose", (k_pose<false, 512>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
+        else LAUNCH(h, "k_pose", (k_pose<false, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
 #undef PPP_POSE_ARGS
     }
     h->path_done = true;
@@ -1531,9 +1541,9 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
         M.slab_x0 = h->h_mn[0]; M.slab_invw = (h->h_nvalid && xr > 0.f) ? (float)h->B / xr : 0.f; /* as enqueue_index */
         M.incl_lo = h->incl_lo; M.incl_hi = h->incl_hi;
         M.B = h->B; M.S_cap = h->S_cap; M.slab_cap = h->slab_cap; M.capb = h->capb; M.node_cap = h->node_cap; M.W_cap = h->W_cap;
-        M.knot_cap = h->knot_cap; M.stage_cap = h->stage_cap; M.pose_pad = h->pose_pad;
+        M.knot_cap = h->knot_cap; M.stage_cap = h->stage_cap; M.tab_slabs = h->tab_slabs; M.pose_pad = h->pose_pad;
         bg->pose_threads = std::max(bg->pose_threads, h->pose_threads);
-        bg->pose_lds = std::max(bg->pose_lds, pose_lds_bytes(h->knot_cap, h->stage_cap));
+        bg->pose_lds = std::max(bg->pose_lds, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs));
         slices_total += h->S_cap;
         M.out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
         M.out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;

@@ -1834,8 +1834,11 @@ __device__ inline void normal_at_point_group(const SlabView &V, bool active, con
 #define POSE_STAGE_CAP 7680 /* most points a workgroup stages (120 KiB of the CU's 160); the plan asks for what the slab grid and the density need */
 #endif
 #define POSE_PRE 6        /* staged points a thread requests before the bookkeeping (registers; none in the 1024-thread form, which is short of them) */
-#define POSE_TAB_SLABS 12 /* y-bucket rows staged beside the points (more slabs than that: the rows are read from global) */
-__host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap) { return (size_t)stage_cap * 16 + (size_t)knot_cap * 12; }
+/* staged points | knots (y, z, x) | y-bucket rows of the staged slabs */
+__host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap, int tab_slabs)
+{
+    return (size_t)stage_cap * 16 + (size_t)knot_cap * 12 + (size_t)tab_slabs * (YTB + 1) * 4;
+}
 /* lanes per waypoint (the two searches walk G slabs side by side): a function of the slice's waypoint count ONLY, so the
    partial sums of the normals -- and with them the last bits of the list -- do not depend on the launch geometry */
 __host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= 256 ? 2 : 1); }
@@ -1865,7 +1868,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
                                           const float *__restrict__ node_z,
                                           const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                           int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
-                                          float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back,
+                                          int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back,
                                           const int *__restrict__ ytab, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -1873,9 +1876,9 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     float *s_ny = (float *)(s_pts + stage_cap);
     float *s_nz = s_ny + knot_cap;
     float *s_nx = s_nz + knot_cap;
+    int *s_tab = (int *)(s_nx + knot_cap); /* tab_slabs rows of YTB + 1 */
     __shared__ int s_scan[17];
     __shared__ int s_mycnt, s_myoff, s_run;
-    __shared__ int s_tab[POSE_TAB_SLABS * (YTB + 1)];
     const int k = bx;
     const int nk = m->nkept;
     if (m->err || k >= nk) return;
@@ -1940,7 +1943,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     /* ... and the y-bucket rows of the staged slabs */
     const int *yt = ALIGNED ? back.ytab : ytab;
     int tab_lo = 0, tab_hi = 0;
-    if (yt && lds_hi > lds_lo && bR - bL + 1 <= POSE_TAB_SLABS) {
+    if (yt && lds_hi > lds_lo && bR - bL + 1 <= tab_slabs) {
         tab_lo = bL; tab_hi = bR + 1;
         for (int i = threadIdx.x; i < (tab_hi - tab_lo) * (YTB + 1); i += blockDim.x) s_tab[i] = yt[(size_t)tab_lo * (YTB + 1) + i];
     }
@@ -2320,7 +2323,7 @@ struct BatchMember {
     int n;
     MinMaxPart *mm_part;
     float slab_x0, slab_invw, incl_lo, incl_hi;
-    int B, S_cap, slab_cap, capb, node_cap, W_cap, out2_cap, knot_cap, stage_cap;
+    int B, S_cap, slab_cap, capb, node_cap, W_cap, out2_cap, knot_cap, stage_cap, tab_slabs;
     float pose_pad;
     int g_minmax, g_scatter, g_sort, g_slice, g_pose, g_smooth; /* workgroups of this member per stage */
     int *slab_cnt, *slab_start, *slab_cursor, *coarse_cursor;
@@ -2444,10 +2447,10 @@ __global__ void __launch_bounds__(TMAX) k_pose(DevMeta *m, DevParams P, const fl
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                               int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
-                                              float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab)
+                                              int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab)
 {
     pose_body<ALIGNED, (TMAX <= 512 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
-                       tail, W_cap, arena_ran, knot_cap, stage_cap, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, blockIdx.x);
+                       tail, W_cap, arena_ran, knot_cap, stage_cap, tab_slabs, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
                                                         float *wp_smooth, float *wp_out, const int *__restrict__ tail,
@@ -2504,7 +2507,7 @@ __global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__
     PoseBack none;
     none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr; none.ytab = nullptr;
     pose_body<false, (TMAX <= 512 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
-                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, blockIdx.x);
+                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.tab_slabs, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
 {
