@@ -343,6 +343,52 @@ __device__ inline void block_bucket_sort(u64 *out, int n, int *hist, int NB, int
     __syncthreads();
 }
 
+/* The same sort with every key made ONCE and kept in registers between the counting and the placing pass (gen may be a
+   global load): for n <= E * blockDim. */
+template <int E, typename Gen, typename Bucket, typename Less>
+__device__ inline void block_bucket_sort_cached(u64 *out, int n, int *hist, int NB, int *scratch17, Gen gen, Bucket bucket, Less less)
+{
+    u64 kr[E];
+    int br[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)threadIdx.x + e * (int)blockDim.x;
+        br[e] = -1;
+        kr[e] = 0;
+        if (i < n) { kr[e] = gen(i); br[e] = bucket(kr[e]); }
+    }
+    for (int b = threadIdx.x; b <= NB; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (br[e] >= 0) atomicAdd(&hist[br[e]], 1);
+    __syncthreads();
+    {
+        const int per = (NB + blockDim.x - 1) / blockDim.x;
+        const int b0 = threadIdx.x * per;
+        int sum = 0;
+        for (int k = 0; k < per; ++k) if (b0 + k < NB) sum += hist[b0 + k];
+        int total;
+        int pre = block_exscan(sum, scratch17, &total);
+        for (int k = 0; k < per; ++k) {
+            if (b0 + k < NB) { int c = hist[b0 + k]; hist[b0 + k] = pre; pre += c; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (br[e] >= 0) out[atomicAdd(&hist[br[e]], 1)] = kr[e];
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += blockDim.x) { /* hist[b] is now the END of bucket b */
+        const int s = b ? hist[b - 1] : 0, e = hist[b];
+        for (int p = s + 1; p < e; ++p) {
+            u64 kp = out[p];
+            int q = p - 1;
+            while (q >= s && less(kp, out[q])) { out[q + 1] = out[q]; --q; }
+            out[q + 1] = kp;
+        }
+    }
+    __syncthreads();
+}
+
 __host__ __device__ inline int next_pow2(int v)
 {
     int p = 1;

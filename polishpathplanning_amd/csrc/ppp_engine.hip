@@ -570,10 +570,10 @@ int enqueue_index(ppp_handle h)
         ScatGrid G;
         G.x0 = slab_x0; G.invw = slab_invw; G.xlo = h->incl_lo; G.xhi = h->incl_hi; G.B = h->B;
         if (ppt8)
-            LAUNCH(h, "k_slab_scatter", k_scatter_setup<8>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
+            LAUNCH(h, "k_scatter_setup", k_scatter_setup<8>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
                    h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
         else
-            LAUNCH(h, "k_slab_scatter", k_scatter_setup<4>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
+            LAUNCH(h, "k_scatter_setup", k_scatter_setup<4>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
                    h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
     } else {
         /* coarse bins into sorted4 (free until k_slab_sort writes it), then from there into the slabs */

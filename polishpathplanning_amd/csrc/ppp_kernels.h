@@ -507,7 +507,8 @@ __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsort
             if (ya != yb) return ya < yb;
             return idx_of(src[YK_POS(a)]) < idx_of(src[YK_POS(bb)]); /* equal y: cloud index */
         };
-        block_bucket_sort(key, c, hist, NB, s_scr, gen, bucket, less);
+        if (!ARENA && c <= 8 * (int)blockDim.x) block_bucket_sort_cached<8>(key, c, hist, NB, s_scr, gen, bucket, less); /* y read once */
+        else block_bucket_sort(key, c, hist, NB, s_scr, gen, bucket, less);
         int *tab = ytab ? ytab + (size_t)b * (YTB + 1) : nullptr;
         for (int i = threadIdx.x; i < c; i += blockDim.x) {
             float4 p = src[YK_POS(key[i])];

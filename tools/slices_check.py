@@ -24,7 +24,8 @@ def main():
     one.set_cloud(pts)
     S = one.gen_path()
     W = one.get_path()
-    one.run_async(); one.sync()   # graph capture
+    one.run_async(); one.sync()   # the first pass of a plan is enqueued directly ...
+    one.run_async(); one.sync()   # ... the second captures the graph
     t = time.perf_counter()
     for _ in range(5):
         one.run_async(); one.sync()
@@ -39,6 +40,7 @@ def main():
         g = engine.Engine(0, tool_radius=R, slice_begin=b, slice_end=e)
         g.set_cloud(pts)
         g.gen_path(); g.get_path()
+        g.run_async(); g.sync()
         g.run_async(); g.sync()
         t = time.perf_counter()
         for _ in range(5):

@@ -19,7 +19,7 @@ def kernel_key(name):
     base = name.split("(")[0].replace("void ", "").strip()
     if "<" in base:
         base, targ = base.split("<", 1)
-        if targ.startswith("true"):
+        if targ.startswith("true") and base != "k_minmax":   # k_minmax<true> is the bounds + histogram pass of the hot path
             base += "_arena"
     return base
 
