@@ -1610,6 +1610,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     if (!hs || !count || !hs[0]) return PPP_ERR_ARG;
     ppp_handle lead = hs[0];
     if (dst_dev && (!offset_rows || !cap_rows)) return fail(lead, PPP_ERR_ARG, "offset_rows / cap_rows are needed with a destination");
+    if (count > 65535) return fail(lead, PPP_ERR_CAPACITY, "a batch holds at most 65535 workpieces (one grid row each)");
     HIPCHK(lead, hipSetDevice(lead->device));
     bool plain = false, batched = true;
     for (size_t i = 0; i < count; ++i) {
