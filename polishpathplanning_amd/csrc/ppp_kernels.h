@@ -1652,8 +1652,9 @@ __device__ inline void normal_at_point(const SlabView &V, const float4 p, float 
    together (inactive queries included: the shuffles are executed by whole groups) and all receive the result. */
 __device__ inline int group_signed_offset(int o) { return o == 0 ? 0 : ((o & 1) ? (o + 1) / 2 : -(o / 2)); }
 
-template <int G>
-__device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, float qx, float qy, float qz, float4 *found, int g, float bound2)
+/* (G is a run-time value: one copy of these two searches in the kernel instead of one per group size -- k_pose was 25 000
+   instructions with three, far beyond the instruction cache) */
+__device__ inline int nearest_in_slabs_group(const int G, const SlabView &V, bool active, float qx, float qy, float qz, float4 *found, int g, float bound2)
 {
     const int B = V.m->B;
     /* bound2: only points closer than this are looked for (INFINITY = all).  A lane that starts in a far slab has no
@@ -1735,8 +1736,7 @@ __device__ inline int nearest_in_slabs_group(const SlabView &V, bool active, flo
 /* normal_at_point with G lanes: every lane sums the neighbours of its slabs, the partial sums are added pairwise across
    the group (a fixed tree, so the result depends on the slab contents only -- identical for a slice-range handle and a
    whole-cloud handle) */
-template <int G>
-__device__ inline void normal_at_point_group(const SlabView &V, bool active, const float4 p, float radius, const float vp[3], float out[4], int g)
+__device__ inline void normal_at_point_group(const int G, const SlabView &V, bool active, const float4 p, float radius, const float vp[3], float out[4], int g)
 {
     const int B = V.m->B;
     const float r2 = radius * radius;
@@ -1964,8 +1964,8 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     const double start = (double)ny[0] + P.trim;
     /* G lanes per waypoint: as many as the workgroup has to spare (the two searches walk G slabs side by side) */
     const bool dy_closed_form = sums_exact(start, P.path_resolution, (double)cnt);
-    auto run = [&](auto gtag) {
-        constexpr int G = decltype(gtag)::value;
+    const int G = pose_lanes(cnt);
+    {
         const int g = threadIdx.x & (G - 1), per = blockDim.x / G;
         for (int base = 0; base < cnt; base += per) {
             const int t = base + threadIdx.x / G;
@@ -1991,8 +1991,11 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
             float n4[4] = {NAN, NAN, NAN, NAN};
             const bool finite = q.x == q.x && q.y == q.y && q.z == q.z;
             float4 p = make_float4(NAN, NAN, NAN, 0.f);
-            int id = nearest_in_slabs_group<G>(V, act && finite, q.x, q.y, q.z, &p, g, P.nn_hint2);
-            if (id < 0) id = nearest_in_slabs_group<G>(V, act && finite, q.x, q.y, q.z, &p, g, INFINITY); /* a hole in the cloud */
+            int id = -1;
+            for (int pass = 0; pass < 2; ++pass) { /* second pass, unbounded: a hole in the cloud (all lanes of a group agree on id) */
+                id = nearest_in_slabs_group(G, V, act && finite, q.x, q.y, q.z, &p, g, pass == 0 ? P.nn_hint2 : INFINITY);
+                if (__all(id >= 0 || !(act && finite))) break;
+            }
             if (P.ranged && act && finite && id >= 0 && g == 0) {
                 /* only part of the cloud is indexed: the answer is the whole cloud's as long as the ball that
                    proves the nearest neighbour and the normal's radius search stay inside the indexed interval */
@@ -2001,7 +2004,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
                 if ((need_lo < m->incl_lo && m->incl_lo > m->mn[0]) || (need_hi > m->incl_hi && m->incl_hi < m->mx[0])) set_err(m, DERR_MARGIN, s);
             }
             STAMP(1, 2); /* nearest */
-            normal_at_point_group<G>(V, act && finite && id >= 0, p, P.normal_radius, P.viewpoint, n4, g);
+            normal_at_point_group(G, V, act && finite && id >= 0, p, P.normal_radius, P.viewpoint, n4, g);
             STAMP(1, 3); /* normal */
             if (act && g == 0) {
                 if (id < 0) { n4[0] = n4[1] = n4[2] = n4[3] = NAN; set_err(m, DERR_QUERY, -1); }
@@ -2018,11 +2021,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
             }
             STAMP(1, 4); /* pose + hand-eye */
         }
-    };
-    const int G = pose_lanes(cnt);
-    if (G == 4) run(std::integral_constant<int, 4>{});
-    else if (G == 2) run(std::integral_constant<int, 2>{});
-    else run(std::integral_constant<int, 1>{});
+    }
 }
 
 __global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
