@@ -905,6 +905,50 @@ def test_batch_of_64_cfg3_workpieces_full_size(engine_mod, oracle_mod):
     assert solo.waypoints().tobytes() == engines[17].waypoints().tobytes()
 
 
+def test_batched_launches_random_members_match_single_handles(engine_mod):
+    """Batches of workpieces of very different sizes, shapes, walks and resolutions through the batched launches (one launch
+    per stage, blockIdx.y = member, every member with its own grid sizes and LDS carving): every list must carry the bytes
+    the member's own launch sequence gives."""
+    rng = np.random.default_rng(77)
+    for rnd in range(3):
+        specs = []
+        for _ in range(int(rng.integers(5, 12))):
+            nx, ny = int(rng.integers(60, 700)), int(rng.integers(30, 260))
+            kind = ["wavy", "dome", "blade", "flat"][int(rng.integers(0, 4))]
+            kw = dict(tool_radius=float(rng.choice([4.0, 6.0, 7.5, 12.0])), walk=int(rng.choice([0, 1, 2, 3])),
+                      path_resolution=float(rng.choice([3.0, 7.0, 11.0])), rpy_resolution=float(rng.choice([0.0, 3.0, 7.0])),
+                      trim=float(rng.choice([5.0, 10.0])), drop_ends=int(rng.integers(0, 2)), smooth=int(rng.integers(0, 2)))
+            specs.append((synth.make_plate(nx, ny, kind, float(rng.uniform(2, 30)), seed=int(rng.integers(1, 10 ** 6))), kw))
+        want, engines = [], []
+        for pts, kw in specs:
+            f = engine_mod.Engine(0, **kw); f.set_cloud(pts)
+            try:
+                f.gen_path(); f.get_path(); want.append(f.waypoints())
+            except engine_mod.PPPError as ex:
+                want.append(ex.code)
+            e = engine_mod.Engine(0, **kw); e.set_cloud(pts); engines.append(e)
+        ws = [0 if isinstance(w, int) else len(w) for w in want]
+        offs = np.concatenate([[0], np.cumsum(ws)[:-1]])
+        buf = _DeviceBuffer(max(sum(ws), 1) * 24)
+        for _ in range(2):                               # capture + replay
+            engine_mod.run_batch_async(engines, buf.ptr, offs, [max(w, 1) for w in ws])
+            try:
+                engine_mod.sync_batch(engines)
+            except engine_mod.PPPError:
+                assert any(isinstance(w, int) for w in want)
+            for i, (e, w) in enumerate(zip(engines, want)):
+                if isinstance(w, int):
+                    with pytest.raises(engine_mod.PPPError):
+                        e.waypoints()
+                else:
+                    e.sync()
+                    assert e.waypoints().tobytes() == w.tobytes(), (rnd, i)
+            got = buf.to_host(max(sum(ws), 1) * 6)[:sum(ws)]
+            good = [w for w in want if not isinstance(w, int)]
+            if good:
+                assert got.tobytes() == np.concatenate(good).tobytes()
+
+
 def test_batch_member_that_overflows_lds_lands_in_the_batch_buffer(engine_mod, oracle_mod):
     """A member whose bands do not fit the LDS fast path is re-planned with the arena passes by ppp_sync_batch: the
     re-planned list must also reach that member's rows of the batch destination (the RCCL send buffer)."""
