@@ -492,9 +492,10 @@ struct Quatf { float w, x, y, z; };
 __device__ __forceinline__ Quatf quat_axis(float angle, int axis)
 {
     float ha = 0.5f * angle;
-    float s = sinf(ha);
+    float s, c;
+    sincosf(ha, &s, &c); /* (one argument reduction for both) */
     Quatf q;
-    q.w = cosf(ha); q.x = 0.f; q.y = 0.f; q.z = 0.f;
+    q.w = c; q.x = 0.f; q.y = 0.f; q.z = 0.f;
     if (axis == 0) q.x = s; else if (axis == 1) q.y = s; else q.z = s;
     return q;
 }
@@ -535,15 +536,16 @@ __device__ __forceinline__ void euler_zyx(const float m[3][3], float e[3])
     } else {
         e[1] = atan2f(-m[2][0], c2);
     }
-    float s1 = sinf(e[0]);
-    float c1 = cosf(e[0]);
+    float s1, c1;
+    sincosf(e[0], &s1, &c1);
     e[2] = atan2f(s1 * m[0][2] - c1 * m[1][2], c1 * m[1][1] - s1 * m[0][1]);
 }
 /* SectPath::HandEyeTransform, path_translation_alg.cpp:3-35 */
-__device__ __forceinline__ void handeye_transform(const float he[6], float wp[6])
+/* (the rotation of the calibration itself is the same for every waypoint: handeye_rotation once, handeye_apply per waypoint) */
+__device__ __forceinline__ void handeye_rotation(const float he[6], float HE[3][3]) { rot_zyx(he[3], he[4], he[5], HE); }
+__device__ __forceinline__ void handeye_apply(const float HE[3][3], const float he[6], float wp[6])
 {
-    float HE[3][3], P[3][3];
-    rot_zyx(he[3], he[4], he[5], HE);
+    float P[3][3];
     rot_zyx(wp[3], wp[4], wp[5], P);
     float R[3][3], t[3];
     for (int i = 0; i < 3; ++i) {
@@ -555,6 +557,12 @@ __device__ __forceinline__ void handeye_transform(const float he[6], float wp[6]
     euler_zyx(R, e);
     wp[0] = t[0]; wp[1] = t[1]; wp[2] = t[2];
     wp[3] = e[2]; wp[4] = e[1]; wp[5] = e[0];
+}
+__device__ __forceinline__ void handeye_transform(const float he[6], float wp[6])
+{
+    float HE[3][3];
+    handeye_rotation(he, HE);
+    handeye_apply(HE, he, wp);
 }
 /* Approach / Orientation / Normal frame, path_translation_alg.cpp:192-202 */
 __device__ __forceinline__ void pose_from_normal(const float n[3], float rpy[3])

@@ -124,7 +124,7 @@ struct ppp_handle_s {
     int dyn_maxNB = 1, dyn_maxNA = 1;
     bool normals_valid = false;
     DevBuf<int> node_start, node_cnt, band_cnt;
-    DevBuf<int> wp_cnt, wp_off, tail;
+    DevBuf<int> wp_cnt, wp_off, tail, slice_wpcnt;
     DevBuf<float4> wp_xyz, wp_normal;
     DevBuf<int> wp_nn;
     DevBuf<float> wp_pre, wp_smooth, wp_out;
@@ -173,7 +173,7 @@ struct ppp_handle_s {
         slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_ytab.release(); slab_xmin.release(); slab_xmax.release();
         meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
         normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
-        node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release();
+        node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
         drop_graph();
@@ -516,6 +516,7 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->node_x.ensure(h->node_cap)); HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
     HIPCHK(h, h->node_start.ensure(h->S_cap)); HIPCHK(h, h->node_cnt.ensure(h->S_cap)); HIPCHK(h, h->band_cnt.ensure(h->S_cap));
     HIPCHK(h, h->wp_cnt.ensure(h->S_cap)); HIPCHK(h, h->wp_off.ensure(h->S_cap + 1)); HIPCHK(h, h->tail.ensure(h->S_cap));
+    HIPCHK(h, h->slice_wpcnt.ensure(h->S_cap));
     HIPCHK(h, h->wp_xyz.ensure(h->W_cap)); HIPCHK(h, h->wp_normal.ensure(h->W_cap)); HIPCHK(h, h->wp_nn.ensure(h->W_cap));
     HIPCHK(h, h->wp_pre.ensure(6 * (size_t)h->W_cap)); HIPCHK(h, h->wp_smooth.ensure(6 * (size_t)h->W_cap));
     HIPCHK(h, h->wp_out.ensure(6 * (size_t)h->W_cap));
@@ -1342,14 +1343,16 @@ int ppp_gen_path_async(ppp_handle h)
     if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
     int rc = enqueue_index(h);
     if (rc) return rc;
+    /* the pairing kernel leaves every slice's waypoint count for k_pose -- unless the dynamic adjustment re-fits the knots after it */
+    int *cnt_out = (h->P.pairing == PPP_PAIR_KD && !h->P.dynamic_adjustment) ? h->slice_wpcnt.p : nullptr;
     if (h->P.pairing == PPP_PAIR_KD) {
         LAUNCH(h, "k_slice_kd", k_slice_kd<false>, h->S_cap, slice_threads(h, h->S_cap), slice_kd_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p,
                h->px.p, h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
-               h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
+               h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap, h->P.trim, h->P.path_resolution, h->W_cap, cnt_out);
         if (h->big_path)
             LAUNCH(h, "k_slice_kd_arena", k_slice_kd<true>, h->S_cap, SLICE_KD_T, 0, h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                    h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
-                   h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap);
+                   h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap, h->P.trim, h->P.path_resolution, h->W_cap, cnt_out);
     } else {
         LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p,
@@ -1389,6 +1392,7 @@ int ppp_get_path_async(ppp_handle h)
     int nk = std::max(1, h->S_cap);
     PoseBack PB;
     memset(&PB, 0, sizeof(PB));
+    const int *cnt_in = (h->P.pairing == PPP_PAIR_KD && !h->P.dynamic_adjustment) ? h->slice_wpcnt.p : nullptr;
     if (h->aligned) {
         if (h->ranged) return fail(h, PPP_ERR_UNSUPPORTED, "Alignment with a slice range");
         if (!h->back || !h->back->index_built) return fail(h, PPP_ERR_ARG, "aligned cloud without its sensor-frame index");
@@ -1398,13 +1402,13 @@ int ppp_get_path_async(ppp_handle h)
         LAUNCH(h, "k_pose<aligned>", (k_pose<true, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p,
                h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p,
                h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->tab_slabs, h->pose_pad,
-               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p);
+               h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p, cnt_in);
     } else
     {
 #define PPP_POSE_ARGS h->meta.p, D, h->sorted4.p, h->slab_start.p, h->slab_xmin.p, \
            h->slab_xmax.p, h->px.p, h->node_x.p, h->node_y.p, h->node_z.p, h->node_start.p, h->node_cnt.p, h->wp_cnt.p, h->wp_off.p, \
            h->tail.p, h->W_cap, h->big_path ? 1 : 0, h->knot_cap, h->stage_cap, h->tab_slabs, h->pose_pad, \
-           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p
+           h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p, cnt_in
         if (h->pose_threads <= 256) LAUNCH(h, "k_pose", (k_pose<false, 256>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
         else if (h->pose_threads <= 512) LAUNCH(h, "k_pose", (k_pose<false, 512>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
         else LAUNCH(h, "k_pose", (k_pose<false, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
@@ -1558,7 +1562,7 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
         M.node_start = h->node_start.p; M.node_cnt = h->node_cnt.p; M.band_cnt = h->band_cnt.p;
         M.wp_cnt = h->wp_cnt.p; M.wp_off = h->wp_off.p; M.tail = h->tail.p;
         M.wp_xyz = h->wp_xyz.p; M.wp_normal = h->wp_normal.p; M.wp_nn = h->wp_nn.p;
-        M.wp_pre = h->wp_pre.p; M.wp_smooth = h->wp_smooth.p; M.wp_out = h->wp_out.p; M.ytab = h->slab_ytab.p;
+        M.wp_pre = h->wp_pre.p; M.wp_smooth = h->wp_smooth.p; M.wp_out = h->wp_out.p; M.ytab = h->slab_ytab.p; M.slice_wpcnt = h->slice_wpcnt.p;
         h->mm_grid_used = M.g_minmax;
         maxB = std::max(maxB, h->B); max_slab_cap = std::max(max_slab_cap, h->slab_cap); max_capb = std::max(max_capb, h->capb);
         full_slabs = full_slabs || (h->B > 0 && h->h_nvalid / h->B > 1000);

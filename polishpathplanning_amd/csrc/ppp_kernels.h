@@ -1017,6 +1017,25 @@ __global__ void __launch_bounds__(1024) k_slice_brute_arena(const float4 *__rest
 /* best distance).  El order only matters through the map's last-writer */
 /* rule, which is carried as the query's cloud index in the sort key.   */
 /* ------------------------------------------------------------------ */
+/* waypoints of one path: the reference's `dy = miny + trim; while (dy < bigy - trim) { ...; dy += res; }`
+   (path_translation_alg.cpp:158-166).  Closed form when the accumulated sums are exact, the loop otherwise. */
+__device__ inline int sample_count(double miny, double bigy, double trim, double res, int cap)
+{
+    double dy = miny + trim;
+    const double lim = bigy - trim;
+    if (!(dy < lim)) return 0;
+    const double est = (lim - dy) / res;
+    if (est < 1.0e6 && sums_exact(dy, res, est + 2.0)) {
+        int j = (int)floor(est) - 1; /* never above the count; dy + j * res is exact for these j */
+        if (j < 0) j = 0;
+        while (dy + (double)j * res < lim) ++j;
+        return j > cap ? cap + 1 : j;
+    }
+    int cnt = 0;
+    while (dy < lim && cnt <= cap) { cnt++; dy += res; }
+    return cnt;
+}
+
 struct SliceKdMem {
     float4 *a4;  /* band points                                              (dead after the NN phase) */
     u64 *keys;   /* band sorted by (side, y): (side<<63) | YK_MAKE(y, slot)  (dead after the NN phase) */
@@ -1095,8 +1114,10 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
                                               DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                               const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
                                               float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
-                                              char *arena, unsigned long long arena_cap, const int bx)
-{
+                                              char *arena, unsigned long long arena_cap, double trim, double res, int W_cap, int *slice_wpcnt,
+                                              const int bx)
+{   /* slice_wpcnt (optional): the slice's waypoint count -- getPath's sampling loop over [first knot + trim, last knot - trim) --
+       left for k_pose, whose every workgroup needs the counts of ALL slices for its offset in the list */
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
     __shared__ int s_n, s_plane, s_ner, s_base, s_m;
@@ -1108,7 +1129,7 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     } else {
         if (s >= m->S) return;
         if (s < m->sb || s >= m->se) { /* another handle's slice */
-            if (threadIdx.x == 0) { node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = 0; }
+            if (threadIdx.x == 0) { node_start[s] = 0; node_cnt[s] = 0; band_cnt[s] = 0; if (slice_wpcnt) slice_wpcnt[s] = 0; }
             return;
         }
     }
@@ -1124,7 +1145,7 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
         if (threadIdx.x == 0) s_off = atomicAdd(&m->arena_cursor, (need + 15) & ~15ull);
         __syncthreads();
         if (s_off + need > arena_cap) {
-            if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; }
+            if (threadIdx.x == 0) { set_err(m, DERR_CAPACITY, s); node_start[s] = 0; node_cnt[s] = 0; if (slice_wpcnt) slice_wpcnt[s] = 0; }
             return;
         }
         mem = arena + s_off;
@@ -1149,7 +1170,7 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     if (!ARENA) {
         if (threadIdx.x == 0) band_cnt[s] = n + s_plane;
         if ((size_t)n > capb) { /* does not fit LDS: leave it to the arena pass */
-            if (threadIdx.x == 0) { big_list[atomicAdd(&m->big_slices, 1)] = s; node_start[s] = 0; node_cnt[s] = 0; }
+            if (threadIdx.x == 0) { big_list[atomicAdd(&m->big_slices, 1)] = s; node_start[s] = 0; node_cnt[s] = 0; if (slice_wpcnt) slice_wpcnt[s] = 0; }
             return;
         }
     }
@@ -1179,7 +1200,7 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     const int nEr = s_ner, nEl = n - nEr;
     if (nEl == 0 || nEr == 0) {
         /* empty left side: empty map -> < 3 knots; empty right side: empty FLANN tree */
-        if (threadIdx.x == 0) { set_err(m, DERR_SLICE, s); node_start[s] = 0; node_cnt[s] = 0; }
+        if (threadIdx.x == 0) { set_err(m, DERR_SLICE, s); node_start[s] = 0; node_cnt[s] = 0; if (slice_wpcnt) slice_wpcnt[s] = 0; }
         return;
     }
     for (int i0q = 0; i0q < nEl; i0q += blockDim.x) {
@@ -1256,6 +1277,8 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
     }
     __syncthreads();
     const int nknots = s_plane;
+    if (slice_wpcnt && threadIdx.x == 0)
+        slice_wpcnt[s] = nknots >= 1 ? sample_count((double)L.cy[L.hist_cand[0]], (double)L.cy[L.hist_cand[nknots - 1]], trim, res, W_cap) : 0;
     if (nknots == 0) return;
     for (int i = threadIdx.x; i < nknots; i += blockDim.x) {
         const int ci = L.hist_cand[i];
@@ -1338,25 +1361,6 @@ __global__ void __launch_bounds__(256) k_insert_api(const float *__restrict__ X,
 /* ------------------------------------------------------------------ */
 /* a9: getPath sampling (path_translation_alg.cpp:149-169)              */
 /* ------------------------------------------------------------------ */
-/* waypoints of one path: the reference's `dy = miny + trim; while (dy < bigy - trim) { ...; dy += res; }`
-   (path_translation_alg.cpp:158-166).  Closed form when the accumulated sums are exact, the loop otherwise. */
-__device__ inline int sample_count(double miny, double bigy, double trim, double res, int cap)
-{
-    double dy = miny + trim;
-    const double lim = bigy - trim;
-    if (!(dy < lim)) return 0;
-    const double est = (lim - dy) / res;
-    if (est < 1.0e6 && sums_exact(dy, res, est + 2.0)) {
-        int j = (int)floor(est) - 1; /* never above the count; dy + j * res is exact for these j */
-        if (j < 0) j = 0;
-        while (dy + (double)j * res < lim) ++j;
-        return j > cap ? cap + 1 : j;
-    }
-    int cnt = 0;
-    while (dy < lim && cnt <= cap) { cnt++; dy += res; }
-    return cnt;
-}
-
 /* ppp_finish_path_async: the list was sampled elsewhere (slice-range handles); rebuild the per-run state
    getPath's second half needs from the per-slice counts: offsets, TailIndex, the B.6 flag, W. */
 __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,
@@ -1870,7 +1874,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
                                           const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                           int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
                                           int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, const PoseBack &back,
-                                          const int *__restrict__ ytab, const int bx)
+                                          const int *__restrict__ ytab, const int *__restrict__ slice_wpcnt, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     float4 *s_pts = (float4 *)s_raw;
@@ -1912,8 +1916,11 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
         if (k2 < nk) {
             const int s2 = k2 + m->first_kept;
             if (s2 >= m->sb && s2 < m->se) {
-                const int st2 = node_start[s2], mm2 = node_cnt[s2];
-                if (mm2 >= 1) c2 = sample_count((double)node_y[st2], (double)node_y[st2 + mm2 - 1], P.trim, P.path_resolution, W_cap);
+                if (slice_wpcnt) c2 = slice_wpcnt[s2]; /* k_slice_kd left it (one load instead of two dependent ones + the count) */
+                else {
+                    const int st2 = node_start[s2], mm2 = node_cnt[s2];
+                    if (mm2 >= 1) c2 = sample_count((double)node_y[st2], (double)node_y[st2 + mm2 - 1], P.trim, P.path_resolution, W_cap);
+                }
             }
         }
         int tot;
@@ -1965,6 +1972,8 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     /* G lanes per waypoint: as many as the workgroup has to spare (the two searches walk G slabs side by side) */
     const bool dy_closed_form = sums_exact(start, P.path_resolution, (double)cnt);
     const int G = pose_lanes(cnt);
+    float HE[3][3];
+    handeye_rotation(P.handeye, HE); /* the calibration's rotation: once per thread, not once per waypoint */
     {
         const int g = threadIdx.x & (G - 1), per = blockDim.x / G;
         for (int base = 0; base < cnt; base += per) {
@@ -2013,7 +2022,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
                 if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
                 else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
                 wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
-                handeye_transform(P.handeye, wp);
+                handeye_apply(HE, P.handeye, wp);
                 wp_xyz[w] = q;
                 wp_nn[w] = id;
                 wp_normal[w] = make_float4(n4[0], n4[1], n4[2], n4[3]);
@@ -2337,7 +2346,7 @@ struct BatchMember {
     float4 *wp_xyz, *wp_normal;
     int *wp_nn;
     float *wp_pre, *wp_smooth, *wp_out, *out2;
-    int *ytab;
+    int *ytab, *slice_wpcnt;
 };
 
 __global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
@@ -2432,10 +2441,10 @@ __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd(const float4 *__restric
                                                   DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                   const float *__restrict__ hi, int capb_lds, float *node_x, float *node_y,
                                                   float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list,
-                                                  char *arena, unsigned long long arena_cap)
+                                                  char *arena, unsigned long long arena_cap, double trim, double res, int W_cap, int *slice_wpcnt)
 {
     slice_kd_body<ARENA>(sorted4, slab_start, m, px, lo, hi, capb_lds, node_x, node_y, node_z, node_cap, node_start, node_cnt, band_cnt,
-                         big_list, arena, arena_cap, blockIdx.x);
+                         big_list, arena, arena_cap, trim, res, W_cap, slice_wpcnt, blockIdx.x);
 }
 /* TMAX: the most threads a launch uses (256, 512 or POSE_T): the register budget follows from it -- the 1024-thread form is
    held to 128 VGPRs and spills a few values, the smaller forms are not */
@@ -2447,10 +2456,11 @@ __global__ void __launch_bounds__(TMAX) k_pose(DevMeta *m, DevParams P, const fl
                                               const float *__restrict__ node_z,
                                               const int *__restrict__ node_start, const int *__restrict__ node_cnt,
                                               int *wp_cnt, int *wp_off, int *tail, int W_cap, int arena_ran, int knot_cap, int stage_cap,
-                                              int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab)
+                                              int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab,
+                                              const int *slice_wpcnt)
 {
     pose_body<ALIGNED, (TMAX <= 512 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
-                       tail, W_cap, arena_ran, knot_cap, stage_cap, tab_slabs, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, blockIdx.x);
+                       tail, W_cap, arena_ran, knot_cap, stage_cap, tab_slabs, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, slice_wpcnt, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
                                                         float *wp_smooth, float *wp_out, const int *__restrict__ tail,
@@ -2497,7 +2507,7 @@ __global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_slice) return;
     slice_kd_body<false>(M.sorted4, M.slab_start, M.m, M.px, M.lo, M.hi, M.capb, M.node_x, M.node_y, M.node_z, M.node_cap, M.node_start,
-                         M.node_cnt, M.band_cnt, M.big_slices, nullptr, 0ull, blockIdx.x);
+                         M.node_cnt, M.band_cnt, M.big_slices, nullptr, 0ull, M.P.trim, M.P.path_resolution, M.W_cap, M.slice_wpcnt, blockIdx.x);
 }
 template <int TMAX>
 __global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__ mem)
@@ -2507,7 +2517,7 @@ __global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__
     PoseBack none;
     none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr; none.ytab = nullptr;
     pose_body<false, (TMAX <= 512 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
-                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.tab_slabs, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, blockIdx.x);
+                     M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.tab_slabs, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, M.slice_wpcnt, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
 {
