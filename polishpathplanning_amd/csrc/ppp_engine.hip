@@ -1661,6 +1661,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     if (!fresh) {
         slot = lead->batch_next;
         lead->batch_next ^= 1;
+        if (lead->batches[slot]) HIPCHK(lead, hipStreamSynchronize(lead->stream)); /* its last launch may still be running: it owns the records that launch reads */
         delete lead->batches[slot];
         bg = new BatchGraph();
         lead->batches[slot] = bg;
