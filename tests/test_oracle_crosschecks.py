@@ -698,3 +698,24 @@ def test_oracle_under_address_sanitizer():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_postion_smooth_abs_binds_the_double_overload(tmp_path):
+    """path_translation_alg.cpp:136 writes `change += abs(y_i - y_i_saved)` with doubles and an unqualified abs.  If that call
+    bound C's abs(int), `change` would stay 0 and the loop would stop after ONE sweep -- a different path by millimetres.  With
+    the standard headers the reference's own header pulls in (Path_Generate_Algorithm.h:4-13: <math.h>, <algorithm>, <string> ...)
+    and this image's g++ (the Ubuntu 22.04 toolchain PCL 1.12 ships for) it binds std::abs(double): checked by compiling the
+    expression, not assumed."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = tmp_path / "abs_overload.cpp"
+    src.write_text('#include <time.h>\n#include <string>\n#include <vector>\n#include <map>\n#include <algorithm>\n#include <math.h>\n'
+                   '#include <chrono>\n#include <memory>\n#include <thread>\n#include <functional>\n#include <cstdio>\n'
+                   'int main() { double y_i = 0.3, y_i_saved = 0.9, change = 0; change += abs(y_i - y_i_saved);\n'
+                   '  printf("%.17g %zu\\n", change, sizeof(abs(y_i - y_i_saved))); return 0; }\n')
+    exe = tmp_path / "abs_overload"
+    subprocess.check_call(["g++", "-std=c++14", "-o", str(exe), str(src)])
+    val, size = subprocess.check_output([str(exe)], text=True).split()
+    assert float(val) == abs(0.3 - 0.9) and int(size) == 8
