@@ -1889,10 +1889,19 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     if (m->err || k >= nk) return;
     /* work was left for the arena passes but they were not launched: report, the host re-runs */
     if (!arena_ran && (m->big_slabs > 0 || m->big_slices > 0)) { if (threadIdx.x == 0) atomicCAS(&m->err, 0, DERR_CAPACITY); return; }
-    /* the slabs to stage (widest symmetric range around the plane's slab that fits) -- and the first POSE_PRE points per
-       thread requested at once, into registers: their trip from memory runs beside the bookkeeping below */
+    /* Everything this workgroup will stage -- the slabs around its plane (widest symmetric range that fits), their y-bucket
+       rows, the slice's knots -- is REQUESTED here, into registers, in as few dependent rounds as the data allow (plane and
+       knot segment; slab offsets; then points, rows and knots together with the slices' waypoint counts): the trips from
+       memory run beside each other and beside the bookkeeping below instead of one after the other. */
     const int s = k + m->first_kept;
     const float Px = px[s];
+    const int st = node_start[s], mm = node_cnt[s];
+    const int first_kept = m->first_kept, sb = m->sb, se = m->se;
+    int c2_first = 0; /* waypoint count of slice threadIdx.x (the first chunk of the scan below) */
+    if (slice_wpcnt && (int)threadIdx.x < nk) {
+        const int s2 = (int)threadIdx.x + first_kept;
+        if (s2 >= sb && s2 < se) c2_first = slice_wpcnt[s2];
+    }
     int bL = slab_of(m, Px - pad), bR = slab_of(m, Px + pad);
     while (slab_start[bR + 1] - slab_start[bL] > stage_cap && bL < bR) {
         const int bc = slab_of(m, Px);
@@ -1906,17 +1915,36 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
         const int i = lds_lo + (int)threadIdx.x + q * (int)blockDim.x;
         pre4[q] = i < lds_hi ? sorted4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    /* a9 bookkeeping (the former k_count launch): the waypoint count of EVERY kept slice is recomputed in every
-       workgroup -- two knots and a closed form each -- so each workgroup knows its own offset in the list and W */
+    const int *yt = ALIGNED ? back.ytab : ytab;
+    int tab_lo = 0, tab_hi = 0;
+    if (yt && lds_hi > lds_lo && bR - bL + 1 <= tab_slabs) { tab_lo = bL; tab_hi = bR + 1; }
+    const int tab_n = (tab_hi - tab_lo) * (YTB + 1);
+    constexpr int TPRE = PRE > 0 ? 2 : 0, KPRE = PRE > 0 ? 2 : 0;
+    int tpre[TPRE > 0 ? TPRE : 1];
+#pragma unroll
+    for (int q = 0; q < TPRE; ++q) {
+        const int i = (int)threadIdx.x + q * (int)blockDim.x;
+        tpre[q] = i < tab_n ? yt[(size_t)tab_lo * (YTB + 1) + i] : 0;
+    }
+    const bool nodes_in_lds = mm <= knot_cap;
+    float kpre[KPRE > 0 ? KPRE : 1][3];
+#pragma unroll
+    for (int q = 0; q < KPRE; ++q) {
+        const int i = (int)threadIdx.x + q * (int)blockDim.x;
+        const bool in = nodes_in_lds && i < mm;
+        kpre[q][0] = in ? node_y[st + i] : 0.f; kpre[q][1] = in ? node_z[st + i] : 0.f; kpre[q][2] = in ? node_x[st + i] : 0.f;
+    }
+    /* a9 bookkeeping (the former k_count launch): every workgroup scans the waypoint counts of ALL kept slices -- left by
+       k_slice_kd, or recomputed here from two knots and a closed form each -- to know its own offset in the list and W */
     if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nk; base += blockDim.x) {
         const int k2 = base + threadIdx.x;
         int c2 = 0;
         if (k2 < nk) {
-            const int s2 = k2 + m->first_kept;
-            if (s2 >= m->sb && s2 < m->se) {
-                if (slice_wpcnt) c2 = slice_wpcnt[s2]; /* k_slice_kd left it (one load instead of two dependent ones + the count) */
+            const int s2 = k2 + first_kept;
+            if (s2 >= sb && s2 < se) {
+                if (slice_wpcnt) c2 = base == 0 ? c2_first : slice_wpcnt[s2];
                 else {
                     const int st2 = node_start[s2], mm2 = node_cnt[s2];
                     if (mm2 >= 1) c2 = sample_count((double)node_y[st2], (double)node_y[st2 + mm2 - 1], P.trim, P.path_resolution, W_cap);
@@ -1940,24 +1968,28 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
         if (k == 0) { m->W = W; wp_off[nk] = W; }
     }
     if (W == 0 || cnt == 0) return;
-    const int st = node_start[s], mm = node_cnt[s];
     STAMP_BEGIN();
+    /* what has arrived goes to LDS; what did not fit the registers is fetched now */
 #pragma unroll
     for (int q = 0; q < PRE; ++q) {
         const int i = lds_lo + (int)threadIdx.x + q * (int)blockDim.x;
         if (i < lds_hi) s_pts[i - lds_lo] = pre4[q];
     }
     for (int i = lds_lo + (int)threadIdx.x + PRE * (int)blockDim.x; i < lds_hi; i += blockDim.x) s_pts[i - lds_lo] = sorted4[i];
-    /* ... and the y-bucket rows of the staged slabs */
-    const int *yt = ALIGNED ? back.ytab : ytab;
-    int tab_lo = 0, tab_hi = 0;
-    if (yt && lds_hi > lds_lo && bR - bL + 1 <= tab_slabs) {
-        tab_lo = bL; tab_hi = bR + 1;
-        for (int i = threadIdx.x; i < (tab_hi - tab_lo) * (YTB + 1); i += blockDim.x) s_tab[i] = yt[(size_t)tab_lo * (YTB + 1) + i];
+#pragma unroll
+    for (int q = 0; q < TPRE; ++q) {
+        const int i = (int)threadIdx.x + q * (int)blockDim.x;
+        if (i < tab_n) s_tab[i] = tpre[q];
     }
-    const bool nodes_in_lds = mm <= knot_cap;
-    if (nodes_in_lds)
-        for (int i = threadIdx.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; s_nx[i] = node_x[st + i]; }
+    for (int i = (int)threadIdx.x + TPRE * (int)blockDim.x; i < tab_n; i += blockDim.x) s_tab[i] = yt[(size_t)tab_lo * (YTB + 1) + i];
+    if (nodes_in_lds) {
+#pragma unroll
+        for (int q = 0; q < KPRE; ++q) {
+            const int i = (int)threadIdx.x + q * (int)blockDim.x;
+            if (i < mm) { s_ny[i] = kpre[q][0]; s_nz[i] = kpre[q][1]; s_nx[i] = kpre[q][2]; }
+        }
+        for (int i = (int)threadIdx.x + KPRE * (int)blockDim.x; i < mm; i += blockDim.x) { s_ny[i] = node_y[st + i]; s_nz[i] = node_z[st + i]; s_nx[i] = node_x[st + i]; }
+    }
     __syncthreads();
     STAMP(1, 0); /* staging */
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, s_pts, lds_lo, lds_hi};
