@@ -17,6 +17,7 @@
 #define DYN_WAVES 4       /* waves (= Area2Cloud evaluations) per workgroup; 1, 2, 4 measure the same, 8 slower */
 #endif
 #define DYN_ELL 721       /* for (float angle = 0; angle <= 360; angle += 0.5)       */
+#define DYN_ELL_PER ((DYN_ELL + 63) / 64) /* ellipse angles per lane */
 
 struct DynParams {
     double tool_radius, depth, toolthickness, adjust_threshold;
@@ -29,6 +30,7 @@ struct __attribute__((aligned(16))) DynWaveLds {
     u64 key[DYN_KNN_CAP];  /* (bits of the squared distance) << 32 | cloud index: one compare ranks a candidate */
     int pos[DYN_KNN_CAP];
     int sel[64];
+    int sel_id[64]; /* cloud index of neighbour r (the low half of its key) */
     int off[65];  /* exclusive prefix of the y-window sizes of 64 neighbouring slabs */
     int w0[64];   /* first position of each window                                  */
 };
@@ -58,13 +60,21 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
             const int bb = cb + lane;
             int a = 0, e = 0;
             if (bb <= bhi) {
-                const int s0 = V.slab_start[bb], s1 = V.slab_start[bb + 1];
-                int l0 = s0, l1 = s1, u0 = s0, u1 = s1; /* first y >= ylo, first y > yhi */
-                while (l0 < l1 || u0 < u1) {
-                    if (l0 < l1) { const int mid = (l0 + l1) >> 1; if (V.at(mid).y < ylo) l0 = mid + 1; else l1 = mid; }
-                    if (u0 < u1) { const int mid = (u0 + u1) >> 1; if (V.at(mid).y <= yhi) u0 = mid + 1; else u1 = mid; }
+                const int s0 = V.slab_start[bb];
+                if (V.ytab) {
+                    /* the slab's y-bucket row bounds the window from outside (bucket() is monotone in y): no search at all,
+                       a few candidates more -- each is tested against r2 below anyway */
+                    const int *T = V.ytab + (size_t)bb * (YTB + 1);
+                    a = s0 + T[ytab_bucket(V.m, ylo)]; e = s0 + T[ytab_bucket(V.m, yhi) + 1];
+                } else {
+                    const int s1 = V.slab_start[bb + 1];
+                    int l0 = s0, l1 = s1, u0 = s0, u1 = s1; /* first y >= ylo, first y > yhi */
+                    while (l0 < l1 || u0 < u1) {
+                        if (l0 < l1) { const int mid = (l0 + l1) >> 1; if (V.at(mid).y < ylo) l0 = mid + 1; else l1 = mid; }
+                        if (u0 < u1) { const int mid = (u0 + u1) >> 1; if (V.at(mid).y <= yhi) u0 = mid + 1; else u1 = mid; }
+                    }
+                    a = l0; e = u0 < l0 ? l0 : u0;
                 }
-                a = l0; e = u0 < l0 ? l0 : u0;
             }
             const int cnt = e - a;
             int inc = cnt;
@@ -75,27 +85,41 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
             if (lane == 63) L.off[64] = T;
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            for (int base = 0; base < T; base += 64) {
-                const int t = base + lane;
-                bool in = false;
-                float d = 0.f;
-                int i = 0, id = 0;
-                if (t < T) {
-                    int lo = 0, hi = 63; /* the window holding flat position t: last lane with off <= t */
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= t) lo = mid; else hi = mid - 1; }
-                    i = L.w0[lo] + (t - L.off[lo]);
-                    const float4 c = V.at(i);
-                    d = dist2_flann(qx, qy, qz, c.x, c.y, c.z);
-                    id = idx_of(c);
-                    in = d <= r2;
+            const int wtop = bhi - cb < 63 ? bhi - cb : 63; /* windows past it are empty */
+            for (int base = 0; base < T && !overflow; base += 256) {
+                /* four rounds of 64 candidates: their reads are in flight together */
+                float4 c4[4];
+                int i4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = base + 64 * u + lane;
+                    i4[u] = -1;
+                    if (t < T) {
+                        int lo = 0, hi = wtop; /* the window holding flat position t: last lane with off <= t */
+                        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= t) lo = mid; else hi = mid - 1; }
+                        i4[u] = L.w0[lo] + (t - L.off[lo]);
+                        c4[u] = V.at(i4[u]);
+                    }
                 }
-                const u64 mask = __ballot(in);
-                if (in) {
-                    const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.pos[slot] = i; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (base + 64 * u >= T) break;
+                    bool in = false;
+                    float d = 0.f;
+                    int id = 0;
+                    if (i4[u] >= 0) {
+                        d = dist2_flann(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
+                        id = idx_of(c4[u]);
+                        in = d <= r2;
+                    }
+                    const u64 mask = __ballot(in);
+                    if (in) {
+                        const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.pos[slot] = i4[u]; }
+                    }
+                    count += __popcll(mask);
+                    if (count > DYN_KNN_CAP) { overflow = true; break; }
                 }
-                count += __popcll(mask);
-                if (count > DYN_KNN_CAP) { overflow = true; break; }
             }
         }
         if (overflow) { r *= 0.8f; continue; }
@@ -120,7 +144,7 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
             const ulonglong2 a0 = kv[o], a1 = kv[o + 1], a2 = kv[o + 2], a3 = kv[o + 3];
             rank += (a0.x < kc) + (a0.y < kc) + (a1.x < kc) + (a1.y < kc) + (a2.x < kc) + (a2.y < kc) + (a3.x < kc) + (a3.y < kc);
         }
-        if (rank < kk) L.sel[rank] = L.pos[c];
+        if (rank < kk) { L.sel[rank] = L.pos[c]; L.sel_id[rank] = (int)(u32)kc; }
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -128,9 +152,20 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
     return kk;
 }
 
+/* a lane's ellipse angles (cos, sin): requested by the caller as early as it can, used at the very end of Area2Cloud */
+__device__ inline void dyn_load_ellipse(const float *__restrict__ ell_cs, float2 (&ecs)[DYN_ELL_PER])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < DYN_ELL_PER; ++q) {
+        const int a = lane + 64 * q;
+        ecs[q] = a < DYN_ELL ? ((const float2 *)ell_cs)[a] : make_float2(0.f, 0.f);
+    }
+}
+
 /* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative. */
 __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
-                                       const float *__restrict__ ell_cs, const DynParams &D, const double point[3], int key,
+                                       const float2 (&ecs)[DYN_ELL_PER], const DynParams &D, const double point[3], int key,
                                        float bound[3], StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
@@ -142,7 +177,7 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
     /* computePointPrincipalCurvatures: lane r holds the neighbour of rank r */
     float nn[3] = {0.f, 0.f, 0.f};
     if (lane < kk) {
-        const float4 nv = normals4[idx_of(V.at(L.sel[lane]))];
+        const float4 nv = normals4[L.sel_id[lane]];
         nn[0] = nv.x; nn[1] = nv.y; nn[2] = nv.z;
     }
     float n0[3];
@@ -154,25 +189,48 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
                         m2 = (i == 2 ? 1.f : 0.f) - n0[i] * n0[2];
             proj[i] = m0 * nn[0] + m1 * nn[1] + m2 * nn[2];
         }
+    sc.mark(9);
     /* centroid and covariance of the projected normals: summed neighbour by neighbour in rank order, as the reference's
        loops do (a tree reduction gives other last bits, and the ellipse extremum below is a discontinuous function of
-       them) -- every lane runs the same sequential sums on values broadcast from lane r */
+       them).  The nine sums are independent of each other, so each gets a lane of its own: the values go through LDS
+       (the key area is free after the ranking), lane a < 3 walks component a, then lane a < 6 walks one product --
+       64 dependent additions per phase instead of 64 x 3 and 64 x 6.  Lanes >= kk hold +0: adding it is exact. */
     auto lane_value = [](float v, int r) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); }; /* r is wave-uniform */
-    /* lanes >= kk hold zeros: adding them is exact, so the loops run all 64 ranks without a branch */
-    float cen[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 64; ++r)
-        for (int i = 0; i < 3; ++i) cen[i] += lane_value(proj[i], r);
-    for (int i = 0; i < 3; ++i) cen[i] /= (float)kk;
+    float *sv = (float *)L.key; /* [3][64] */
+    const int kk4 = (kk + 3) >> 2;
+    __builtin_amdgcn_wave_barrier();
+    sv[lane] = proj[0]; sv[64 + lane] = proj[1]; sv[128 + lane] = proj[2];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    float acc = 0.f;
+    {
+        const float4 *row = (const float4 *)(sv + 64 * (lane < 3 ? lane : 0));
+#pragma unroll 4
+        for (int r = 0; r < kk4; ++r) { const float4 v = row[r]; acc += v.x; acc += v.y; acc += v.z; acc += v.w; }
+    }
+    float cen[3];
+    for (int i = 0; i < 3; ++i) cen[i] = lane_value(acc, i) / (float)kk;
     float d[3] = {0.f, 0.f, 0.f};
     if (lane < kk) for (int i = 0; i < 3; ++i) d[i] = proj[i] - cen[i];
-    float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 64; ++r) {
-        const float dx = lane_value(d[0], r), dy = lane_value(d[1], r), dz = lane_value(d[2], r);
-        cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz;
-        cov[4] += dy * dy; cov[5] += dy * dz; cov[8] += dz * dz;
+    __builtin_amdgcn_wave_barrier();
+    sv[lane] = d[0]; sv[64 + lane] = d[1]; sv[128 + lane] = d[2];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    acc = 0.f;
+    {
+        /* lane 0..5: xx xy xz yy yz zz */
+        const int ia = lane < 3 ? 0 : (lane < 5 ? 1 : 2), ja = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
+        const float4 *ra = (const float4 *)(sv + 64 * (lane < 6 ? ia : 0)), *rb = (const float4 *)(sv + 64 * (lane < 6 ? ja : 0));
+#pragma unroll 4
+        for (int r = 0; r < kk4; ++r) {
+            const float4 a = ra[r], b = rb[r];
+            acc += a.x * b.x; acc += a.y * b.y; acc += a.z * b.z; acc += a.w * b.w;
+        }
     }
+    float cov[9];
+    cov[0] = lane_value(acc, 0); cov[1] = lane_value(acc, 1); cov[2] = lane_value(acc, 2);
+    cov[4] = lane_value(acc, 3); cov[5] = lane_value(acc, 4); cov[8] = lane_value(acc, 5);
+    sc.mark(10);
     cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
     /* pcl::eigen33(mat, evals) + computeCorrespondingEigenVector(mat, evals[2]) */
     float scale = 0.f;
@@ -217,13 +275,17 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
         shortAxis = (double)fabsf(1 / pc0) - sqrt(i0 * i0 - toolRadius * toolRadius);
         if (shortAxis > toolthickness) shortAxis = toolthickness;
     }
+    sc.mark(11);
     /* 721-point ellipse, transformed (SSE order c0*x + (c1*y + (c2*0 + c3))), first extremum in x */
     float bx = 0.f, by = 0.f, bz = 0.f;
     int ba = 0x7fffffff;
     bool have = false, first_nan = false;
-    for (int a = lane; a < DYN_ELL; a += 64) {
-        const float ex = (float)(longAxis * (double)ell_cs[2 * a]);
-        const float ey = (float)(shortAxis * (double)ell_cs[2 * a + 1]);
+#pragma unroll
+    for (int q = 0; q < DYN_ELL_PER; ++q) {
+        const int a = lane + 64 * q;
+        if (a >= DYN_ELL) break;
+        const float ex = (float)(longAxis * (double)ecs[q].x);
+        const float ey = (float)(shortAxis * (double)ecs[q].y);
         float t[3];
         for (int i = 0; i < 3; ++i) t[i] = cr[i] * ex + (cv[i] * ey + (n0[i] * 0.f + sp[i]));
         if (a == 0 && !(t[0] == t[0])) first_nan = true;
@@ -232,6 +294,7 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
         }
     }
     /* the reference folds in ascending angle: a NaN at angle 0 poisons the whole fold */
+    sc.mark(12);
     if (__ballot(first_nan)) return;
     for (int o = 32; o > 0; o >>= 1) {
         const float ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
@@ -255,18 +318,20 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_area2cloud_api(DevMeta *m, D
                                                                    const float *__restrict__ slab_xmin,
                                                                    const float *__restrict__ slab_xmax,
                                                                    const float4 *__restrict__ normals4,
-                                                                   const float *__restrict__ ell_cs, const double *__restrict__ pts,
-                                                                   int k, int key, float *out)
+                                                                   const float *__restrict__ ell_cs, const int *__restrict__ ytab,
+                                                                   const double *__restrict__ pts, int k, int key, float *out)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * DYN_WAVES + wv;
     if (q >= k) return;
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     double p[3] = {pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]};
     float b[3];
     StampCtx sc; sc.begin(15, false);
-    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, p, key, b, sc);
+    float2 ecs[DYN_ELL_PER];
+    dyn_load_ellipse(ell_cs, ecs);
+    wave_area2cloud(V, s_w[wv], normals4, ecs, D, p, key, b, sc);
     if ((threadIdx.x & 63) == 0) { out[3 * q] = b[0]; out[3 * q + 1] = b[1]; out[3 * q + 2] = b[2]; }
 }
 
@@ -294,38 +359,245 @@ struct DynBuffers {
     int *bnd_n;        /* [chain] knots of the current boundary (0 = none yet)  */
     float4 *adj_pts;   /* [chain][maxNA]  y x z valid                           */
     int maxNB, maxNA;
+    /* what k_dyn_first_eval leaves for every node i of every slice s, at [s][i] (it does not depend on the chain) */
+    float4 *first_ab;   /* Area2Cloud of the node as sampled: x y z, w = 0 no such node, 1 evaluated, 2 sample outside the spline */
+    double *first_node; /* [3]: the node as sampled                                                                           */
+    float4 *first_snap; /* its nearest cloud point: y x z, w = 1 found, 0 node not finite, 2 no answer                        */
 };
 
-/* Spline::point on float knots (y, x, z): same operations as GSL's steffen.c */
+/* LDS of the chain kernels: the scratch of a fit (keys, their staging, the samples themselves while there are at most
+   2048 of them, a histogram) shares its bytes with the per-wave search areas that are used after it; the knots the fit
+   produces follow */
+__host__ __device__ inline int dyn_fit_cap(int maxN) { const int c = maxN < 64 ? 64 : maxN; return c > 4096 ? 4096 : c; }
+__host__ __device__ inline bool dyn_fit_keeps_samples(int cap) { return cap <= 2048; }
+__host__ __device__ inline size_t dyn_scratch_bytes(int maxN)
+{
+    const int cap = dyn_fit_cap(maxN);
+    const size_t s = (dyn_fit_keeps_samples(cap) ? 36 : 20) * (size_t)cap + 16, w = DYN_WAVES * sizeof(DynWaveLds);
+    return ((s > w ? s : w) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t dyn_boundary_pts_lds(int maxNA) { return dyn_scratch_bytes(maxNA) + 12 * (size_t)dyn_fit_cap(maxNA); }
+__host__ __device__ inline size_t dyn_adjust_pts_lds(int maxNB) { return dyn_scratch_bytes(maxNB) + 16 * ((size_t)dyn_fit_cap(maxNB) + 2); }
+struct DynFitLds { u64 *keys, *stage; float4 *pay; int *hist; };
+__device__ inline DynFitLds dyn_fit_lds(char *raw, int cap)
+{
+    DynFitLds F;
+    F.keys = (u64 *)raw; F.stage = F.keys + cap;
+    F.pay = dyn_fit_keeps_samples(cap) ? (float4 *)(F.stage + cap) : nullptr;
+    F.hist = F.pay ? (int *)(F.pay + cap) : (int *)(F.stage + cap);
+    return F;
+}
+
+/* A fit, first part: the samples of one chain step are requested and staged (with their sort keys; ~0 marks an invalid
+   one).  No barrier in here: a kernel starts with it, so that these reads travel together with its other first reads.
+   Returns the thread's number of valid samples. */
+template <typename Valid, typename YOf>
+__device__ inline int dyn_stage_samples(const float4 *pts, int maxN, const DynFitLds &F, Valid valid, YOf yof)
+{
+    int nv = 0;
+#pragma unroll 4
+    for (int j = threadIdx.x; j < maxN; j += blockDim.x) {
+        const float4 p = pts[j];
+        if (F.pay) F.pay[j] = p;
+        u64 key = ~0ull;
+        if (valid(p)) {
+            float y = yof(p);
+            y = y == 0.f ? 0.f : y;
+            key = YK_MAKE(y, j);
+            ++nv;
+        }
+        F.stage[j] = key;
+    }
+    return nv;
+}
+
+/* Second part: the staged samples sorted by (y, sample number) -- the order of the reference's std::map insertions, whose
+   last writer wins --, invalid ones behind the valid ones; returns the number of valid ones.  maxN <= cap.  The buckets
+   span the cloud's y range (they only have to be monotone in y).  Whole workgroup. */
+__device__ inline int dyn_sort_staged(int nv, int maxN, const DynFitLds &F, int cap, int *scr17, const DevMeta *m)
+{
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    nv = wave_sum(nv);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && nv) atomicAdd(&s_n, nv);
+    const float y0 = m->mn[1], y1 = m->mx[1];
+    const int NB = min(next_pow2(max(maxN, 64)), cap);
+    const float scale = (y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
+    auto gen = [&](int i) { return F.stage[i]; };
+    auto bucket = [&](u64 k) {
+        if (k == ~0ull) return NB - 1;
+        const int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
+        return q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+    };
+    auto less = [&](u64 a, u64 b) { return a < b; };
+    block_bucket_sort(F.keys, maxN, F.hist, NB, scr17, gen, bucket, less);
+    return s_n;
+}
+
+/* One knot per distinct y of the n sorted keys: the last writer (highest sample number) of an equal-y run.  Every thread
+   takes a run of consecutive positions [q0, q1); returns the number of knots, *pre = the place of the thread's first one. */
+__device__ inline int dyn_count_knots(const u64 *keys, int n, int *scr17, int *pre, int *q0, int *q1)
+{
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    *q0 = min((int)threadIdx.x * per, n); *q1 = min(*q0 + per, n);
+    int c = 0;
+    for (int q = *q0; q < *q1; ++q) c += (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
+    int tot;
+    *pre = block_exscan(c, scr17, &tot);
+    return tot;
+}
+template <typename Emit>
+__device__ inline void dyn_emit_knots(const float4 *pts, const DynFitLds &F, int n, int q0, int q1, int pre, Emit emit)
+{
+    for (int q = q0; q < q1; ++q)
+        if ((q == n - 1) || (YK_Y(F.keys[q + 1]) != YK_Y(F.keys[q]))) {
+            const int j = YK_POS(F.keys[q]);
+            emit(pre++, F.pay ? F.pay[j] : pts[j]);
+        }
+}
+
+/* gsl_interp_bsearch over ascending float knots for a finite dy, by the whole wave: the largest i in [0, mm-2] with
+   y[i] <= dy (0 if there is none) from two rounds of 64 reads instead of log2(mm) dependent ones */
+__device__ inline int wave_gsl_bsearch_f(const float *ny, int mm, double dy)
+{
+    const int lane = threadIdx.x & 63;
+    const int top = mm - 1;
+    const int stride = (top + 63) >> 6;
+    if (stride > 64) { auto Yf = [&](int i) { return (double)ny[i]; }; return gsl_bsearch(mm, dy, Yf); }
+    const int i1 = lane * stride;
+    const u64 m1 = __ballot(i1 < top && (double)ny[i1] <= dy);
+    if (m1 == 0) return 0;
+    const int seg = (63 - __clzll(m1)) * stride;
+    const int i2 = seg + lane;
+    const u64 m2 = __ballot(lane < stride && i2 < top && (double)ny[i2] <= dy);
+    return seg + (63 - __clzll(m2));
+}
+
+/* Spline::point on float knots (y, x, z): same operations as GSL's steffen.c.  Called by all lanes of a wave together. */
 __device__ inline void spline_point_f(const float *ny, const float *nx, const float *nz, int mm, double dy, double out[3])
 {
     auto Yf = [&](int i) { return (double)ny[i]; };
     auto Xf = [&](int i) { return (double)nx[i]; };
     auto Zf = [&](int i) { return (double)nz[i]; };
-    const int iv = gsl_bsearch(mm, dy, Yf);
+    const int iv = wave_gsl_bsearch_f(ny, mm, dy);
     out[0] = steffen_eval_at(iv, mm, dy, Yf, Xf);
     out[1] = dy;
     out[2] = steffen_eval_at(iv, mm, dy, Yf, Zf);
 }
 
-/* compute_boundary, first half (path_dynamic_alg.cpp:191-203): one wave per sample of the previous path */
-__global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m, DynParams D, int walk, int t, int centre,
+/* The first Area2Cloud of dynamic_adjust_path's bisection (path_dynamic_alg.cpp:237-243) is taken at the node as sampled
+   from the slice's own spline (:278-284), and so is the final snap (:291-294) of a node the bisection leaves where it is:
+   neither depends on the neighbour's boundary.  They are evaluated here for all slices at once, ahead of the chain, which
+   then starts every node at its first comparison.  One wave per node; blockIdx.y = slice. */
+__global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, DynParams D, int walk, int centre,
         const float4 *__restrict__ sorted4, const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
-        const float *__restrict__ slab_xmax, const float4 *__restrict__ normals4, const float *__restrict__ ell_cs,
+        const float *__restrict__ slab_xmax, const float4 *__restrict__ normals4, const float *__restrict__ ell_cs, const int *__restrict__ ytab,
         const float *__restrict__ node_x, const float *__restrict__ node_y, const float *__restrict__ node_z,
         const int *__restrict__ node_start, const int *__restrict__ node_cnt, DynBuffers Bf)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
-    StampCtx sc; sc.begin(3, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    StampCtx sc; sc.begin(6, blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0);
     if (m->err) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * DYN_WAVES + wv, chain = blockIdx.y;
-    const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
-    if (!c.active || j >= Bf.maxNB) return;
-    const int st = node_start[c.prev], mm = node_cnt[c.prev];
+    const int s = blockIdx.y, i = blockIdx.x * DYN_WAVES + wv;
+    if (s >= m->S || i >= Bf.maxNA) return;
+    int key; /* of the chain that adjusts slice s */
+    if (walk == 1) { if (s == centre) return; key = s < centre ? 0 : 1; }
+    else { if (s == 0) return; key = 1; }
+    const size_t at = (size_t)s * Bf.maxNA + i;
+    auto none = [&](float status) { if (lane == 0) Bf.first_ab[at] = make_float4(0.f, 0.f, 0.f, status); };
+    const int st = node_start[s], mm = node_cnt[s];
+    if (mm < 3) { none(0.f); return; }
+    const double miny = (double)node_y[st], maxy = (double)node_y[st + mm - 1];
+    const int NumOfNode = (int)((maxy - miny) / 5);
+    const bool v1 = walk == 3; /* Path_Generation.cpp:607: for (i = 1; i < NumOfNode; i++) */
+    const int ii = v1 ? i + 1 : i;
+    if (v1 ? ii >= NumOfNode : ii > NumOfNode) { none(0.f); return; }
+    double dy = ((maxy - miny) / NumOfNode * ii) + miny;
+    if (dy > maxy) dy = maxy; /* B.13: the reference aborts in GSL when the last sample lands an ulp past the last knot */
+    if (!(dy >= miny && dy <= maxy)) { none(2.f); return; } /* gsl_spline_eval: GSL_EDOM (raised by the chain when it gets here) */
+    double node[3];
+    spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
+    float ab[3];
+    float2 ecs[DYN_ELL_PER];
+    dyn_load_ellipse(ell_cs, ecs);
+    wave_area2cloud(V, s_w[wv], normals4, ecs, D, node, key == 0 ? 1 : 0, ab, sc);
+    const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
+    const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
+    const int got = finite ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
+    if (lane == 0) {
+        Bf.first_ab[at] = make_float4(ab[0], ab[1], ab[2], 1.f);
+        Bf.first_node[3 * at] = node[0]; Bf.first_node[3 * at + 1] = node[1]; Bf.first_node[3 * at + 2] = node[2];
+        if (!finite) Bf.first_snap[at] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (got < 1) Bf.first_snap[at] = make_float4(0.f, 0.f, 0.f, 2.f);
+        else { const float4 p = V.at(s_w[wv].sel[0]); Bf.first_snap[at] = make_float4(p.y, p.x, p.z, 1.f); }
+    }
+}
+
+/* Step t, first launch.  Every workgroup begins with the second half of dynamic_adjust_path for the slice of step t-1
+   (path_dynamic_alg.cpp:297-305: map by y, Spline::restart) -- the same few hundred samples sorted by every workgroup for
+   itself, which costs less than a launch of its own between two dependent kernels; one extra workgroup per chain, which
+   has no samples, commits the knots to the node arrays -- and goes on with compute_boundary's first half (:191-203) on those knots: one wave per
+   sample of the previous path. */
+__global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m, DynParams D, int walk, int t, int centre,
+        const float4 *__restrict__ sorted4, const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+        const float *__restrict__ slab_xmax, const float4 *__restrict__ normals4, const float *__restrict__ ell_cs, const int *__restrict__ ytab,
+        float *node_x, float *node_y, float *node_z, int node_cap, int *node_start, int *node_cnt, DynBuffers Bf)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    __shared__ int s_scr[17];
+    __shared__ int s_base;
+    StampCtx sc; sc.begin(3, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chain = blockIdx.y;
+    const int capA = dyn_fit_cap(Bf.maxNA);
+    float *ly = (float *)(s_raw + dyn_scratch_bytes(Bf.maxNA)), *lx = ly + capA, *lz = lx + capA;
+    const DynFitLds F = dyn_fit_lds(s_raw, capA);
+    const float4 *pts = Bf.adj_pts + (size_t)chain * Bf.maxNA; /* (y, x, z, valid) */
+    /* first reads, all at once: the samples of the step before, the ellipse table, the state of the pass */
+    const int nv = t > 0 ? dyn_stage_samples(pts, Bf.maxNA, F, [](const float4 &p) { return p.w != 0.f; }, [](const float4 &p) { return p.x; }) : 0;
+    const int bn = (t > 0 && walk == 3) ? Bf.bnd_n[chain] : 3;
+    float2 ecs[DYN_ELL_PER];
+    dyn_load_ellipse(ell_cs, ecs);
+    if (m->err) return;
+    const int S = m->S;
+    const float *ky = nullptr, *kx = nullptr, *kz = nullptr; /* knots of the previous path */
+    int mm = 0;
+    if (t > 0) {
+        const DynChain cp = dyn_chain(walk, chain, t - 1, centre, S);
+        /* v1, "generate boundary fail": the path stays as fitted */
+        if (cp.active && !(walk == 3 && bn < 3)) {
+            const int n = dyn_sort_staged(nv, Bf.maxNA, F, capA, s_scr, m);
+            int pre, q0, q1;
+            const int tot = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
+            if (tot < 3) { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) set_err(m, DERR_SLICE, cp.s); return; } /* gsl_spline_alloc */
+            dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) { ly[o] = p.x == 0.f ? 0.f : p.x; lx[o] = p.y; lz[o] = p.z; });
+            __syncthreads();
+            if (blockIdx.x == gridDim.x - 1) { /* the launch's extra workgroup: it commits the knots and has no samples */
+                if (threadIdx.x == 0) {
+                    int base = atomicAdd(&m->node_cursor, tot);
+                    if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, cp.s); base = -1; }
+                    s_base = base;
+                }
+                __syncthreads();
+                const int base = s_base;
+                if (base < 0) return;
+                for (int q = threadIdx.x; q < tot; q += blockDim.x) { node_y[base + q] = ly[q]; node_x[base + q] = lx[q]; node_z[base + q] = lz[q]; }
+                if (threadIdx.x == 0) { node_start[cp.s] = base; node_cnt[cp.s] = tot; }
+                return;
+            }
+            ky = ly; kx = lx; kz = lz; mm = tot;
+        }
+    }
+    const DynChain c = dyn_chain(walk, chain, t, centre, S);
+    const int j = blockIdx.x * DYN_WAVES + wv;
+    if (!c.active || j >= Bf.maxNB || blockIdx.x == gridDim.x - 1) return;
+    if (!ky) { const int st = node_start[c.prev]; mm = node_cnt[c.prev]; ky = node_y + st; kx = node_x + st; kz = node_z + st; }
     float4 *dst = Bf.bnd_pts + (size_t)chain * Bf.maxNB + j;
     if (mm < 3) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
-    const double miny = (double)node_y[st], maxy = (double)node_y[st + mm - 1];
+    const double miny = (double)ky[0], maxy = (double)ky[mm - 1];
     /* dy = miny + 2; dy += toolRadius/4 per sample.  When start and step are multiples of 2^-20 (float knots and the
        usual radii are) every partial sum is exact in double and the closed form gives the same bits; else accumulate */
     const double dstep = D.tool_radius / 4, dy0 = miny + 2;
@@ -340,233 +612,177 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     if (!(dy < maxy - 2)) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
     sc.mark(0);
     double point[3];
-    spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, point);
+    spline_point_f(ky, kx, kz, mm, dy, point);
     sc.mark(1);
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float b[3];
-    wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, point, c.key, b, sc);
+    wave_area2cloud(V, ((DynWaveLds *)s_raw)[wv], normals4, ecs, D, point, c.key, b, sc);
     if (lane == 0) *dst = make_float4(b[0], b[1], b[2], 1.f);
     sc.mark(6);
 }
 
-/* compute_boundary, second half (:211-234): std::map by y (last writer wins), two extra end knots */
-__global__ void __launch_bounds__(256) k_dyn_boundary_fit(DevMeta *m, int walk, int t, int centre, DynBuffers Bf)
+/* Step t, second launch.  Every workgroup begins with compute_boundary's second half (path_dynamic_alg.cpp:211-234:
+   std::map by y, last writer wins, two extra end knots) on the samples the first launch left -- again sorted by each
+   workgroup for itself, the knots staying in its LDS; workgroup 0 of the chain keeps the copy in HBM that a later step falls
+   back to when its own boundary has fewer than 3 knots -- and goes on with dynamic_adjust_path's first half (:278-295),
+   one wave per node, from the node's first comparison on (its first Area2Cloud is k_dyn_first_eval's). */
+__global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, DynParams D, int walk, int t, int centre,
+        const float4 *__restrict__ sorted4, const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
+        const float *__restrict__ slab_xmax, const float4 *__restrict__ normals4, const float *__restrict__ ell_cs, const int *__restrict__ ytab,
+        int S_cap, DynBuffers Bf)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
-    __shared__ int s_n, s_m;
+    StampCtx sc; sc.begin(4, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chain = blockIdx.y;
+    const int capB = dyn_fit_cap(Bf.maxNB);
+    const DynFitLds F = dyn_fit_lds(s_raw, capB);
+    const float4 *pts = Bf.bnd_pts + (size_t)chain * Bf.maxNB;
+    /* first reads, all at once: the boundary samples of this step (isnan(boundpoint[0]) -> continue; a NaN key is skipped
+       too), this wave's node as k_dyn_first_eval left it, the state of the pass */
+    const int nv = dyn_stage_samples(pts, Bf.maxNB, F, [](const float4 &p) { return p.w != 0.f && p.x == p.x && p.y == p.y; },
+                                     [](const float4 &p) { return p.y; });
+    const int i = blockIdx.x * DYN_WAVES + wv;
+    const DynChain cg = dyn_chain(walk, chain, t, centre, S_cap); /* the step's slice, whether or not it exists */
+    const size_t at = (cg.s >= 0 && cg.s < S_cap && i < Bf.maxNA) ? (size_t)cg.s * Bf.maxNA + i : 0;
+    const float4 first = Bf.first_ab[at];
+    double node[3] = {Bf.first_node[3 * at], Bf.first_node[3 * at + 1], Bf.first_node[3 * at + 2]};
     if (m->err) return;
-    const int chain = blockIdx.x;
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
-    const int cap = 4096;
-    u64 *keys = (u64 *)s_raw;            /* cap: (ord(by) << 31) | j */
-    int *hist = (int *)(keys + cap);     /* cap + 1 */
-    u64 *stage = (u64 *)(hist + cap + 2); /* cap */
-    const float4 *pts = Bf.bnd_pts + (size_t)chain * Bf.maxNB;
-    if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
-    __syncthreads();
-    /* gather the valid samples in loop order (the order only matters inside equal keys, and there
-       the key carries j) */
-    float ymin = INFINITY, ymax = -INFINITY;
-    for (int j = threadIdx.x; j < Bf.maxNB; j += blockDim.x) {
-        float4 p = pts[j];
-        if (p.w != 0.f && p.x == p.x && p.y == p.y) { /* isnan(boundpoint[0]) -> continue; a NaN key is skipped too */
-            float y = p.y == 0.f ? 0.f : p.y;
-            int slot = atomicAdd(&s_n, 1);
-            if (slot < cap) stage[slot] = YK_MAKE(y, j);
-            ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
+    double *ly = (double *)(s_raw + dyn_scratch_bytes(Bf.maxNB)), *lx = ly + capB + 2;
+    double *gy = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *gx = gy + (Bf.maxNB + 2), *gz = gx + (Bf.maxNB + 2);
+    const double *ky = gy, *kx = gx;
+    int nb;
+    {
+        const int n = dyn_sort_staged(nv, Bf.maxNB, F, capB, s_scr, m);
+        int pre, q0, q1;
+        const int node_number = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
+        if (node_number <= 2) { /* compute_boundary returns 0: the previous boundary stays; v1 has none then (Path_Generation.cpp:589-592) */
+            if (walk == 3) { nb = 0; if (blockIdx.x == 0 && threadIdx.x == 0) Bf.bnd_n[chain] = 0; }
+            else nb = Bf.bnd_n[chain];
+            __syncthreads(); /* the scratch becomes the waves' search areas */
+        } else {
+            const bool keep_copy = blockIdx.x == 0;
+            dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) {
+                const double y = (double)(p.y == 0.f ? 0.f : p.y);
+                ly[1 + o] = y; lx[1 + o] = (double)p.x;
+                if (keep_copy) { gy[1 + o] = y; gx[1 + o] = (double)p.x; gz[1 + o] = (double)p.z; }
+            });
+            __syncthreads();
+            if (threadIdx.x == 0) { /* get longer boundary, add new node at start & end (:223-229) */
+                const int idx = node_number;
+                lx[0] = lx[1]; ly[0] = ly[1] - 20;
+                lx[idx + 1] = lx[idx]; ly[idx + 1] = ly[idx] + 20;
+                if (keep_copy) {
+                    gx[0] = lx[0]; gy[0] = ly[0]; gz[0] = gz[1];
+                    gx[idx + 1] = lx[idx + 1]; gy[idx + 1] = ly[idx + 1]; gz[idx + 1] = gz[idx];
+                    Bf.bnd_n[chain] = node_number + 2;
+                }
+            }
+            __syncthreads();
+            nb = node_number + 2; ky = ly; kx = lx;
         }
     }
-    __syncthreads();
-    const int n = s_n;
-    if (n > cap) { if (threadIdx.x == 0) set_err(m, DERR_CAPACITY, c.s); return; }
-    ymin = wave_min(ymin); ymax = wave_max(ymax);
-    __shared__ float s_lo[4], s_hi[4];
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = ymin; s_hi[threadIdx.x >> 6] = ymax; }
-    __syncthreads();
-    const float y0 = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
-    const float y1 = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-    const int NB = next_pow2(max(n, 64));
-    const float scale = (y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
-    auto gen = [&](int i) { return stage[i]; };
-    auto bucket = [&](u64 k) { int q = (int)((ord2f(YK_Y(k)) - y0) * scale); return q < 0 ? 0 : (q >= NB ? NB - 1 : q); };
-    auto less = [&](u64 a, u64 b) { return a < b; };
-    block_bucket_sort(keys, n, hist, min(NB, cap), s_scr, gen, bucket, less);
-    /* one knot per distinct y: the last writer (highest j) of an equal-y run */
-    int mcount = 0;
-    for (int q = threadIdx.x; q < n; q += blockDim.x) mcount += (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
-    int node_number;
-    block_exscan(mcount, s_scr, &node_number);
-    if (node_number <= 2) { /* compute_boundary returns 0: the previous boundary stays; v1 has none then (Path_Generation.cpp:589-592) */
-        if (walk == 3 && threadIdx.x == 0) Bf.bnd_n[chain] = 0;
-        return;
-    }
-    double *ky = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *kx = ky + (Bf.maxNB + 2), *kz = kx + (Bf.maxNB + 2);
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int q = base + threadIdx.x;
-        int keep = 0;
-        if (q < n) keep = (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
-        int tot;
-        const int pre = block_exscan(keep, s_scr, &tot);
-        const int o = s_m;
-        if (keep) {
-            const float4 p = pts[YK_POS(keys[q])];
-            ky[1 + o + pre] = (double)(p.y == 0.f ? 0.f : p.y); kx[1 + o + pre] = (double)p.x; kz[1 + o + pre] = (double)p.z;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_m = o + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { /* get longer boundary, add new node at start & end (:223-229) */
-        const int idx = node_number;
-        kx[0] = kx[1]; ky[0] = ky[1] - 20; kz[0] = kz[1];
-        kx[idx + 1] = kx[idx]; ky[idx + 1] = ky[idx] + 20; kz[idx + 1] = kz[idx];
-        Bf.bnd_n[chain] = node_number + 2;
-    }
-}
-
-/* dynamic_adjust_path, first half (path_dynamic_alg.cpp:278-295): one wave per node of the path */
-__global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, DynParams D, int walk, int t, int centre,
-        const float4 *__restrict__ sorted4, const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
-        const float *__restrict__ slab_xmax, const float4 *__restrict__ normals4, const float *__restrict__ ell_cs,
-        const float *__restrict__ node_x, const float *__restrict__ node_y, const float *__restrict__ node_z,
-        const int *__restrict__ node_start, const int *__restrict__ node_cnt, DynBuffers Bf)
-{
-    __shared__ DynWaveLds s_w[DYN_WAVES];
-    StampCtx sc; sc.begin(4, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
-    if (m->err) return;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * DYN_WAVES + wv, chain = blockIdx.y;
-    const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
-    if (!c.active || i >= Bf.maxNA) return;
+    if (i >= Bf.maxNA) return;
     float4 *dst = Bf.adj_pts + (size_t)chain * Bf.maxNA + i;
-    const int st = node_start[c.s], mm = node_cnt[c.s];
-    if (mm < 3) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
-    const double miny = (double)node_y[st], maxy = (double)node_y[st + mm - 1];
-    const int NumOfNode = (int)((maxy - miny) / 5);
-    const bool v1 = walk == 3; /* Path_Generation.cpp:607: for (i = 1; i < NumOfNode; i++) */
-    const int ii = v1 ? i + 1 : i;
-    if (v1 ? ii >= NumOfNode : ii > NumOfNode) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
-    const int nb = Bf.bnd_n[chain];
+    if (first.w == 0.f) { if (lane == 0) *dst = make_float4(0, 0, 0, 0); return; }
+    const bool v1 = walk == 3;
     if (nb < 3) { /* no boundary: v1 leaves the path alone; v2 would read an unconstructed Spline */
         if (lane == 0) { if (v1) *dst = make_float4(0, 0, 0, 0); else set_err(m, DERR_SLICE, c.s); }
         return;
     }
-    double dy = ((maxy - miny) / NumOfNode * ii) + miny;
-    if (dy > maxy) dy = maxy; /* B.13: the reference aborts in GSL when the last sample lands an ulp past the last knot */
-    if (!(dy >= miny && dy <= maxy)) { if (lane == 0) set_err(m, DERR_DOMAIN, c.s); return; } /* gsl_spline_eval: GSL_EDOM */
+    if (first.w == 2.f) { if (lane == 0) set_err(m, DERR_DOMAIN, c.s); return; } /* gsl_spline_eval: GSL_EDOM */
     sc.mark(0);
-    double node[3];
-    spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
-    sc.mark(1);
-    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
-    const double *ky = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *kx = ky + (Bf.maxNB + 2);
+    SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
+    DynWaveLds &L = ((DynWaveLds *)s_raw)[wv];
     const double bminy = ky[0], bbigy = ky[nb - 1];
     auto BY = [&](int q) { return ky[q]; };
     auto BX = [&](int q) { return kx[q]; };
-    /* bisection (:237-265), at most 6 Area2Cloud evaluations */
+    /* bisection (:237-265), at most 6 Area2Cloud evaluations, the first of them taken ahead of the chain */
+    float ab[3] = {first.x, first.y, first.z};
+    bool moved = false;
+#ifdef DYN_COUNT_ITERS
+    int nev = 0;
+#endif
     for (int itr = 0; itr <= 5; ++itr) {
-        float ab[3];
-        wave_area2cloud(V, s_w[wv], normals4, ell_cs, D, node, c.key == 0 ? 1 : 0, ab, sc);
+#ifdef DYN_COUNT_ITERS
+        ++nev;
+#endif
+        if (itr > 0) {
+            float2 ecs[DYN_ELL_PER];
+            dyn_load_ellipse(ell_cs, ecs);
+            wave_area2cloud(V, L, normals4, ecs, D, node, c.key == 0 ? 1 : 0, ab, sc);
+        }
         if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break; /* a NaN bound passes, as in the reference: the node turns NaN below */
         const int iv = gsl_bsearch(nb, (double)ab[1], BY);
         const double bpx = steffen_eval_at(iv, nb, (double)ab[1], BY, BX);
         const double norm0 = (double)ab[0] - bpx;
         if (fabs(norm0) < D.adjust_threshold) break;
         node[0] = node[0] - norm0;
+        moved = true;
         if (!(node[0] == node[0])) break;
         sc.mark(6);
     }
     sc.mark(7);
+#ifdef DYN_COUNT_ITERS
+    if (lane == 0) atomicAdd(&m->sweeps, 1 + (nev > 1 ? 65536 : 0));
+#endif
     /* kdtree.nearestKSearch(point, 3): only pointIdx[0] is used (:291-294).  B.14: a node that Area2Cloud turned NaN
        ("adjust path node NAN", :258-261) adds no knot (the reference hands the NaN to FLANN and reads whatever
        pointIdx holds afterwards) */
+    if (!moved) { /* the node as sampled: its snap is k_dyn_first_eval's */
+        if (lane == 0) {
+            const float4 sn = Bf.first_snap[at];
+            if (sn.w == 1.f) *dst = sn;
+            else { if (sn.w == 2.f) set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
+        }
+        return;
+    }
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
-    const int got = finite ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
+    const int got = finite ? wave_knn(V, L, qx, qy, qz, 1, D.r1, sc) : 0;
     if (lane == 0) {
         if (!finite) *dst = make_float4(0, 0, 0, 0);
         else if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
-        else { const float4 p = V.at(s_w[wv].sel[0]); *dst = make_float4(p.y, p.x, p.z, 1.f); }
+        else { const float4 p = V.at(L.sel[0]); *dst = make_float4(p.y, p.x, p.z, 1.f); }
     }
     sc.mark(8);
 }
 
-/* dynamic_adjust_path, second half (:297-305): map by y, Spline::restart */
+/* dynamic_adjust_path, second half (:297-305) as a launch of its own: after the last step of the chains (every earlier step
+   is finished by the next step's first launch) */
 __global__ void __launch_bounds__(256) k_dyn_adjust_fit(DevMeta *m, int walk, int t, int centre, DynBuffers Bf, float *node_x,
                                                         float *node_y, float *node_z, int node_cap, int *node_start, int *node_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
-    __shared__ int s_n, s_m, s_base;
-    __shared__ float s_lo[4], s_hi[4];
+    __shared__ int s_base;
     if (m->err) return;
     const int chain = blockIdx.x;
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
     if (walk == 3 && Bf.bnd_n[chain] < 3) return; /* "generate boundary fail": the path stays as fitted */
-    const int cap = 4096;
-    u64 *keys = (u64 *)s_raw;
-    int *hist = (int *)(keys + cap);
-    u64 *stage = (u64 *)(hist + cap + 2);
+    const int capA = dyn_fit_cap(Bf.maxNA);
+    const DynFitLds F = dyn_fit_lds(s_raw, capA);
     const float4 *pts = Bf.adj_pts + (size_t)chain * Bf.maxNA;
-    if (threadIdx.x == 0) { s_n = 0; s_m = 0; }
-    __syncthreads();
-    float ymin = INFINITY, ymax = -INFINITY;
-    for (int i = threadIdx.x; i < Bf.maxNA; i += blockDim.x) {
-        float4 p = pts[i];
-        if (p.w != 0.f) {
-            float y = p.x == 0.f ? 0.f : p.x; /* adj_pts = (y, x, z, valid) */
-            int slot = atomicAdd(&s_n, 1);
-            if (slot < cap) stage[slot] = YK_MAKE(y, i);
-            ymin = fminf(ymin, y); ymax = fmaxf(ymax, y);
-        }
-    }
-    __syncthreads();
-    const int n = s_n;
-    if (n > cap) { if (threadIdx.x == 0) set_err(m, DERR_CAPACITY, c.s); return; }
-    ymin = wave_min(ymin); ymax = wave_max(ymax);
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = ymin; s_hi[threadIdx.x >> 6] = ymax; }
-    __syncthreads();
-    const float y0 = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
-    const float y1 = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
-    const int NB = next_pow2(max(n, 64));
-    const float scale = (y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
-    auto gen = [&](int i) { return stage[i]; };
-    auto bucket = [&](u64 k) { int q = (int)((ord2f(YK_Y(k)) - y0) * scale); return q < 0 ? 0 : (q >= NB ? NB - 1 : q); };
-    auto less = [&](u64 a, u64 b) { return a < b; };
-    block_bucket_sort(keys, n, hist, min(NB, cap), s_scr, gen, bucket, less);
-    int mcount = 0;
-    for (int q = threadIdx.x; q < n; q += blockDim.x) mcount += (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
-    int tot;
-    block_exscan(mcount, s_scr, &tot);
+    const int nv = dyn_stage_samples(pts, Bf.maxNA, F, [](const float4 &p) { return p.w != 0.f; }, [](const float4 &p) { return p.x; });
+    const int n = dyn_sort_staged(nv, Bf.maxNA, F, capA, s_scr, m);
+    int pre, q0, q1;
+    const int tot = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
     if (threadIdx.x == 0) {
-        int base = 0;
+        int base = -1;
         if (tot < 3) set_err(m, DERR_SLICE, c.s); /* gsl_spline_alloc */
         else {
             base = atomicAdd(&m->node_cursor, tot);
-            if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, c.s); base = 0; tot = 0; }
+            if (base + tot > node_cap) { set_err(m, DERR_CAPACITY, c.s); base = -1; }
         }
         s_base = base;
     }
     __syncthreads();
-    if (m->err) return;
-    float *ox = node_x + s_base, *oy = node_y + s_base, *oz = node_z + s_base;
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int q = base + threadIdx.x;
-        int keep = 0;
-        if (q < n) keep = (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
-        int t2;
-        const int pre = block_exscan(keep, s_scr, &t2);
-        const int o = s_m;
-        if (keep) {
-            const float4 p = pts[YK_POS(keys[q])];
-            oy[o + pre] = p.x == 0.f ? 0.f : p.x; ox[o + pre] = p.y; oz[o + pre] = p.z;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_m = o + t2;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { node_start[c.s] = s_base; node_cnt[c.s] = s_m; }
+    const int base = s_base;
+    if (base < 0) return;
+    dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) { node_y[base + o] = p.x == 0.f ? 0.f : p.x; node_x[base + o] = p.y; node_z[base + o] = p.z; });
+    if (threadIdx.x == 0) { node_start[c.s] = base; node_cnt[c.s] = tot; }
 }

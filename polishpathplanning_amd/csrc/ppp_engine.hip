@@ -117,7 +117,8 @@ struct ppp_handle_s {
     DevBuf<float> px, lo, hi;
     DevBuf<float> node_x, node_y, node_z;
     /* dynamic adjustment (allocated when Dynamic_adjustment is on or ppp_area2cloud is used) */
-    DevBuf<float4> normals4, dyn_bnd_pts, dyn_adj_pts;
+    DevBuf<float4> normals4, dyn_bnd_pts, dyn_adj_pts, dyn_first_ab, dyn_first_snap;
+    DevBuf<double> dyn_first_node;
     DevBuf<float> ell_cs;
     DevBuf<double> dyn_bnd_knots;
     DevBuf<int> dyn_bnd_n;
@@ -172,7 +173,7 @@ struct ppp_handle_s {
         X.release(); Y.release(); Z.release(); Xp.release(); Yp.release(); Zp.release(); part_idx.release(); unsorted4.release(); sorted4.release();
         slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_ytab.release(); slab_xmin.release(); slab_xmax.release();
         meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
-        normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
+        normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); dyn_first_ab.release(); dyn_first_snap.release(); dyn_first_node.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
@@ -337,6 +338,8 @@ int ensure_dynamic_buffers(ppp_handle h)
     HIPCHK(h, h->normals4.ensure(std::max<size_t>(h->n, 1)));
     HIPCHK(h, h->dyn_bnd_pts.ensure(2 * (size_t)h->dyn_maxNB)); HIPCHK(h, h->dyn_adj_pts.ensure(2 * (size_t)h->dyn_maxNA));
     HIPCHK(h, h->dyn_bnd_knots.ensure(2 * 3 * ((size_t)h->dyn_maxNB + 2))); HIPCHK(h, h->dyn_bnd_n.ensure(2));
+    const size_t nfirst = (size_t)std::max(h->S_cap, 1) * h->dyn_maxNA;
+    HIPCHK(h, h->dyn_first_ab.ensure(nfirst)); HIPCHK(h, h->dyn_first_node.ensure(3 * nfirst)); HIPCHK(h, h->dyn_first_snap.ensure(nfirst));
     if (!h->ell_cs.p) {
         /* cos / sin of the 721 ellipse angles, computed as the reference does (float angle, pcl::deg2rad,
            std::cos(float)) with the host libm so the device uses the very same values */
@@ -617,28 +620,35 @@ int host_centre_index(const ppp_handle h)
 /* GenPath with Adjust = true: whole-cloud normals, then the slice-to-slice chains */
 int enqueue_dynamic(ppp_handle h)
 {
+    if (h->dyn_maxNB > 4096 || h->dyn_maxNA > 4096)
+        return fail(h, PPP_ERR_CAPACITY, "dynamic adjustment: more than 4096 boundary or path samples per slice");
     int rc = enqueue_normals(h);
     if (rc) return rc;
     const DynParams D = dyn_params(h);
-    DynBuffers Bf{h->dyn_bnd_pts.p, h->dyn_bnd_knots.p, h->dyn_bnd_n.p, h->dyn_adj_pts.p, h->dyn_maxNB, h->dyn_maxNA};
+    DynBuffers Bf{h->dyn_bnd_pts.p, h->dyn_bnd_knots.p, h->dyn_bnd_n.p, h->dyn_adj_pts.p, h->dyn_maxNB, h->dyn_maxNA,
+                  h->dyn_first_ab.p, h->dyn_first_node.p, h->dyn_first_snap.p};
     HIPCHK(h, hipMemsetAsync(h->dyn_bnd_n.p, 0, 2 * sizeof(int), h->stream));
     const int S = h->S_cap, walk = h->P.walk;
     const int centre = walk == PPP_WALK_CENTER_INT ? host_centre_index(h) : 0;
     const int nchains = walk == PPP_WALK_CENTER_INT ? 2 : 1;
     const int steps = walk == PPP_WALK_CENTER_INT ? std::max(centre, S - 1 - centre) : S - 1;
-    const size_t fit_lds = (size_t)4096 * 8 * 2 + (size_t)(4096 + 2) * 4 + 64;
-    const dim3 gb((Bf.maxNB + DYN_WAVES - 1) / DYN_WAVES, nchains), ga((Bf.maxNA + DYN_WAVES - 1) / DYN_WAVES, nchains);
+    const dim3 gb((Bf.maxNB + DYN_WAVES - 1) / DYN_WAVES + 1, nchains), ga((Bf.maxNA + DYN_WAVES - 1) / DYN_WAVES, nchains);
+    const size_t lds_b = dyn_boundary_pts_lds(Bf.maxNA), lds_a = dyn_adjust_pts_lds(Bf.maxNB);
+    /* every node's first Area2Cloud and snap, for all slices at once: they do not depend on the chains */
+    LAUNCH(h, "k_dyn_first_eval", k_dyn_first_eval, dim3(ga.x, S), 64 * DYN_WAVES, 0, h->meta.p, D, walk, centre, h->sorted4.p,
+           h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->slab_ytab.p, h->node_x.p, h->node_y.p,
+           h->node_z.p, h->node_start.p, h->node_cnt.p, Bf);
+    /* two launches per step: each begins with the fit of what the launch before it sampled */
     for (int t = 0; t < steps; ++t) {
-        LAUNCH(h, "k_dyn_boundary_pts", k_dyn_boundary_pts, gb, 64 * DYN_WAVES, 0, h->meta.p, D, walk, t, centre, h->sorted4.p,
-               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->node_x.p, h->node_y.p, h->node_z.p,
-               h->node_start.p, h->node_cnt.p, Bf);
-        LAUNCH(h, "k_dyn_boundary_fit", k_dyn_boundary_fit, nchains, 256, fit_lds, h->meta.p, walk, t, centre, Bf);
-        LAUNCH(h, "k_dyn_adjust_pts", k_dyn_adjust_pts, ga, 64 * DYN_WAVES, 0, h->meta.p, D, walk, t, centre, h->sorted4.p,
-               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->node_x.p, h->node_y.p, h->node_z.p,
-               h->node_start.p, h->node_cnt.p, Bf);
-        LAUNCH(h, "k_dyn_adjust_fit", k_dyn_adjust_fit, nchains, 256, fit_lds, h->meta.p, walk, t, centre, Bf, h->node_x.p, h->node_y.p,
-               h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p);
+        LAUNCH(h, "k_dyn_boundary_pts", k_dyn_boundary_pts, gb, 64 * DYN_WAVES, lds_b, h->meta.p, D, walk, t, centre, h->sorted4.p,
+               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->slab_ytab.p, h->node_x.p, h->node_y.p,
+               h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p, Bf);
+        LAUNCH(h, "k_dyn_adjust_pts", k_dyn_adjust_pts, ga, 64 * DYN_WAVES, lds_a, h->meta.p, D, walk, t, centre, h->sorted4.p,
+               h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->slab_ytab.p, S, Bf);
     }
+    if (steps > 0)
+        LAUNCH(h, "k_dyn_adjust_fit", k_dyn_adjust_fit, nchains, 256, dyn_scratch_bytes(Bf.maxNA), h->meta.p, walk, steps - 1, centre, Bf,
+               h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p);
     return PPP_OK;
 }
 
@@ -856,7 +866,8 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_pose<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<false, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<true, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
-    (void)hipFuncSetAttribute((const void *)k_dyn_boundary_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_dyn_boundary_pts, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_dyn_adjust_pts, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
@@ -2181,7 +2192,7 @@ int ppp_area2cloud(ppp_handle h, const double *pts_xyz, size_t k, int key, float
     float *dout = (float *)(dq + 3 * k);
     HIPCHK(h, hipMemcpyAsync(dq, pts_xyz, k * 24, hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "k_area2cloud_api", k_area2cloud_api, (unsigned)((k + DYN_WAVES - 1) / DYN_WAVES), 64 * DYN_WAVES, 0, h->meta.p, dyn_params(h),
-           h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, dq, (int)k, key, dout);
+           h->sorted4.p, h->slab_start.p, h->slab_xmin.p, h->slab_xmax.p, h->normals4.p, h->ell_cs.p, h->slab_ytab.p, dq, (int)k, key, dout);
     HIPCHK(h, hipMemcpyAsync(out3, dout, k * 12, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PPP_OK;

@@ -22,9 +22,10 @@ labels = {0: ("k_slice_kd", ["gather", "band sort", "NN+lerp", "cand sort", "fla
           5: ("k_setup", ["partials", "slab scan", "bounds+walk", "band limits"]),
           }
 if dynamic:
-    labels[3] = ("k_dyn_boundary_pts", ["prologue+dy", "spline", "knn search", "knn rank", "curvature", "ellipse", "store"])
-    labels[4] = ("k_dyn_adjust_pts", ["prologue", "spline", "knn search (all)", "knn rank (all)", "curvature", "ellipse",
-                                      "boundary eval", "-", "snap store"])
+    labels[3] = ("k_dyn_boundary_pts", ["prologue+dy", "spline", "knn search", "knn rank", "eigen", "extremum", "store", "-", "-",
+                                         "normals gather", "rank-order sums", "axes", "ellipse points"])
+    labels[4] = ("k_dyn_adjust_pts", ["prologue", "spline", "knn search (all)", "knn rank (all)", "eigen", "extremum",
+                                      "boundary eval", "-", "snap store", "normals gather", "rank-order sums", "axes", "ellipse points"])
 for kid, (kn, ls) in labels.items():
     vals = [out[16 * kid + i] / N for i in range(len(ls))]
     tot = sum(vals) or 1
