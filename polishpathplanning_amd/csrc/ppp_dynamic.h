@@ -412,48 +412,73 @@ __device__ inline int dyn_stage_samples(const float4 *pts, int maxN, const DynFi
 }
 
 /* Second part: the staged samples sorted by (y, sample number) -- the order of the reference's std::map insertions, whose
-   last writer wins --, invalid ones behind the valid ones; returns the number of valid ones.  maxN <= cap.  The buckets
-   span the cloud's y range (they only have to be monotone in y).  Whole workgroup. */
-__device__ inline int dyn_sort_staged(int nv, int maxN, const DynFitLds &F, int cap, int *scr17, const DevMeta *m)
+   last writer wins: one knot per distinct y, the highest sample number of an equal-y run --, invalid ones behind the valid
+   ones.  The samples are taken at ascending y and what is kept of each lies close to it, so as a rule they arrive in that
+   order already, every y new (`identity`: knot o is sample o) -- found out in one pass; otherwise they are sorted (buckets
+   over the cloud's y range: they only have to be monotone in y) or, if only equal y occur, just counted.  maxN <= cap.
+   Whole workgroup. */
+struct DynFit { int n, tot, identity, pre, q0, q1; };
+__device__ inline DynFit dyn_fit_prepare(int nv, int maxN, const DynFitLds &F, int cap, int *scr17, const DevMeta *m)
 {
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ int s_n, s_flags;
+    if (threadIdx.x == 0) { s_n = 0; s_flags = 0; }
     nv = wave_sum(nv);
     __syncthreads();
     if ((threadIdx.x & 63) == 0 && nv) atomicAdd(&s_n, nv);
-    const float y0 = m->mn[1], y1 = m->mx[1];
-    const int NB = min(next_pow2(max(maxN, 64)), cap);
-    const float scale = (y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
-    auto gen = [&](int i) { return F.stage[i]; };
-    auto bucket = [&](u64 k) {
-        if (k == ~0ull) return NB - 1;
-        const int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
-        return q < 0 ? 0 : (q >= NB ? NB - 1 : q);
-    };
-    auto less = [&](u64 a, u64 b) { return a < b; };
-    block_bucket_sort(F.keys, maxN, F.hist, NB, scr17, gen, bucket, less);
-    return s_n;
-}
-
-/* One knot per distinct y of the n sorted keys: the last writer (highest sample number) of an equal-y run.  Every thread
-   takes a run of consecutive positions [q0, q1); returns the number of knots, *pre = the place of the thread's first one. */
-__device__ inline int dyn_count_knots(const u64 *keys, int n, int *scr17, int *pre, int *q0, int *q1)
-{
+    int flags = 0; /* 1: not the identity, 2: not even sorted */
+    for (int j = threadIdx.x; j < maxN; j += blockDim.x) {
+        const u64 k = F.stage[j];
+        F.keys[j] = k;
+        if (j + 1 < maxN) {
+            const u64 k1 = F.stage[j + 1];
+            if (k1 != ~0ull && (k == ~0ull || YK_Y(k) >= YK_Y(k1))) flags |= 1;
+            if (k > k1) flags |= 2;
+        }
+    }
+    if (flags) atomicOr(&s_flags, flags);
+    __syncthreads();
+    flags = s_flags;
+#ifdef DYN_FIT_FORCE /* test builds: take the counting (1) or the sorting (3) path whatever the samples look like */
+    flags |= DYN_FIT_FORCE;
+#endif
+    DynFit ft;
+    ft.n = s_n; ft.identity = !(flags & 1); ft.pre = ft.q0 = ft.q1 = 0;
+    if (ft.identity) { ft.tot = ft.n; return ft; }
+    if (flags & 2) {
+        const float y0 = m->mn[1], y1 = m->mx[1];
+        const int NB = min(next_pow2(max(maxN, 64)), cap);
+        const float scale = (y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
+        auto gen = [&](int i) { return F.stage[i]; };
+        auto bucket = [&](u64 k) {
+            if (k == ~0ull) return NB - 1;
+            const int q = (int)((ord2f(YK_Y(k)) - y0) * scale);
+            return q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+        };
+        auto less = [&](u64 a, u64 b) { return a < b; };
+        block_bucket_sort(F.keys, maxN, F.hist, NB, scr17, gen, bucket, less);
+    }
+    /* every thread takes a run of consecutive positions [q0, q1); pre = the place of its first knot */
+    const int n = ft.n;
     const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
-    *q0 = min((int)threadIdx.x * per, n); *q1 = min(*q0 + per, n);
+    ft.q0 = min((int)threadIdx.x * per, n); ft.q1 = min(ft.q0 + per, n);
     int c = 0;
-    for (int q = *q0; q < *q1; ++q) c += (q == n - 1) || (YK_Y(keys[q + 1]) != YK_Y(keys[q]));
-    int tot;
-    *pre = block_exscan(c, scr17, &tot);
-    return tot;
+    for (int q = ft.q0; q < ft.q1; ++q) c += (q == n - 1) || (YK_Y(F.keys[q + 1]) != YK_Y(F.keys[q]));
+    ft.pre = block_exscan(c, scr17, &ft.tot);
+    return ft;
 }
+/* emit(o, sample) for knot o = 0 .. tot-1 (no barrier in here) */
 template <typename Emit>
-__device__ inline void dyn_emit_knots(const float4 *pts, const DynFitLds &F, int n, int q0, int q1, int pre, Emit emit)
+__device__ inline void dyn_emit_knots(const float4 *pts, const DynFitLds &F, const DynFit &ft, Emit emit)
 {
-    for (int q = q0; q < q1; ++q)
-        if ((q == n - 1) || (YK_Y(F.keys[q + 1]) != YK_Y(F.keys[q]))) {
+    if (ft.identity) {
+        for (int j = threadIdx.x; j < ft.n; j += blockDim.x) emit(j, F.pay ? F.pay[j] : pts[j]);
+        return;
+    }
+    int o = ft.pre;
+    for (int q = ft.q0; q < ft.q1; ++q)
+        if ((q == ft.n - 1) || (YK_Y(F.keys[q + 1]) != YK_Y(F.keys[q]))) {
             const int j = YK_POS(F.keys[q]);
-            emit(pre++, F.pay ? F.pay[j] : pts[j]);
+            emit(o++, F.pay ? F.pay[j] : pts[j]);
         }
 }
 
@@ -569,11 +594,10 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
         const DynChain cp = dyn_chain(walk, chain, t - 1, centre, S);
         /* v1, "generate boundary fail": the path stays as fitted */
         if (cp.active && !(walk == 3 && bn < 3)) {
-            const int n = dyn_sort_staged(nv, Bf.maxNA, F, capA, s_scr, m);
-            int pre, q0, q1;
-            const int tot = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
+            const DynFit ft = dyn_fit_prepare(nv, Bf.maxNA, F, capA, s_scr, m);
+            const int tot = ft.tot;
             if (tot < 3) { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) set_err(m, DERR_SLICE, cp.s); return; } /* gsl_spline_alloc */
-            dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) { ly[o] = p.x == 0.f ? 0.f : p.x; lx[o] = p.y; lz[o] = p.z; });
+            dyn_emit_knots(pts, F, ft, [&](int o, const float4 &p) { ly[o] = p.x == 0.f ? 0.f : p.x; lx[o] = p.y; lz[o] = p.z; });
             __syncthreads();
             if (blockIdx.x == gridDim.x - 1) { /* the launch's extra workgroup: it commits the knots and has no samples */
                 if (threadIdx.x == 0) {
@@ -656,16 +680,17 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     const double *ky = gy, *kx = gx;
     int nb;
     {
-        const int n = dyn_sort_staged(nv, Bf.maxNB, F, capB, s_scr, m);
-        int pre, q0, q1;
-        const int node_number = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
+        sc.mark(13);
+        const DynFit ft = dyn_fit_prepare(nv, Bf.maxNB, F, capB, s_scr, m);
+        const int node_number = ft.tot;
+        sc.mark(14);
         if (node_number <= 2) { /* compute_boundary returns 0: the previous boundary stays; v1 has none then (Path_Generation.cpp:589-592) */
             if (walk == 3) { nb = 0; if (blockIdx.x == 0 && threadIdx.x == 0) Bf.bnd_n[chain] = 0; }
             else nb = Bf.bnd_n[chain];
             __syncthreads(); /* the scratch becomes the waves' search areas */
         } else {
             const bool keep_copy = blockIdx.x == 0;
-            dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) {
+            dyn_emit_knots(pts, F, ft, [&](int o, const float4 &p) {
                 const double y = (double)(p.y == 0.f ? 0.f : p.y);
                 ly[1 + o] = y; lx[1 + o] = (double)p.x;
                 if (keep_copy) { gy[1 + o] = y; gx[1 + o] = (double)p.x; gz[1 + o] = (double)p.z; }
@@ -703,13 +728,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     /* bisection (:237-265), at most 6 Area2Cloud evaluations, the first of them taken ahead of the chain */
     float ab[3] = {first.x, first.y, first.z};
     bool moved = false;
-#ifdef DYN_COUNT_ITERS
-    int nev = 0;
-#endif
     for (int itr = 0; itr <= 5; ++itr) {
-#ifdef DYN_COUNT_ITERS
-        ++nev;
-#endif
         if (itr > 0) {
             float2 ecs[DYN_ELL_PER];
             dyn_load_ellipse(ell_cs, ecs);
@@ -726,9 +745,6 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
         sc.mark(6);
     }
     sc.mark(7);
-#ifdef DYN_COUNT_ITERS
-    if (lane == 0) atomicAdd(&m->sweeps, 1 + (nev > 1 ? 65536 : 0));
-#endif
     /* kdtree.nearestKSearch(point, 3): only pointIdx[0] is used (:291-294).  B.14: a node that Area2Cloud turned NaN
        ("adjust path node NAN", :258-261) adds no knot (the reference hands the NaN to FLANN and reads whatever
        pointIdx holds afterwards) */
@@ -768,9 +784,8 @@ __global__ void __launch_bounds__(256) k_dyn_adjust_fit(DevMeta *m, int walk, in
     const DynFitLds F = dyn_fit_lds(s_raw, capA);
     const float4 *pts = Bf.adj_pts + (size_t)chain * Bf.maxNA;
     const int nv = dyn_stage_samples(pts, Bf.maxNA, F, [](const float4 &p) { return p.w != 0.f; }, [](const float4 &p) { return p.x; });
-    const int n = dyn_sort_staged(nv, Bf.maxNA, F, capA, s_scr, m);
-    int pre, q0, q1;
-    const int tot = dyn_count_knots(F.keys, n, s_scr, &pre, &q0, &q1);
+    const DynFit ft = dyn_fit_prepare(nv, Bf.maxNA, F, capA, s_scr, m);
+    const int tot = ft.tot;
     if (threadIdx.x == 0) {
         int base = -1;
         if (tot < 3) set_err(m, DERR_SLICE, c.s); /* gsl_spline_alloc */
@@ -783,6 +798,6 @@ __global__ void __launch_bounds__(256) k_dyn_adjust_fit(DevMeta *m, int walk, in
     __syncthreads();
     const int base = s_base;
     if (base < 0) return;
-    dyn_emit_knots(pts, F, n, q0, q1, pre, [&](int o, const float4 &p) { node_y[base + o] = p.x == 0.f ? 0.f : p.x; node_x[base + o] = p.y; node_z[base + o] = p.z; });
+    dyn_emit_knots(pts, F, ft, [&](int o, const float4 &p) { node_y[base + o] = p.x == 0.f ? 0.f : p.x; node_x[base + o] = p.y; node_z[base + o] = p.z; });
     if (threadIdx.x == 0) { node_start[c.s] = base; node_cnt[c.s] = tot; }
 }

@@ -2343,11 +2343,7 @@ __device__ __forceinline__ void smooth_solve_body(DevMeta *m, const DevParams &P
             if (copy2) for (size_t i = threadIdx.x; i < 6 * (size_t)W; i += blockDim.x) dst2[i] = wp_out[i];
         }
     }
-#ifdef DYN_COUNT_ITERS
-    if (tile == 0 && threadIdx.x == 0) m->smooth_done = 0;
-#else
     if (tile == 0 && threadIdx.x == 0) { m->sweeps = 0; m->smooth_done = 0; }
-#endif
 }
 
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer check: the fits of the dynamic adjustment take one of three paths (samples already in knot order; equal y to
+merge; unsorted).  Test builds that force the second and the third path on every fit must give the knots and the list of
+the product build, bit for bit.
+  make -C polishpathplanning_amd/csrc variant NAME=fitcount DEFS=-DDYN_FIT_FORCE=1
+  make -C polishpathplanning_amd/csrc variant NAME=fitsort DEFS=-DDYN_FIT_FORCE=3
+usage: python tools/dyn_variants_check.py"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polishpathplanning_amd import engine, synth  # noqa: E402
+
+base = os.path.dirname(engine.LIB_PATH)
+cases = []
+for name in ("cfg1_50k_s32", "cfg3_250k_s128"):
+    pts, cfg = synth.make_config(name)
+    for walk in (1, 2, 3):
+        cases.append((name, pts, dict(tool_radius=cfg["tool_radius"], walk=walk, pairing=1 if walk == 3 else 0)))
+rng = np.random.default_rng(5)
+for i in range(6):
+    pts = synth.make_plate(int(rng.integers(150, 500)), int(rng.integers(60, 200)), kind=["dome", "wavy", "blade"][i % 3], seed=100 + i)
+    cases.append(("plate%d" % i, pts, dict(tool_radius=float(rng.choice([4.0, 6.0, 9.0])), walk=int(rng.choice([1, 2])))))
+ref = None
+bad = 0
+for libname in ("libppp_hip.so", "libppp_hip_fitcount.so", "libppp_hip_fitsort.so"):
+    engine.LIB_PATH = os.path.join(base, libname)
+    engine._lib = None
+    sums = []
+    for name, pts, kw in cases:
+        e = engine.Engine(0, dynamic_adjustment=1, **kw)
+        e.set_cloud(pts)
+        try:
+            e.gen_path(); e.get_path()
+            nodes = b"".join(e.nodes(s)[0].tobytes() + e.nodes(s)[1].tobytes() + e.nodes(s)[2].tobytes() for s in range(e.num_slices()))
+            sums.append(hashlib.md5(nodes + e.waypoints().tobytes()).hexdigest()[:10])
+        except engine.PPPError as ex:
+            sums.append("error %d slice %d" % (ex.code, e.failed_slice()))
+        e.close()
+    print(libname, " ".join(sums))
+    if ref is None:
+        ref = sums
+    elif sums != ref:
+        bad += 1
+print("FAILED" if bad else "ok: the three paths agree on %d cases" % len(cases))
+sys.exit(1 if bad else 0)

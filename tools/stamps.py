@@ -25,7 +25,8 @@ if dynamic:
     labels[3] = ("k_dyn_boundary_pts", ["prologue+dy", "spline", "knn search", "knn rank", "eigen", "extremum", "store", "-", "-",
                                          "normals gather", "rank-order sums", "axes", "ellipse points"])
     labels[4] = ("k_dyn_adjust_pts", ["prologue", "spline", "knn search (all)", "knn rank (all)", "eigen", "extremum",
-                                      "boundary eval", "-", "snap store", "normals gather", "rank-order sums", "axes", "ellipse points"])
+                                      "boundary eval", "-", "snap store", "normals gather", "rank-order sums", "axes", "ellipse points",
+                                      "first reads", "fit"])
 for kid, (kn, ls) in labels.items():
     vals = [out[16 * kid + i] / N for i in range(len(ls))]
     tot = sum(vals) or 1
