@@ -364,7 +364,7 @@ int enqueue_normals(ppp_handle h)
     HIPCHK(h, hipMemsetAsync(h->normals4.p, 0xff, std::max<size_t>(n, 1) * 16, h->stream)); /* dropped points: NaN */
     if (n)
         LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((n + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
-               h->slab_xmin.p, h->slab_xmax.p, -1, h->normals4.p);
+               h->slab_xmin.p, h->slab_xmax.p, h->slab_ytab.p, -1, h->normals4.p);
     return PPP_OK;
 }
 
@@ -2170,7 +2170,7 @@ int ppp_estimate_normals(ppp_handle h, float *out4)
     const int nsorted = h->hmeta.n_sorted;
     if (nsorted > 0)
         LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((nsorted + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
-               h->slab_xmin.p, h->slab_xmax.p, nsorted, (float4 *)h->scratch.p);
+               h->slab_xmin.p, h->slab_xmax.p, h->slab_ytab.p, nsorted, (float4 *)h->scratch.p);
     HIPCHK(h, hipMemcpyAsync(out4, h->scratch.p, n * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return PPP_OK;
