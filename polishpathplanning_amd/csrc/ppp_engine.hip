@@ -487,9 +487,8 @@ int make_plan(ppp_handle h)
         while (pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs) > (size_t)h->max_lds - 8192 && h->knot_cap > 256) h->knot_cap >>= 1;
         while (pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs) > (size_t)h->max_lds - 8192 && h->stage_cap > 512) h->stage_cap -= 128;
         h->cnt_est = (int)std::min(1.0e6, per);
-        int t = 256;
-        while (t < POSE_T && t < h->cnt_est * pose_lanes(h->cnt_est)) t <<= 1;
-        h->pose_threads = t;
+        /* whole waves for every waypoint's lanes; the kernel is instantiated per 256 threads of budget */
+        h->pose_threads = std::min(POSE_T, std::max(256, 64 * ((h->cnt_est * pose_lanes(h->cnt_est) + 63) / 64)));
     }
     double wc = per * (double)h->S_cap;
     if (wc > 2.0e8) return fail(h, PPP_ERR_CAPACITY, "waypoint bound too large");
@@ -861,9 +860,11 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
     (void)hipFuncSetAttribute((const void *)k_pose_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose_b<768>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose_b<POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
+    (void)hipFuncSetAttribute((const void *)k_pose<false, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<false, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_pose<true, POSE_T>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
     (void)hipFuncSetAttribute((const void *)k_dyn_boundary_pts, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -1422,6 +1423,7 @@ int ppp_get_path_async(ppp_handle h)
            h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p, h->wp_pre.p, PB, h->slab_ytab.p, cnt_in
         if (h->pose_threads <= 256) LAUNCH(h, "k_pose", (k_pose<false, 256>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
         else if (h->pose_threads <= 512) LAUNCH(h, "k_pose", (k_pose<false, 512>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
+        else if (h->pose_threads <= 768) LAUNCH(h, "k_pose", (k_pose<false, 768>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
         else LAUNCH(h, "k_pose", (k_pose<false, POSE_T>), nk, h->pose_threads, pose_lds_bytes(h->knot_cap, h->stage_cap, h->tab_slabs), PPP_POSE_ARGS);
 #undef PPP_POSE_ARGS
     }
@@ -1606,6 +1608,7 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
     LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), bg->members.p);
     if (bg->pose_threads <= 256) LAUNCHB(lead, "k_pose_b", k_pose_b<256>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
     else if (bg->pose_threads <= 512) LAUNCHB(lead, "k_pose_b", k_pose_b<512>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
+    else if (bg->pose_threads <= 768) LAUNCHB(lead, "k_pose_b", k_pose_b<768>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
     else LAUNCHB(lead, "k_pose_b", k_pose_b<POSE_T>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
     LAUNCHB(lead, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, bg->members.p);
     if (count == 1) { /* nothing to collect: the one meta block goes straight to the host */

@@ -1846,7 +1846,10 @@ __host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap, in
 }
 /* lanes per waypoint (the two searches walk G slabs side by side): a function of the slice's waypoint count ONLY, so the
    partial sums of the normals -- and with them the last bits of the list -- do not depend on the launch geometry */
-__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= 256 ? 2 : 1); }
+#ifndef POSE_G2_MAX
+#define POSE_G2_MAX 384 /* 2 lanes x 384 waypoints = 768 threads, the largest form that keeps its registers (cfg 5, 258 waypoints per slice: 145 -> 135 us) */
+#endif
+__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= POSE_G2_MAX ? 2 : 1); }
 
 #ifndef POSE_T
 #define POSE_T 1024
@@ -2606,7 +2609,7 @@ __global__ void __launch_bounds__(TMAX) k_pose(DevMeta *m, DevParams P, const fl
                                               int tab_slabs, float pad, float4 *wp_xyz, int *wp_nn, float4 *wp_normal, float *wp_pre, PoseBack back, const int *ytab,
                                               const int *slice_wpcnt)
 {
-    pose_body<ALIGNED, (TMAX <= 512 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
+    pose_body<ALIGNED, (TMAX <= 768 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
                        tail, W_cap, arena_ran, knot_cap, stage_cap, tab_slabs, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, slice_wpcnt, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
@@ -2663,7 +2666,7 @@ __global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__
     if ((int)blockIdx.x >= M.g_pose) return;
     PoseBack none;
     none.sorted4 = nullptr; none.slab_start = nullptr; none.slab_xmin = nullptr; none.slab_xmax = nullptr; none.m = nullptr; none.ytab = nullptr;
-    pose_body<false, (TMAX <= 512 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
+    pose_body<false, (TMAX <= 768 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
                      M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.tab_slabs, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, M.slice_wpcnt, blockIdx.x);
 }
 __global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
