@@ -64,9 +64,12 @@ def main():
     ap.add_argument("--rotate", type=int, default=None,
                     help="also report the step time over K distinct resident clouds planned round-robin (K x working set beyond "
                          "the 256 MiB Infinity Cache) and the cold time of a never-seen cloud; 0 = off, the default run uses 8")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="plan with Dynamic_adjustment = true (the reference's config.txt default; SURVEY.md 8f rank 1): the same "
+                         "workload through the slice-to-slice chains -- a measurement beside the headline, not the headline")
     args = ap.parse_args()
     if args.rotate is None:
-        args.rotate = 8 if (args.gpus == 1 and args.batch == 1) else 0
+        args.rotate = 8 if (args.gpus == 1 and args.batch == 1 and not args.dynamic) else 0
     if args.config is None:
         args.config = "cfg5_10m_s1024" if (args.mode == "slices" and args.gpus > 1) else ("cfg4_2m_s256" if args.gpus > 1 else "cfg2_1m_s256")
 
@@ -117,7 +120,7 @@ def main():
         if args.batch > 1:   # every workpiece of a batch has its own seed and surface amplitude
             over["amp"] = float(synth.CONFIGS[args.config]["amp"] * amp_rng.uniform(0.5, 1.5))
         pts, cfg = synth.make_config(args.config, seed=base_seed + 1000 * rank + 17 * bi, **over)
-        e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+        e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], dynamic_adjustment=1 if args.dynamic else 0)
         e.set_cloud(pts)
         engines.append(e)
         clouds.append(pts)
@@ -224,7 +227,7 @@ def main():
         # 12 B per point read once + 24 B per waypoint written once; one launch processes the whole batch
         alg_bytes = 12.0 * float(sum(int(c.shape[0]) for c in clouds)) + 24.0 * float(sum(w_all))
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
-        workload_key = args.config + ("_b%d" % args.batch if args.batch > 1 else "")
+        workload_key = args.config + ("_b%d" % args.batch if args.batch > 1 else "") + ("_dyn" if args.dynamic else "")
         traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), workload_key)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
@@ -248,7 +251,7 @@ def main():
         err = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ppo
-            o = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1)
+            o = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1, dynamic_adjustment=1 if args.dynamic else 0)
             t1 = time.perf_counter()
             o.gen_path()
             wo = o.get_path()
@@ -273,7 +276,7 @@ def main():
                 nt = os.cpu_count() or 1
             nt = min(nt, 16)   # the CPU share of one GPU on the bench node
             if nt > 1:
-                o2 = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1, threads=nt)
+                o2 = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], reference_complexity=1, threads=nt, dynamic_adjustment=1 if args.dynamic else 0)
                 t2 = time.perf_counter()
                 o2.gen_path()
                 wo2 = o2.get_path()
@@ -296,7 +299,8 @@ def main():
             "config": {"workload": args.config, "points_per_workpiece": n_points, "slices": S,
                        "waypoints_per_workpiece": int(w_all[0]), "workpieces": world * args.batch, "batch_per_gpu": args.batch,
                        "parallelism": "one workpiece per GPU, RCCL gather of robot_path to rank 0" if world > 1 else "single GPU",
-                       "pairing": "kd", "walk": "center_int (connect)", "tool_radius_mm": cfg["tool_radius"]},
+                       "pairing": "kd", "walk": "center_int (connect)", "tool_radius_mm": cfg["tool_radius"],
+                       "dynamic_adjustment": bool(args.dynamic)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "path_l2_err": err,
