@@ -28,7 +28,9 @@ struct DynParams {
 
 struct __attribute__((aligned(16))) DynWaveLds {
     u64 key[DYN_KNN_CAP];  /* (bits of the squared distance) << 32 | cloud index: one compare ranks a candidate */
+    u32 dk[DYN_KNN_CAP + 16]; /* the distance bits alone (d >= 0: they order like the value): what the ranking reads, four per access */
     int pos[DYN_KNN_CAP];
+    int cnt[64];           /* candidates per rank: more than one = equal distances, ranked again on the whole key */
     int sel[64];
     int sel_id[64]; /* cloud index of neighbour r (the low half of its key) */
     int off[65];  /* exclusive prefix of the y-window sizes of 64 neighbouring slabs */
@@ -115,7 +117,7 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
                     const u64 mask = __ballot(in);
                     if (in) {
                         const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.pos[slot] = i4[u]; }
+                        if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.dk[slot] = __float_as_uint(d); L.pos[slot] = i4[u]; }
                     }
                     count += __popcll(mask);
                     if (count > DYN_KNN_CAP) { overflow = true; break; }
@@ -130,22 +132,48 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
     __threadfence_block();
     sc.mark(2);
     const int kk = count < k ? count : k;
-    /* rank by counting: (distance, cloud index) is a total order; d >= 0, so its bit pattern orders like the value.
-       The keys are read two per LDS access (every lane the same address: a broadcast), padded to a multiple of 8 */
+    /* rank by counting: (distance, cloud index) is a total order.  Distances are almost always all different, so a candidate's
+       rank is the number of smaller DISTANCES -- 32-bit compares on values read four per LDS access (every lane the same
+       address: a broadcast), two candidates per lane in one sweep; candidates that land on the same rank (equal distances)
+       are ranked again on the whole key.  Only ranks below k matter. */
     const int cpad = (count + 7) & ~7;
-    for (int c = count + lane; c < cpad; c += 64) L.key[c] = ~0ull;
+    for (int c = count + lane; c < cpad; c += 64) L.dk[c] = 0xffffffffu;
+    L.cnt[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    for (int c = lane; c < count; c += 64) {
-        const u64 kc = L.key[c];
-        int rank = 0;
-        const ulonglong2 *kv = (const ulonglong2 *)L.key;
-        for (int o = 0; o < cpad / 2; o += 4) {
-            const ulonglong2 a0 = kv[o], a1 = kv[o + 1], a2 = kv[o + 2], a3 = kv[o + 3];
-            rank += (a0.x < kc) + (a0.y < kc) + (a1.x < kc) + (a1.y < kc) + (a2.x < kc) + (a2.y < kc) + (a3.x < kc) + (a3.y < kc);
+    int rr[(DYN_KNN_CAP + 127) / 128][2];
+#pragma unroll
+    for (int sw = 0; sw < (DYN_KNN_CAP + 127) / 128; ++sw) {
+        rr[sw][0] = rr[sw][1] = 0x7fffffff;
+        if (sw * 128 >= count) continue; /* (wave-uniform) */
+        const int c0 = sw * 128 + lane, c1 = c0 + 64;
+        const u32 d0 = c0 < count ? L.dk[c0] : 0u, d1 = c1 < count ? L.dk[c1] : 0u;
+        int r0 = 0, r1 = 0;
+        const uint4 *dv = (const uint4 *)L.dk;
+        for (int o = 0; o < cpad / 4; o += 2) {
+            const uint4 a = dv[o], b = dv[o + 1];
+            r0 += (a.x < d0) + (a.y < d0) + (a.z < d0) + (a.w < d0) + (b.x < d0) + (b.y < d0) + (b.z < d0) + (b.w < d0);
+            r1 += (a.x < d1) + (a.y < d1) + (a.z < d1) + (a.w < d1) + (b.x < d1) + (b.y < d1) + (b.z < d1) + (b.w < d1);
         }
-        if (rank < kk) { L.sel[rank] = L.pos[c]; L.sel_id[rank] = (int)(u32)kc; }
+        if (c0 < count && r0 < kk) { rr[sw][0] = r0; atomicAdd(&L.cnt[r0], 1); }
+        if (c1 < count && r1 < kk) { rr[sw][1] = r1; atomicAdd(&L.cnt[r1], 1); }
     }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+#pragma unroll
+    for (int sw = 0; sw < (DYN_KNN_CAP + 127) / 128; ++sw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int rank = rr[sw][h];
+            if (rank == 0x7fffffff) continue;
+            const int c = sw * 128 + 64 * h + lane;
+            const u64 kc = L.key[c];
+            if (L.cnt[rank] > 1) { /* equal distances: the whole key decides */
+                rank = 0;
+                for (int j = 0; j < count; ++j) rank += L.key[j] < kc;
+            }
+            if (rank < kk) { L.sel[rank] = L.pos[c]; L.sel_id[rank] = (int)(u32)kc; }
+        }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     sc.mark(3);
@@ -296,17 +324,25 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
     /* the reference folds in ascending angle: a NaN at angle 0 poisons the whole fold */
     sc.mark(12);
     if (__ballot(first_nan)) return;
+    /* the wave's extremum: one 64-bit key per lane -- x in an order-preserving integer form (complemented for the minimum; a
+       zero of either sign is one value), then the earlier angle first -- maximised over the lanes; the lane that held it
+       hands over the point */
+    u64 ek = 0;
+    if (have) {
+        const u32 ox = f2ord(bx == 0.f ? 0.f : bx);
+        ek = ((u64)(key == 1 ? ox : ~ox) << 32) | (u32)(0x7fffffff - ba);
+    }
     for (int o = 32; o > 0; o >>= 1) {
-        const float ox = __shfl_xor(bx, o, 64), oy = __shfl_xor(by, o, 64), oz = __shfl_xor(bz, o, 64);
-        const int oa = __shfl_xor(ba, o, 64);
-        const bool ohave = __shfl_xor(have ? 1 : 0, o, 64) != 0;
-        bool take = false;
-        if (ohave) {
-            if (!have) take = true;
-            else if (key == 1 ? (ox > bx) : (ox < bx)) take = true;
-            else if (ox == bx && oa < ba) take = true;
-        }
-        if (take) { bx = ox; by = oy; bz = oz; ba = oa; have = true; }
+        const u32 hi = __shfl_xor((u32)(ek >> 32), o, 64), lo = __shfl_xor((u32)ek, o, 64);
+        const u64 other = ((u64)hi << 32) | lo;
+        ek = other > ek ? other : ek;
+    }
+    have = ek != 0;
+    if (have) {
+        const int wl = __builtin_amdgcn_readfirstlane((0x7fffffff - (int)(u32)ek) & 63); /* angle a sits in lane a mod 64 */
+        bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl));
+        by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl));
+        bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
     }
     if (have) { bound[0] = bx; bound[1] = by; bound[2] = bz; }
     sc.mark(5);

@@ -665,6 +665,26 @@ def test_area2cloud_api(engine_mod, oracle_mod):
         assert np.array_equal(got[~nan], want[~nan])
 
 
+def test_area2cloud_with_equal_distances(engine_mod, oracle_mod):
+    """Every fifth point of the cloud exists twice (same coordinates, two cloud indices): the k-NN selection meets equal
+    distances in nearly every neighbourhood and must break them by cloud index, as the oracle's (distance, index) order
+    does -- the ranking's second path (whole 64-bit key) next to its first (distance bits only)."""
+    base = synth.make_plate(150, 80, kind="blade", amp=25.0, seed=19)
+    rng = np.random.default_rng(3)
+    dup = base[rng.permutation(len(base))[: len(base) // 5]]
+    pts = np.concatenate([base, dup])[rng.permutation(len(base) + len(dup))].astype(np.float32)
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=6.0)
+    cloud = o.points().astype(np.float64)
+    q = cloud[rng.integers(0, len(cloud), 300)] + rng.normal(0, 0.3, (300, 3))
+    for key in (0, 1):
+        got = e.area2cloud(q, key)
+        want = np.stack([o.area2cloud(p, key) for p in q])
+        nan = np.isnan(want[:, 0])
+        assert np.array_equal(np.isnan(got[:, 0]), nan)
+        assert np.array_equal(got[~nan], want[~nan])
+    assert (~nan).sum() > 100
+
+
 @pytest.mark.parametrize("walk", [1, 2, 3])
 def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
     """GenPath with Dynamic_adjustment = true (config.txt:13) for connect (walk 1), connect1 (walk 2) and
