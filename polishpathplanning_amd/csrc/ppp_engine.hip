@@ -339,6 +339,8 @@ int ensure_dynamic_buffers(ppp_handle h)
     HIPCHK(h, h->dyn_bnd_pts.ensure(2 * (size_t)h->dyn_maxNB)); HIPCHK(h, h->dyn_adj_pts.ensure(2 * (size_t)h->dyn_maxNA));
     HIPCHK(h, h->dyn_bnd_knots.ensure(2 * 3 * ((size_t)h->dyn_maxNB + 2))); HIPCHK(h, h->dyn_bnd_n.ensure(2));
     const size_t nfirst = (size_t)std::max(h->S_cap, 1) * h->dyn_maxNA;
+    if (nfirst > ((size_t)1 << 27)) /* 56 bytes a node: 7.5 GB */
+        return fail(h, PPP_ERR_CAPACITY, "dynamic adjustment: slices x nodes per slice beyond 2^27");
     HIPCHK(h, h->dyn_first_ab.ensure(nfirst)); HIPCHK(h, h->dyn_first_node.ensure(3 * nfirst)); HIPCHK(h, h->dyn_first_snap.ensure(nfirst));
     if (!h->ell_cs.p) {
         /* cos / sin of the 721 ellipse angles, computed as the reference does (float angle, pcl::deg2rad,
