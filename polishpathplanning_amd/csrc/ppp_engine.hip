@@ -23,6 +23,9 @@
 #ifndef PPP_PPT8_FROM
 #define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
 #endif
+#ifndef PPP_PPT16_FROM
+#define PPP_PPT16_FROM 1500000 /* ... and 16: a workgroup's run in a slab grows to ~7 points = most of a 128-byte line (2 M points: scatter 36.4 -> 32.4 us) */
+#endif
 #ifndef PPP_MM_GRID_MAX
 #define PPP_MM_GRID_MAX 192 /* workgroups of the bounds + histogram pass: every one flushes its LDS histogram with an atomic per non-empty slab, which is what grows with the grid (1 M points: 192 is 1.5 us ahead of 256; 128 .. 160 the same) */
 #endif
@@ -565,7 +568,8 @@ int enqueue_index(ppp_handle h)
     /* points per scatter workgroup: every workgroup reserves its share of each slab with one global atomic per
        non-empty (workgroup, slab) pair, so larger clouds use 8 instead of 4 points per thread */
     const bool ppt8 = n > PPP_PPT8_FROM;
-    const int chunk = (ppt8 ? 8 : 4) * SCAT_T;
+    const bool ppt16 = n > PPP_PPT16_FROM && !h->two_pass_scatter;
+    const int chunk = (ppt16 ? 16 : (ppt8 ? 8 : 4)) * SCAT_T;
     const int gs = std::max(1, (n + chunk - 1) / chunk);
     if (h->two_pass_scatter)
         LAUNCH(h, "k_setup", k_setup, 1, SETUP_T, 0, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->B,
@@ -574,7 +578,10 @@ int enqueue_index(ppp_handle h)
         /* one level: the set-up rides in the scatter's launch as its last workgroup (k_scatter_setup) */
         ScatGrid G;
         G.x0 = slab_x0; G.invw = slab_invw; G.xlo = h->incl_lo; G.xhi = h->incl_hi; G.B = h->B;
-        if (ppt8)
+        if (ppt16)
+            LAUNCH(h, "k_scatter_setup", k_scatter_setup<16>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
+                   h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
+        else if (ppt8)
             LAUNCH(h, "k_scatter_setup", k_scatter_setup<8>, gs + 1, SCAT_T, 2 * hist_lds, sX, sY, sZ, n, G, h->slab_cnt.p, h->slab_cursor.p,
                    h->unsorted4.p, idmap, gs, h->meta.p, D, h->mm_part.p, h->mm_grid_used, h->px.p, h->lo.p, h->hi.p, h->S_cap, h->slab_start.p);
         else
@@ -859,6 +866,7 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_slab_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_scatter_setup<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_scatter_setup<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+    (void)hipFuncSetAttribute((const void *)k_scatter_setup<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
     (void)hipFuncSetAttribute((const void *)k_slice_kd_b, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     (void)hipFuncSetAttribute((const void *)k_pose_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192); /* (8 KiB: the kernel's static LDS, the y-bucket rows) */
     (void)hipFuncSetAttribute((const void *)k_pose_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 8192);
