@@ -180,20 +180,16 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
     return kk;
 }
 
-/* a lane's ellipse angles (cos, sin): requested by the caller as early as it can, used at the very end of Area2Cloud */
-__device__ inline void dyn_load_ellipse(const float *__restrict__ ell_cs, float2 (&ecs)[DYN_ELL_PER])
+/* the 721 ellipse angles (cos, sin) as a table in LDS: the whole workgroup stages it when the kernel starts (a barrier follows
+   before the first use) */
+__device__ inline void dyn_stage_ellipse(const float *__restrict__ ell_cs, float2 *s_ell)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < DYN_ELL_PER; ++q) {
-        const int a = lane + 64 * q;
-        ecs[q] = a < DYN_ELL ? ((const float2 *)ell_cs)[a] : make_float2(0.f, 0.f);
-    }
+    for (int a = threadIdx.x; a < DYN_ELL; a += blockDim.x) s_ell[a] = ((const float2 *)ell_cs)[a];
 }
 
 /* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative. */
 __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
-                                       const float2 (&ecs)[DYN_ELL_PER], const DynParams &D, const double point[3], int key,
+                                       const float2 *ell, const DynParams &D, const double point[3], int key,
                                        float bound[3], StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
@@ -304,26 +300,66 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
         if (shortAxis > toolthickness) shortAxis = toolthickness;
     }
     sc.mark(11);
-    /* 721-point ellipse, transformed (SSE order c0*x + (c1*y + (c2*0 + c3))), first extremum in x */
+    /* 721-point ellipse, transformed (SSE order c0*x + (c1*y + (c2*0 + c3))), first extremum in x.  Returns 1 with the point,
+       0 when no sample is a number, 2 when the fold is poisoned (below) */
+    auto ellipse_extremum = [&](const bool allow_window, float res[3]) -> int {
     float bx = 0.f, by = 0.f, bz = 0.f;
     int ba = 0x7fffffff;
     bool have = false, first_nan = false;
-#pragma unroll
-    for (int q = 0; q < DYN_ELL_PER; ++q) {
-        const int a = lane + 64 * q;
-        if (a >= DYN_ELL) break;
-        const float ex = (float)(longAxis * (double)ecs[q].x);
-        const float ey = (float)(shortAxis * (double)ecs[q].y);
+    auto sample = [&](int a) {
+        const float2 csn = ell[a];
+        const float ex = (float)(longAxis * (double)csn.x);
+        const float ey = (float)(shortAxis * (double)csn.y);
         float t[3];
         for (int i = 0; i < 3; ++i) t[i] = cr[i] * ex + (cv[i] * ey + (n0[i] * 0.f + sp[i]));
         if (a == 0 && !(t[0] == t[0])) first_nan = true;
         if (t[0] == t[0]) {
             if (!have || (key == 1 ? (bx < t[0]) : (t[0] < bx))) { bx = t[0]; by = t[1]; bz = t[2]; ba = a; have = true; }
         }
+    };
+    /* Where the extremum can be is known beforehand: x(theta) = A cos theta + B sin theta + C peaks at atan2(B, A) (the minimum
+       half a turn further), and a sample k half-degree steps away from the peak lies 0.49 R (k delta)^2 below it (R = |(A, B)|)
+       while the float evaluation of a sample is off by at most E = 4 ulp(|C| + R) + 8 R 2^-23.  Samples further away than
+       K = sqrt((2 E / (R delta^2) + 1/8) / 0.49) steps cannot hold the extremum, nor tie with it; when K < 27 the 63 samples
+       around the peak (and the 360-degree sample when the 0-degree one is among them) are all that is evaluated, one per
+       lane instead of twelve -- the same values compared in the same order, so the same sample wins. */
+    bool windowed = false;
+    int a_star = 0;
+#ifndef DYN_ELL_FULL
+    if (allow_window) { /* (float arithmetic is plenty for locating the window; its width carries the slack) */
+        const float A = cr[0] * (float)longAxis, Bq = cv[0] * (float)shortAxis;
+        const float R = sqrtf(A * A + Bq * Bq), Cm = fabsf(sp[0]) + R;
+        if (R > 0.f && R < 1e30f && Cm < 1e30f && cr[1] == cr[1] && cr[2] == cr[2] && cv[1] == cv[1] && cv[2] == cv[2]) {
+            const float ulp = __uint_as_float(__float_as_uint(Cm) & 0x7f800000u) * 1.1920929e-7f; /* of a float of Cm's size */
+            const float E = 4.f * ulp + 8.f * R * 1.1920929e-7f;
+            const float dl = 0.008726646f; /* half a degree */
+            const float K2 = (2.f * E / (R * dl * dl) + 0.125f) / 0.49f;
+            if (K2 < 27.f * 27.f) {
+                float th = atan2f(Bq, A);
+                if (key != 1) th += 3.14159265f;
+                if (th < 0.f) th += 6.2831853f;
+                a_star = (int)floorf(th / dl + 0.5f) % 720;
+                windowed = true;
+            }
+        }
+    }
+#endif
+    if (windowed) {
+        int a = (a_star + lane - 31 + 720) % 720;
+        const bool zero_in = __ballot(lane < 63 && a == 0) != 0;
+        if (lane == 63) a = 720;
+        if (lane < 63 || zero_in) sample(a);
+    } else {
+#pragma unroll
+        for (int q = 0; q < DYN_ELL_PER; ++q) {
+            const int a = lane + 64 * q;
+            if (a >= DYN_ELL) break;
+            sample(a);
+        }
     }
     /* the reference folds in ascending angle: a NaN at angle 0 poisons the whole fold */
     sc.mark(12);
-    if (__ballot(first_nan)) return;
+    if (__ballot(first_nan)) return 2;
     /* the wave's extremum: one 64-bit key per lane -- x in an order-preserving integer form (complemented for the minimum; a
        zero of either sign is one value), then the earlier angle first -- maximised over the lanes; the lane that held it
        hands over the point */
@@ -339,12 +375,27 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
     }
     have = ek != 0;
     if (have) {
-        const int wl = __builtin_amdgcn_readfirstlane((0x7fffffff - (int)(u32)ek) & 63); /* angle a sits in lane a mod 64 */
+        const int wa = 0x7fffffff - (int)(u32)ek; /* the winning angle: in lane a mod 64, or at its place in the window */
+        const int wl = __builtin_amdgcn_readfirstlane(windowed ? (wa == 720 ? 63 : (wa - a_star + 31 + 720) % 720) : (wa & 63));
         bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl));
         by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl));
         bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
     }
-    if (have) { bound[0] = bx; bound[1] = by; bound[2] = bz; }
+    if (have) { res[0] = bx; res[1] = by; res[2] = bz; }
+    return have ? 1 : 0;
+    };
+    float res[3];
+    const int st = ellipse_extremum(true, res);
+#ifdef DYN_ELL_CHECK /* test build: the windowed evaluation against all 721 samples, every time */
+    {
+        float ref[3];
+        const int st2 = ellipse_extremum(false, ref);
+        if (st != st2 || (st == 1 && (__float_as_uint(res[0]) != __float_as_uint(ref[0]) || __float_as_uint(res[1]) != __float_as_uint(ref[1]) ||
+                                      __float_as_uint(res[2]) != __float_as_uint(ref[2]))))
+            set_err(const_cast<DevMeta *>(V.m), DERR_DOMAIN, -1);
+    }
+#endif
+    if (st == 1) { bound[0] = res[0]; bound[1] = res[1]; bound[2] = res[2]; }
     sc.mark(5);
 }
 
@@ -358,6 +409,9 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_area2cloud_api(DevMeta *m, D
                                                                    const double *__restrict__ pts, int k, int key, float *out)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
+    __shared__ float2 s_ell[DYN_ELL];
+    dyn_stage_ellipse(ell_cs, s_ell);
+    __syncthreads();
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * DYN_WAVES + wv;
     if (q >= k) return;
@@ -365,9 +419,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_area2cloud_api(DevMeta *m, D
     double p[3] = {pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]};
     float b[3];
     StampCtx sc; sc.begin(15, false);
-    float2 ecs[DYN_ELL_PER];
-    dyn_load_ellipse(ell_cs, ecs);
-    wave_area2cloud(V, s_w[wv], normals4, ecs, D, p, key, b, sc);
+    wave_area2cloud(V, s_w[wv], normals4, s_ell, D, p, key, b, sc);
     if ((threadIdx.x & 63) == 0) { out[3 * q] = b[0]; out[3 * q + 1] = b[1]; out[3 * q + 2] = b[2]; }
 }
 
@@ -558,7 +610,10 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, D
         const int *__restrict__ node_start, const int *__restrict__ node_cnt, DynBuffers Bf)
 {
     __shared__ DynWaveLds s_w[DYN_WAVES];
+    __shared__ float2 s_ell[DYN_ELL];
     StampCtx sc; sc.begin(6, blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0);
+    dyn_stage_ellipse(ell_cs, s_ell);
+    __syncthreads();
     if (m->err) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.y, i = blockIdx.x * DYN_WAVES + wv;
@@ -582,9 +637,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, D
     spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float ab[3];
-    float2 ecs[DYN_ELL_PER];
-    dyn_load_ellipse(ell_cs, ecs);
-    wave_area2cloud(V, s_w[wv], normals4, ecs, D, node, key == 0 ? 1 : 0, ab, sc);
+    wave_area2cloud(V, s_w[wv], normals4, s_ell, D, node, key == 0 ? 1 : 0, ab, sc);
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
     const int got = finite ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
@@ -610,6 +663,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
     __shared__ int s_base;
+    __shared__ float2 s_ell[DYN_ELL];
     StampCtx sc; sc.begin(3, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chain = blockIdx.y;
@@ -620,9 +674,10 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     /* first reads, all at once: the samples of the step before, the ellipse table, the state of the pass */
     const int nv = t > 0 ? dyn_stage_samples(pts, Bf.maxNA, F, [](const float4 &p) { return p.w != 0.f; }, [](const float4 &p) { return p.x; }) : 0;
     const int bn = (t > 0 && walk == 3) ? Bf.bnd_n[chain] : 3;
-    float2 ecs[DYN_ELL_PER];
-    dyn_load_ellipse(ell_cs, ecs);
-    if (m->err) return;
+    dyn_stage_ellipse(ell_cs, s_ell);
+    const int err = m->err;
+    __syncthreads();
+    if (err) return;
     const int S = m->S;
     const float *ky = nullptr, *kx = nullptr, *kz = nullptr; /* knots of the previous path */
     int mm = 0;
@@ -676,7 +731,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     sc.mark(1);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float b[3];
-    wave_area2cloud(V, ((DynWaveLds *)s_raw)[wv], normals4, ecs, D, point, c.key, b, sc);
+    wave_area2cloud(V, ((DynWaveLds *)s_raw)[wv], normals4, s_ell, D, point, c.key, b, sc);
     if (lane == 0) *dst = make_float4(b[0], b[1], b[2], 1.f);
     sc.mark(6);
 }
@@ -693,6 +748,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
     __shared__ int s_scr[17];
+    __shared__ float2 s_ell[DYN_ELL];
     StampCtx sc; sc.begin(4, blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chain = blockIdx.y;
@@ -708,6 +764,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     const size_t at = (cg.s >= 0 && cg.s < S_cap && i < Bf.maxNA) ? (size_t)cg.s * Bf.maxNA + i : 0;
     const float4 first = Bf.first_ab[at];
     double node[3] = {Bf.first_node[3 * at], Bf.first_node[3 * at + 1], Bf.first_node[3 * at + 2]};
+    dyn_stage_ellipse(ell_cs, s_ell); /* (the barriers of the fit come before any use) */
     if (m->err) return;
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
@@ -765,11 +822,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     float ab[3] = {first.x, first.y, first.z};
     bool moved = false;
     for (int itr = 0; itr <= 5; ++itr) {
-        if (itr > 0) {
-            float2 ecs[DYN_ELL_PER];
-            dyn_load_ellipse(ell_cs, ecs);
-            wave_area2cloud(V, L, normals4, ecs, D, node, c.key == 0 ? 1 : 0, ab, sc);
-        }
+        if (itr > 0) wave_area2cloud(V, L, normals4, s_ell, D, node, c.key == 0 ? 1 : 0, ab, sc);
         if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break; /* a NaN bound passes, as in the reference: the node turns NaN below */
         const int iv = gsl_bsearch(nb, (double)ab[1], BY);
         const double bpx = steffen_eval_at(iv, nb, (double)ab[1], BY, BX);

@@ -719,16 +719,17 @@ def test_dynamic_fit_paths_agree():
     """The fits of the chain (compute_boundary's std::map + end knots, dynamic_adjust_path's map + Spline::restart) take one
     of three paths: samples already in knot order, equal y to merge, unsorted.  The synthetic clouds mostly take the
     first; test builds that force the second and the third on every fit must reproduce the product build's knots and
-    waypoints bit for bit (tools/dyn_variants_check.py; the variants are compiled here, ~1 min, when they are missing
-    or stale)."""
+    waypoints bit for bit.  Likewise Area2Cloud's windowed ellipse extremum (63 samples around the analytic peak when
+    the error bound allows): a build that evaluates all 721 samples as well, every time, and raises a device error on
+    any difference must run clean (tools/dyn_variants_check.py; the variants are compiled here, ~2 min, when they are
+    missing or stale)."""
     import os, shutil, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "polishpathplanning_amd", "csrc")
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc to build the test variants with")
-    for name, force in (("fitcount", 1), ("fitsort", 3)):
-        subprocess.run(["make", "-C", src, "variant", "NAME=%s" % name, "DEFS=-DDYN_FIT_FORCE=%d" % force], check=True,
-                       stdout=subprocess.DEVNULL, timeout=600)
+    for name, defs in (("fitcount", "-DDYN_FIT_FORCE=1"), ("fitsort", "-DDYN_FIT_FORCE=3"), ("ellcheck", "-DDYN_ELL_CHECK")):
+        subprocess.run(["make", "-C", src, "variant", "NAME=%s" % name, "DEFS=%s" % defs], check=True, stdout=subprocess.DEVNULL, timeout=600)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dyn_variants_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "the three paths agree" in r.stdout, r.stdout + r.stderr
 

@@ -256,6 +256,8 @@ def one_case(rng, i, only=None, verbose=False, big=None):
 
 
 def main():
+    if os.environ.get("PPP_FUZZ_LIB"):   # a test build of the engine (e.g. libppp_hip_ellcheck.so) instead of the product library
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), os.environ["PPP_FUZZ_LIB"])
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     only = int(sys.argv[3]) if len(sys.argv) > 3 else None

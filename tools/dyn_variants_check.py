@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Developer check: the fits of the dynamic adjustment take one of three paths (samples already in knot order; equal y to
-merge; unsorted).  Test builds that force the second and the third path on every fit must give the knots and the list of
-the product build, bit for bit.
+"""Developer check of the dynamic adjustment's data-dependent shortcuts against test builds of the same engine.
+* The fits take one of three paths (samples already in knot order; equal y to merge; unsorted): builds that force the second
+  and the third path on every fit must give the knots and the list of the product build, bit for bit.
+* Area2Cloud evaluates only the 63 ellipse samples around the analytic extremum when its error bound allows: a build that also
+  evaluates all 721 samples every time and raises a device error on any difference must run clean, with the same results.
   make -C polishpathplanning_amd/csrc variant NAME=fitcount DEFS=-DDYN_FIT_FORCE=1
   make -C polishpathplanning_amd/csrc variant NAME=fitsort DEFS=-DDYN_FIT_FORCE=3
+  make -C polishpathplanning_amd/csrc variant NAME=ellcheck DEFS=-DDYN_ELL_CHECK
 usage: python tools/dyn_variants_check.py"""
 import hashlib
 import os
@@ -26,7 +29,7 @@ for i in range(6):
     cases.append(("plate%d" % i, pts, dict(tool_radius=float(rng.choice([4.0, 6.0, 9.0])), walk=int(rng.choice([1, 2])))))
 ref = None
 bad = 0
-for libname in ("libppp_hip.so", "libppp_hip_fitcount.so", "libppp_hip_fitsort.so"):
+for libname in ("libppp_hip.so", "libppp_hip_fitcount.so", "libppp_hip_fitsort.so", "libppp_hip_ellcheck.so"):
     engine.LIB_PATH = os.path.join(base, libname)
     engine._lib = None
     sums = []
@@ -45,5 +48,5 @@ for libname in ("libppp_hip.so", "libppp_hip_fitcount.so", "libppp_hip_fitsort.s
         ref = sums
     elif sums != ref:
         bad += 1
-print("FAILED" if bad else "ok: the three paths agree on %d cases" % len(cases))
+print("FAILED" if bad else "ok: the three paths agree on %d cases (and the windowed ellipse extremum with all 721 samples)" % len(cases))
 sys.exit(1 if bad else 0)
