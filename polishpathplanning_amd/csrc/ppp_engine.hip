@@ -26,6 +26,9 @@
 #ifndef PPP_PPT16_FROM
 #define PPP_PPT16_FROM 1500000 /* ... and 16: a workgroup's run in a slab grows to ~7 points = most of a 128-byte line (2 M points: scatter 36.4 -> 32.4 us) */
 #endif
+#ifndef PPP_BATCH_SPLIT_FROM
+#define PPP_BATCH_SPLIT_FROM 8 /* members from which a batch is launched as two halves side by side (8 x 1 M points: 0.549 -> 0.533 ms; 16: 1.07 -> 1.04; 64 x 250 k: 0.877 -> 0.844) */
+#endif
 #ifndef PPP_MM_GRID_MAX
 #define PPP_MM_GRID_MAX 192 /* workgroups of the bounds + histogram pass: every one flushes its LDS histogram with an atomic per non-empty slab, which is what grows with the grid (1 M points: 192 is 1.5 us ahead of 256; 128 .. 160 the same) */
 #endif
@@ -1529,13 +1532,13 @@ bool batch_eligible(const ppp_handle h)
            slice_lds_ok(h, h->capb);
 }
 
-#define LAUNCHB(lead, name, kern, grid, block, shmem, ...)                                            \
+#define LAUNCHB(lead, strm, name, kern, grid, block, shmem, ...)                                      \
     do {                                                                                              \
         KTimer *_t = (lead)->timing ? timer_for((lead), name) : nullptr;                              \
-        if (_t) (void)hipEventRecord(_t->e0[_t->used], (lead)->stream);                               \
+        if (_t) (void)hipEventRecord(_t->e0[_t->used], (strm));                                       \
         (void)hipGetLastError();                                                                      \
-        hipLaunchKernelGGL(kern, grid, dim3(block), (shmem), (lead)->stream, __VA_ARGS__);            \
-        if (_t) { (void)hipEventRecord(_t->e1[_t->used], (lead)->stream); _t->used++; }               \
+        hipLaunchKernelGGL(kern, grid, dim3(block), (shmem), (strm), __VA_ARGS__);                    \
+        if (_t) { (void)hipEventRecord(_t->e1[_t->used], (strm)); _t->used++; }                       \
         hipError_t _le = hipGetLastError();                                                           \
         if (_le != hipSuccess) return fail((lead), PPP_ERR_HIP, std::string(name) + ": " + hipGetErrorString(_le)); \
     } while (0)
@@ -1602,30 +1605,56 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
 }
 
 /* one launch per stage over all members (blockIdx.y = member); ends with ONE copy of all meta blocks */
-int enqueue_batched(ppp_handle lead, BatchGraph *bg)
+/* the stage launches over members [first, first + n) of a batch, on `strm` (timers: the lead's, eager runs only) */
+static int enqueue_batched_stages(ppp_handle lead, BatchGraph *bg, hipStream_t strm, size_t first, size_t n)
 {
-    const size_t count = bg->hs.size();
     const int maxB = bg->maxB, max_slab_cap = bg->max_slab_cap, max_capb = bg->max_capb;
     const int gx_mm = bg->gx_mm, gx_scat = bg->gx_scat, gx_sort = bg->gx_sort, gx_slice = bg->gx_slice, gx_pose = bg->gx_pose, gx_smooth = bg->gx_smooth;
     const bool full_slabs = bg->full_slabs, ppt8 = bg->ppt8;
-    const unsigned gy = (unsigned)count;
+    const unsigned gy = (unsigned)n;
+    const BatchMember *mem = bg->members.p + first;
     const size_t hist_lds = sizeof(int) * (size_t)maxB;
-    LAUNCHB(lead, "k_minmax_b", k_minmax_b, dim3(gx_mm, gy), MM_T, hist_lds, bg->members.p);
+    LAUNCHB(lead, strm, "k_minmax_b", k_minmax_b, dim3(gx_mm, gy), MM_T, hist_lds, mem);
     /* (the set-up of every member rides in the scatter launch as that member's last workgroup) */
-    if (ppt8) LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, bg->members.p);
-    else LAUNCHB(lead, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, bg->members.p);
-    LAUNCHB(lead, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, bg->members.p);
-    LAUNCHB(lead, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), bg->members.p);
-    if (bg->pose_threads <= 256) LAUNCHB(lead, "k_pose_b", k_pose_b<256>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
-    else if (bg->pose_threads <= 512) LAUNCHB(lead, "k_pose_b", k_pose_b<512>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
-    else if (bg->pose_threads <= 768) LAUNCHB(lead, "k_pose_b", k_pose_b<768>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
-    else LAUNCHB(lead, "k_pose_b", k_pose_b<POSE_T>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, bg->members.p);
-    LAUNCHB(lead, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, bg->members.p);
+    if (ppt8) LAUNCHB(lead, strm, "k_slab_scatter_b", k_slab_scatter_b<8>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, mem);
+    else LAUNCHB(lead, strm, "k_slab_scatter_b", k_slab_scatter_b<4>, dim3(gx_scat + 1, gy), SCAT_T, 2 * hist_lds, mem);
+    LAUNCHB(lead, strm, "k_slab_sort_b", k_slab_sort_b, dim3(gx_sort, gy), full_slabs ? SORT_T : 256, (size_t)max_slab_cap * 12 + 16, mem);
+    LAUNCHB(lead, strm, "k_slice_kd_b", k_slice_kd_b, dim3(gx_slice, gy), bg->slice_thr, slice_kd_bytes(max_capb), mem);
+    if (bg->pose_threads <= 256) LAUNCHB(lead, strm, "k_pose_b", k_pose_b<256>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, mem);
+    else if (bg->pose_threads <= 512) LAUNCHB(lead, strm, "k_pose_b", k_pose_b<512>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, mem);
+    else if (bg->pose_threads <= 768) LAUNCHB(lead, strm, "k_pose_b", k_pose_b<768>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, mem);
+    else LAUNCHB(lead, strm, "k_pose_b", k_pose_b<POSE_T>, dim3(gx_pose, gy), bg->pose_threads, bg->pose_lds, mem);
+    LAUNCHB(lead, strm, "k_smooth_solve_b", k_smooth_solve_b, dim3(gx_smooth, gy), SMF_T, 0, mem);
+    return PPP_OK;
+}
+
+int enqueue_batched(ppp_handle lead, BatchGraph *bg)
+{
+    const size_t count = bg->hs.size();
+    /* A large batch goes as two halves side by side (the second on a member's own, otherwise idle stream, forked from and
+       joined to the lead's): while one half's launch drains -- its last workgroups on a mostly idle device -- the other
+       half's next stage is already running (64 x 250 k points: 0.87 -> 0.81 ms; four parts: 0.98).  Not when every launch is
+       timed (eager): the events would serialise the halves anyway. */
+    const bool split = !bg->eager && bg->fork && count >= PPP_BATCH_SPLIT_FROM;
+    if (!split) {
+        int rc = enqueue_batched_stages(lead, bg, lead->stream, 0, count);
+        if (rc) return rc;
+    } else {
+        const size_t half = count / 2;
+        hipStream_t side = bg->hs[half]->stream;
+        HIPCHK(lead, hipEventRecord(bg->fork, lead->stream));
+        HIPCHK(lead, hipStreamWaitEvent(side, bg->fork, 0));
+        int rc = enqueue_batched_stages(lead, bg, lead->stream, 0, half);
+        if (rc == PPP_OK) rc = enqueue_batched_stages(lead, bg, side, half, count - half);
+        if (rc) return rc;
+        HIPCHK(lead, hipEventRecord(bg->join[0], side));
+        HIPCHK(lead, hipStreamWaitEvent(lead->stream, bg->join[0], 0));
+    }
     if (count == 1) { /* nothing to collect: the one meta block goes straight to the host */
         HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->hs[0]->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, lead->stream));
         return PPP_OK;
     }
-    LAUNCHB(lead, "k_collect_meta", k_collect_meta, dim3(gy), 64, 0, bg->members.p, (int)count, bg->metas.p);
+    LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta, dim3((unsigned)count), 64, 0, bg->members.p, (int)count, bg->metas.p);
     HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->metas.p, sizeof(DevMeta) * count, hipMemcpyDeviceToHost, lead->stream));
     return PPP_OK;
 }
@@ -1707,6 +1736,12 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
             if (ea != hipSuccess) { discard(); return fail(lead, PPP_ERR_HIP, std::string("batch buffers: ") + hipGetErrorString(ea)); }
             rc = upload_members(lead, bg, dst_dev, offset_rows, cap_rows);
             if (rc != PPP_OK) { discard(); return rc; }
+            if (!eager && count >= PPP_BATCH_SPLIT_FROM) { /* the two halves of a large batch run side by side (enqueue_batched) */
+                bg->join.resize(1, nullptr);
+                hipError_t ee = hipEventCreateWithFlags(&bg->fork, hipEventDisableTiming);
+                if (ee == hipSuccess) ee = hipEventCreateWithFlags(&bg->join[0], hipEventDisableTiming);
+                if (ee != hipSuccess) { discard(); return fail(lead, PPP_ERR_HIP, std::string("batch events: ") + hipGetErrorString(ee)); }
+            }
             if (!eager) {
                 HIPCHK(lead, hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal));
                 rc = enqueue_batched(lead, bg);
