@@ -120,6 +120,9 @@ __device__ inline int slab_of_grid(float x, float x0, float invw, int B)
 #ifndef MM_T
 #define MM_T 512
 #endif
+#ifndef MM_UNROLL
+#define MM_UNROLL 2
+#endif
 /* bx / gx: this workgroup's index and the number of workgroups working on THIS cloud (the batched launch runs the
    workgroups of many clouds side by side: blockIdx.y = cloud) */
 template <bool HIST>
@@ -138,16 +141,26 @@ __device__ __forceinline__ void minmax_body(const float *__restrict__ X, const f
     int cnt = 0;
     const int n4 = n >> 2;
     const float4 *X4 = (const float4 *)X, *Y4 = (const float4 *)Y, *Z4 = (const float4 *)Z;
-    for (int i = bx * blockDim.x + threadIdx.x; i < n4; i += gx * blockDim.x) {
-        float4 x = X4[i], y = Y4[i], z = Z4[i];
-        const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w}, zs[4] = {z.x, z.y, z.z, z.w};
-        for (int k = 0; k < 4; ++k) {
-            if (xs[k] == xs[k]) {
-                mn[0] = fminf(mn[0], xs[k]); mx[0] = fmaxf(mx[0], xs[k]);
-                mn[1] = fminf(mn[1], ys[k]); mx[1] = fmaxf(mx[1], ys[k]);
-                mn[2] = fminf(mn[2], zs[k]); mx[2] = fmaxf(mx[2], zs[k]);
-                cnt++;
-                if (HIST && xs[k] >= xlo && xs[k] <= xhi) atomicAdd(&s_hist[slab_of_grid(xs[k], x0, invw, B)], 1);
+    const int stride = gx * (int)blockDim.x;
+    for (int i = bx * blockDim.x + threadIdx.x; i < n4; i += MM_UNROLL * stride) { /* MM_UNROLL groups of four points: their reads travel together */
+        float4 xq[MM_UNROLL], yq[MM_UNROLL], zq[MM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; ++u) {
+            const int j = i + u * stride;
+            if (j < n4) { xq[u] = X4[j]; yq[u] = Y4[j]; zq[u] = Z4[j]; }
+            else xq[u] = yq[u] = zq[u] = make_float4(NAN, NAN, NAN, NAN);
+        }
+#pragma unroll
+        for (int u = 0; u < MM_UNROLL; ++u) {
+            const float xs[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w}, ys[4] = {yq[u].x, yq[u].y, yq[u].z, yq[u].w}, zs[4] = {zq[u].x, zq[u].y, zq[u].z, zq[u].w};
+            for (int k = 0; k < 4; ++k) {
+                if (xs[k] == xs[k]) {
+                    mn[0] = fminf(mn[0], xs[k]); mx[0] = fmaxf(mx[0], xs[k]);
+                    mn[1] = fminf(mn[1], ys[k]); mx[1] = fmaxf(mx[1], ys[k]);
+                    mn[2] = fminf(mn[2], zs[k]); mx[2] = fmaxf(mx[2], zs[k]);
+                    cnt++;
+                    if (HIST && xs[k] >= xlo && xs[k] <= xhi) atomicAdd(&s_hist[slab_of_grid(xs[k], x0, invw, B)], 1);
+                }
             }
         }
     }
