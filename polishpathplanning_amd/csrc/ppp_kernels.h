@@ -1862,7 +1862,10 @@ __host__ __device__ inline size_t pose_lds_bytes(int knot_cap, int stage_cap, in
 #ifndef POSE_G2_MAX
 #define POSE_G2_MAX 384 /* 2 lanes x 384 waypoints = 768 threads, the largest form that keeps its registers (cfg 5, 258 waypoints per slice: 145 -> 135 us) */
 #endif
-__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= 128 ? 4 : (cnt <= POSE_G2_MAX ? 2 : 1); }
+#ifndef POSE_G4_MAX
+#define POSE_G4_MAX 128 /* (cfg 2, 103 waypoints a slice: 4 lanes 26.5 us, 2 lanes 29.6, 1 lane 29.3 -- the searches are a third of the kernel, the rest is the same for any lane count) */
+#endif
+__host__ __device__ inline int pose_lanes(int cnt) { return cnt <= POSE_G4_MAX ? 4 : (cnt <= POSE_G2_MAX ? 2 : 1); }
 
 #ifndef POSE_T
 #define POSE_T 1024
