@@ -56,7 +56,27 @@ def main():
     for _ in range(5):
         fin.finish_path_async(buf.value, off, counts); fin.sync()
     t_fin = (time.perf_counter() - t) / 5
+    # all ranges side by side on ONE GPU (each on its handle's own stream), then the finish: what splitting one large
+    # cloud across streams of the same device would give
+    t_conc = None
+    if os.environ.get("PPP_SLICES_CONCURRENT", "0") == "1":
+        def together():
+            for g in engines:
+                g.run_async()
+            for g in engines:
+                g.sync()
+            o = 0
+            for g in engines:
+                o += g.copy_stage_to_device(engine.STAGE_WP_PRESMOOTH, buf.value + 24 * o, W - o)
+            fin.finish_path_async(buf.value, o, counts); fin.sync()
+        together(); together()
+        t = time.perf_counter()
+        for _ in range(5):
+            together()
+        t_conc = (time.perf_counter() - t) / 5
     same = off == W and fin.waypoints().tobytes() == one.waypoints().tobytes() and np.array_equal(fin.tail_index(), one.tail_index())
+    if t_conc is not None:
+        print("all %d ranges side by side on this one GPU + copies + finish (host-driven): %.3f ms" % (len(engines), t_conc * 1e3))
     print("%s: N %d S %d W %d | one handle %.3f ms | %d ranges: slowest %.3f ms, mean %.3f ms | finish on rank 0 %.3f ms | "
           "projected %d-GPU step (no gather) %.3f ms | identical to one handle: %s"
           % (name, len(pts), S, W, t_one * 1e3, len(t_ranges), max(t_ranges) * 1e3, np.mean(t_ranges) * 1e3, t_fin * 1e3,
