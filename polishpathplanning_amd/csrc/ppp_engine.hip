@@ -11,6 +11,7 @@
 #include "ppp_preproc.h"
 #include "ppp_sort.h"
 #include "ppp_align.h"
+#include "ppp_gather.h"
 /* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
    clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
    slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
@@ -380,6 +381,11 @@ int enqueue_normals(ppp_handle h)
 int make_plan(ppp_handle h)
 {
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    /* from here on the handle's members are rewritten step by step: a re-plan that fails half way (a slice range wider
+       than the part this handle holds, an allocation) must leave no old plan, no finished-looking results and no
+       captured graph behind for a later ppp_run_async to replay against the new members */
+    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
+    h->drop_graph();
     const int n = (int)h->n;
     /* exact slice count from the cached bounds (the device recomputes the same walk) */
     int S = h->h_nvalid ? ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, nullptr, 0) : 0;
@@ -910,11 +916,14 @@ int ppp_set_params(ppp_handle h, const ppp_params *p)
     if (rc) return rc;
     bool rescale = h->have_cloud && (p->change_range != h->P.change_range);
     if (rescale) return fail(h, PPP_ERR_ARG, "ChangeRange changed after the cloud was set: set the cloud again");
+    const ppp_params before = h->P;
     h->P = *p;
     if (h->have_cloud) {
         HIPCHK(h, hipSetDevice(h->device));
         int rcs = settle(h);
-        return rcs ? rcs : make_plan(h);
+        if (!rcs) rcs = make_plan(h);
+        if (rcs) h->P = before; /* the rejected parameters do not stay: the next call plans the accepted ones again (planned is false) */
+        return rcs;
     }
     return PPP_OK;
 }
@@ -960,6 +969,10 @@ int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_
 {
     if (!h || (!xyz_host && n_part) || stride_bytes < 12 || (stride_bytes & 3) || !mn || !mx) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
     if (!(part_lo <= part_hi) || n_valid_total < n_part || n_valid_total > 0x7fffffffu / 8) return fail(h, PPP_ERR_ARG, "bad part interval / point count");
+    if (n_valid_total > 0)
+        for (int d = 0; d < 3; ++d)
+            if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || !(mn[d] <= mx[d]))
+                return fail(h, PPP_ERR_ARG, "the whole cloud's bounds must be finite and ordered (mn <= mx): they define the slice walk and the slab grid");
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     const size_t bytes = n_part * stride_bytes;
@@ -1822,8 +1835,11 @@ const Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl x;
-        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        /* PPP_RCCL_LIB: another RCCL build (or the recording stand-in of tests/test_gpu_parity.py) instead of the system's */
+        const char *over = getenv("PPP_RCCL_LIB");
+        void *lib = (over && *over) ? dlopen(over, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+        if (!lib && !(over && *over)) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib && !(over && *over)) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) return x;
         x.group_start = (int (*)())dlsym(lib, "ncclGroupStart");
         x.group_end = (int (*)())dlsym(lib, "ncclGroupEnd");
@@ -1846,7 +1862,6 @@ int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, in
     if (!h->path_done || !h->list_final) return fail(h, PPP_ERR_ARG, "no finished list on this handle (call ppp_get_path_async / ppp_run_async first)");
     if (counts_rows[rank] > (size_t)h->W_cap) return fail(h, PPP_ERR_CAPACITY, "counts_rows[rank] exceeds this handle's list capacity");
     if (rank == root && !recv_dev) return fail(h, PPP_ERR_ARG, "the root needs a receive buffer");
-    const int kFloat = 7; /* ncclFloat32 */
     if (nranks == 1) { /* nothing to exchange: the list goes to the receive buffer */
         if (counts_rows[0]) HIPCHK(h, hipMemcpyAsync(recv_dev, h->wp_out.p, counts_rows[0] * 24, hipMemcpyDeviceToDevice, h->stream));
         return PPP_OK;
@@ -1854,18 +1869,20 @@ int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, in
     if (!nccl_comm) return fail(h, PPP_ERR_ARG, "nccl_comm is NULL");
     const Rccl &R = rccl();
     if (!R.ok) return fail(h, PPP_ERR_UNSUPPORTED, "librccl.so not found (ncclGroupStart / ncclSend / ncclRecv)");
-    int e = R.group_start();
-    if (e) return fail(h, PPP_ERR_HIP, "ncclGroupStart failed");
-    if (rank == root) {
-        size_t off = 0;
-        for (int r = 0; r < nranks && !e; ++r) {
-            if (r == root) { if (counts_rows[r]) HIPCHK(h, hipMemcpyAsync(recv_dev + 6 * off, h->wp_out.p, counts_rows[r] * 24, hipMemcpyDeviceToDevice, h->stream)); }
-            else if (counts_rows[r]) e = R.recv(recv_dev + 6 * off, counts_rows[r] * 6, kFloat, r, nccl_comm, h->stream);
-            off += counts_rows[r];
-        }
-    } else if (counts_rows[rank]) e = R.send(h->wp_out.p, counts_rows[rank] * 6, kFloat, root, nccl_comm, h->stream);
-    const int e2 = R.group_end();
-    if (e || e2) return fail(h, PPP_ERR_HIP, "RCCL send / recv failed (ncclResult " + std::to_string(e ? e : e2) + ")");
+    PppGatherOps ops;
+    ops.group_start = R.group_start; ops.group_end = R.group_end;
+    ops.send = [](const void *buf, size_t count, int dtype, int peer, void *comm, void *stream) -> int { return rccl().send(buf, count, dtype, peer, comm, (hipStream_t)stream); };
+    ops.recv = [](void *buf, size_t count, int dtype, int peer, void *comm, void *stream) -> int { return rccl().recv(buf, count, dtype, peer, comm, (hipStream_t)stream); };
+    ops.local_copy = [](void *dst, const void *src, size_t bytes, void *stream) -> int {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : 1;
+    };
+    int nres = 0;
+    switch (ppp_gather_exchange(ops, rank, nranks, root, counts_rows, h->wp_out.p, recv_dev, nccl_comm, (void *)h->stream, &nres)) {
+    case PPP_GATHER_OK: break;
+    case PPP_GATHER_COPY_FAILED: return fail(h, PPP_ERR_HIP, "copy of the root's own block failed");
+    case PPP_GATHER_GROUP_START_FAILED: return fail(h, PPP_ERR_HIP, "ncclGroupStart failed (ncclResult " + std::to_string(nres) + ")");
+    default: return fail(h, PPP_ERR_HIP, "RCCL send / recv failed (ncclResult " + std::to_string(nres) + ")");
+    }
     return PPP_OK;
 }
 
@@ -2344,6 +2361,7 @@ int ppp_spline_eval(ppp_spline sp, const double *y, size_t k, double *xyz)
 {
     if (!sp || sp->n < 3 || (k && (!y || !xyz))) return PPP_ERR_ARG;
     if (!k) return PPP_OK;
+    if (k > 0x7fffffffu / 8) return PPP_ERR_CAPACITY; /* the kernel indexes with int, the scratch holds 4 k doubles */
     if (hipSetDevice(sp->device) != hipSuccess) return PPP_ERR_HIP;
     if (sp->scratch.ensure(4 * k) != hipSuccess) return PPP_ERR_HIP;
     double *dq = sp->scratch.p, *dout = dq + k;

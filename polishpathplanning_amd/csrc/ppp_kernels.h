@@ -2390,8 +2390,13 @@ __device__ __forceinline__ void smooth_solve_body(DevMeta *m, const DevParams &P
     __shared__ int s_last;
     __shared__ double s_rp[SMF_END]; /* r^k */
     __shared__ double s_e[2][3];     /* x - p at the two fixed ends */
+    __shared__ int s_err;
     const int W = m->W;
-    if (m->err || W == 0) return;
+    /* the error state is read ONCE per workgroup (thread 0, then a barrier): tile 0 may raise DERR_CAPACITY below while the
+       waves of this workgroup are still arriving here, and a wave that saw it would leave before the barriers its siblings wait at */
+    if (threadIdx.x == 0) s_err = m->err;
+    __syncthreads();
+    if (s_err || W == 0) return;
     const int ntiles = smooth_tiles(W);
     const int tile = bx;
     if (tile >= ntiles) return;

@@ -1400,3 +1400,30 @@ def test_gather_waypoints_single_rank_and_argument_checks(engine_mod):
     r = engine_mod.Engine(0, tool_radius=6.0, slice_begin=2, slice_end=5); r.set_cloud(pts); r.gen_path(); r.get_path()
     with pytest.raises(engine_mod.PPPError):
         r.gather_waypoints(0, 0, 1, 0, [1], buf.ptr)         # a slice-range handle has no finished list
+
+
+def test_gather_waypoints_multi_rank_pattern_through_a_recording_rccl(tmp_path):
+    """The send/recv branch of ppp_gather_waypoints through the real entry point: the engine dlopens its RCCL, so a
+    recording stand-in (PPP_RCCL_LIB, tests/helpers/rccl_standin.c) shows what a rank would enqueue -- blocks in rank
+    order, the root's own block copied in place, a rank without rows skipped, the handle's stream and the caller's
+    communicator passed through, the group closed when a transfer fails.  (The transfers themselves need several GPUs.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "gather_standin_drive.py"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    W, base, stream = d["W"], d["recv_ptr"], d["stream"]
+    assert d["own_block_in_place"]
+    tail = "dtype=7 peer=%d comm=4660 stream=%d"
+    assert d["root_log"] == ["group_start",
+                             "recv buf=%d count=42 " % base + tail % (0, stream),
+                             "recv buf=%d count=66 " % (base + 24 * (7 + W)) + tail % (3, stream),
+                             "group_end"]
+    assert len(d["send_log"]) == 3 and d["send_log"][0] == "group_start" and d["send_log"][2] == "group_end"
+    assert d["send_log"][1].startswith("send buf=") and d["send_log"][1].endswith("count=%d " % (6 * W) + tail % (2, stream))
+    assert d["fail_raised"] and "ncclResult 5" in d["fail_msg"]
+    assert d["fail_log"][0] == "group_start" and d["fail_log"][-1] == "group_end" and len(d["fail_log"]) == 3   # no second recv after the failure

@@ -431,3 +431,68 @@ def test_range_interval_is_the_walk_of_the_oracle(engine_mod, oracle_mod, walk):
         else:
             assert lo.value == np.float32(int(px[b]) - 2) - np.float32(margin)
             assert hi.value == np.float32(int(px[se - 1]) + 2) + np.float32(margin)
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference tree exists in the build container only (never copied, never shipped to the GPU box)")
+@pytest.mark.parametrize("driver,defs", [("main", []), ("connect", []), ("connect1", ["-DPPP_SDIR"]), ("contour", [])])
+def test_reference_drivers_compile_unchanged(engine_mod, tmp_path, driver, defs):
+    """the reference's own src/{main,connect,connect1,contour}.cpp compile UNCHANGED against
+    include/ (which supplies the cout / endl names VTK leaks upstream) and link against libppp_hip.so.  The only thing
+    this image lacks for them is PCL's console helper: tests/helpers/pcl_console_standin stands in for
+    <pcl/console/parse.h> / <pcl/console/print.h>.  The sources are compiled where they lie; nothing is copied."""
+    import subprocess
+    src = os.path.join(REF_SRC, driver + ".cpp")
+    exe = str(tmp_path / driver)
+    libdir = os.path.dirname(engine_mod.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", *defs, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "helpers", "pcl_console_standin"),
+           "-o", exe, src, "-L", libdir, "-lppp_hip", "-lX11", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # the drivers' own argument check (src/connect.cpp:11-21): no .pcd argument -> the usage line and -1, before any planner exists
+    r = subprocess.run([exe, "not_a_cloud.txt"], capture_output=True, text=True)
+    assert r.returncode == 255 and "./slicing_method cad_name.pcd" in r.stdout
+
+
+def _gather_drive(workdir, *args):
+    import subprocess
+    exe = os.path.join(workdir, "gather_drive")
+    if not os.path.exists(exe):
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "polishpathplanning_amd", "csrc"), "-o", exe,
+                            os.path.join(ROOT, "tests", "helpers", "gather_exchange_drive.cpp")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout.strip().split("\n")
+
+
+def test_gather_exchange_call_pattern(tmp_path):
+    """The send/recv branch of ppp_gather_waypoints (its host logic, ppp_gather.h) under recording stand-ins for RCCL:
+    block offsets in rank order, element counts, a root that is not rank 0, ranks without rows, and ncclGroupEnd
+    reached on every path once ncclGroupStart has succeeded (the open-group early return)."""
+    d = str(tmp_path)
+    counts = [5, 0, 7, 3]
+    # root = 2 of 4: its own block is copied (outside the group) to row offset 5, ranks 0 and 3 are received at 0 and 12, rank 1 has no rows
+    out = _gather_drive(d, 2, 4, 2, -1, *counts)
+    assert out[0].startswith("copy off=%d bytes=%d src_off=0" % (6 * 5, 24 * 7))
+    assert out[1] == "group_start" and out[-2] == "group_end" and out[-1] == "rc=0 nccl=0"
+    body = out[2:-2]
+    assert len(body) == 2
+    assert body[0].startswith("recv off=0 count=%d dtype=7 peer=0 comm=0x1234 stream=0x5678" % (6 * 5))
+    assert body[1].startswith("recv off=%d count=%d dtype=7 peer=3 " % (6 * 12, 6 * 3))
+    # a sending rank: one send of its rows to the root, nothing else
+    out = _gather_drive(d, 3, 4, 2, -1, *counts)
+    assert out == ["group_start", "send off=0 count=18 dtype=7 peer=2 comm=0x1234 stream=0x5678", "group_end", "rc=0 nccl=0"]
+    # a rank without rows opens and closes an empty group (every rank of the communicator takes part in the group call)
+    assert _gather_drive(d, 1, 4, 2, -1, *counts) == ["group_start", "group_end", "rc=0 nccl=0"]
+    # root 0, failures: the first recv fails -> no further recv, group_end still reached, the ncclResult is reported
+    out = _gather_drive(d, 0, 3, 0, 1, 4, 4, 4)
+    assert [l.split()[0] for l in out] == ["copy", "group_start", "recv", "group_end", "rc=3"] and out[-1] == "rc=3 nccl=5"
+    # group_end itself fails
+    assert _gather_drive(d, 1, 3, 0, 100, 4, 4, 4)[-1] == "rc=3 nccl=3"
+    # group_start fails: nothing is enqueued and no group is left open (none was opened)
+    assert _gather_drive(d, 1, 3, 0, 0, 4, 4, 4) == ["group_start", "rc=2 nccl=2"]
+    # the root's own copy fails before any group call
+    assert _gather_drive(d, 0, 3, 0, 200, 4, 4, 4)[1:] == ["rc=1 nccl=0"]
