@@ -297,6 +297,18 @@ int ppp_read_config(const char *path, ppp_config *c);
 /* pathFile writer (path_translation_alg.cpp:216-228): "x y z r p y " per line, ostream defaults */
 int ppp_write_path_file(const char *path, const float *wp6, size_t W);
 
+/* ---- which launch sequence plans a cloud ---- */
+/* The engine has two launch sequences for the same hot path, with the same results up to the last bits of the normals'
+ * float sums (both within the tolerances of tests/): the WINDOW path (three launches: every point binned once into the
+ * window of its slice, one fused per-slice kernel, the finish; kd pairing, no dynamic adjustment / alignment, tool steps
+ * wide enough that the slices' +-pad windows do not overlap, windows that fit a workgroup's LDS) and the SLAB-INDEX path
+ * (six launches, any parameters; also what the single-call mirrors and the dynamic adjustment search).  The plan picks the
+ * window path whenever it applies; a pass whose windows overflow or whose searches reach beyond them is repeated on the
+ * slab-index path by itself.  ppp_set_fast_path(h, 0) keeps a handle on the slab-index path (tests, comparisons);
+ * ppp_get_fast_path tells which one the current plan uses. */
+int ppp_set_fast_path(ppp_handle h, int on);
+int ppp_get_fast_path(ppp_handle h, int *active);
+
 /* ---- measurement ---- */
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
 int ppp_enable_timing(ppp_handle h, int on);

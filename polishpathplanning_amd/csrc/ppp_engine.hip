@@ -8,6 +8,7 @@
  * There is no CPU fallback: without a HIP device every entry point fails loudly.
  */
 #include "ppp_kernels.h"
+#include "ppp_window.h"
 #include "ppp_preproc.h"
 #include "ppp_sort.h"
 #include "ppp_align.h"
@@ -142,6 +143,22 @@ struct ppp_handle_s {
     bool big_path = false;             /* launch the fallback kernels (set by the plan or after an overflow) */
     int mm_grid = 1, mm_grid_used = 1, sm_tiles = 1;
     DevBuf<char> scratch; /* API staging */
+    /* window path (ppp_window.h): three launches, every point binned once into the window of its slice */
+    bool win_allowed = true;    /* ppp_set_fast_path */
+    bool win_disabled = false;  /* a pass was handed back (overflow / reach / stale plan): this cloud + parameters stay on the slab path */
+    bool win_path = false;      /* the current plan runs the window path */
+    bool stage_compact = true;  /* wp_xyz / wp_nn / wp_normal hold the list order (a window pass leaves them in per-slice slots) */
+    float win_pad = 4.f;
+    int win_capw = 0, win_cap_el = 0, win_NB = 0, win_NBc = 0, win_stride = 1, win_threads = 256, win_ppt = 4, win_gs = 1;
+    int win_nkept = 0, win_first_kept = 0;
+    float win_px0 = 0.f;
+    DevBuf<float> win_px;
+    DevBuf<int> win_cnt;
+    DevBuf<float4> win_pts;
+    DevBuf<MinMaxPart> win_part;
+    DevBuf<float4> wps_xyz, wps_normal;
+    DevBuf<int> wps_nn;
+    DevBuf<float> wps_pre;
 
     DevMeta hmeta;
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
@@ -184,6 +201,7 @@ struct ppp_handle_s {
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
+        win_px.release(); win_cnt.release(); win_pts.release(); win_part.release(); wps_xyz.release(); wps_normal.release(); wps_nn.release(); wps_pre.release();
         drop_graph();
         drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
@@ -215,6 +233,10 @@ struct BatchGraph {
     int gx_mm = 1, gx_scat = 1, gx_sort = 1, gx_slice = 1, gx_pose = 1, gx_smooth = 1;
     bool full_slabs = false, ppt8 = false;
     DevBuf<BatchMember> members;
+    bool win = false;              /* every member runs the window path: the three k_win_*_b launches */
+    DevBuf<WinArgs> wmembers;
+    int win_ppt = 4, win_threads = 256, gx_wfin = 1;
+    size_t win_lds = 0, win_scat_lds = 0, win_fin_lds = 0;
     DevBuf<DevMeta> metas;
     std::shared_ptr<BatchMetas> hmetas;
     ~BatchGraph()
@@ -223,7 +245,7 @@ struct BatchGraph {
         if (g) (void)hipGraphDestroy(g);
         if (fork) (void)hipEventDestroy(fork);
         for (auto e : join) if (e) (void)hipEventDestroy(e);
-        members.release(); metas.release();
+        members.release(); wmembers.release(); metas.release();
     }
 };
 void ppp_handle_s::drop_batch()
@@ -374,6 +396,136 @@ int enqueue_normals(ppp_handle h)
     if (n)
         LAUNCH(h, "k_normals_all", k_normals_all, (unsigned)((n + 255) / 256), 256, 0, h->meta.p, D, h->sorted4.p, h->slab_start.p,
                h->slab_xmin.p, h->slab_xmax.p, h->slab_ytab.p, -1, h->normals4.p);
+    return PPP_OK;
+}
+
+/* The window path (ppp_window.h) for this plan, when it applies: kd pairing without dynamic adjustment or alignment, windows
+   [Px - pad, Px + pad] that do not overlap (tool steps of about 2 pad + 2 mm and more) and that fit a workgroup's LDS.  Everything
+   else -- and every pass the window path hands back -- runs on the slab index.  Sizes come from the cached bounds, as the slab
+   grid's do; the device re-derives bounds and walk in every pass and checks them against this plan. */
+int plan_window(ppp_handle h, int S, double per)
+{
+    h->win_path = false;
+    const int step = (int)(h->P.tool_radius * 2);
+    if (!h->win_allowed || h->win_disabled || getenv("PPP_NO_WINDOW_PATH")) return PPP_OK;
+    if (h->P.pairing != PPP_PAIR_KD || h->P.dynamic_adjustment || h->aligned || h->big_path) return PPP_OK;
+    if (h->h_nvalid <= 0 || S < 1 || S > WIN_S_MAX || step < 1) return PPP_OK;
+    const double rx = (double)h->h_mx[0] - h->h_mn[0], ry = (double)h->h_mx[1] - h->h_mn[1];
+    const double area = rx * ry;
+    const double spacing = area > 0 ? std::sqrt(area / h->h_nvalid) : 1.0;
+    /* the band reaches 2 + |Px - trunc(Px)| < 3 mm from the plane; the nearest point of a waypoint lies within a point spacing or
+       so of the plane, its normal neighbourhood a radius further */
+    const float pad = (float)std::max(3.0, (double)h->P.normal_radius + std::max(1.5, spacing));
+    std::vector<float> px((size_t)S);
+    ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, px.data(), S);
+    double el_w = 0.0; /* widest left side of a band: bhi - Px */
+    for (int s = 0; s < S; ++s) {
+        if (!(std::fabs((double)px[s]) < 1.0e7)) return PPP_OK;
+        if (s + 1 < S && !((double)px[s + 1] - (double)px[s] > 2.0 * pad + 1.0e-2)) return PPP_OK; /* windows would overlap */
+        const double bhi = (double)(float)(2 + (int)px[s]), blo = (double)(float)(-2 + (int)px[s]);
+        el_w = std::max(el_w, std::max(bhi - (double)px[s], (double)px[s] - blo));
+    }
+    const double expect = rx > 2.0 * pad ? (double)h->h_nvalid * 2.0 * pad / rx : (double)h->h_nvalid;
+    const double el_expect = expect * el_w / (2.0 * pad);
+    int NBc = 16;
+    while (NBc < expect / 10.0 && NBc < 4096) NBc <<= 1;
+    /* capacities: 10 % and a few dozen points over the mean where LDS allows, never less than 3 % */
+    const size_t budget = (size_t)h->max_lds - 2048;
+    int capw = 0, cap_el = 0;
+    for (double f = 1.0; f >= 0.0; f -= 0.125) {
+        const double mw = 1.03 + 0.07 * f, aw = 32 + 160 * f;
+        capw = 64 * (int)std::ceil((mw * expect + aw) / 64.0);
+        cap_el = 64 * (int)std::ceil((mw * el_expect + aw / 2) / 64.0);
+        while (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget && NBc > 64 && f < 0.5) NBc >>= 1;
+        if (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) <= budget) break;
+        capw = 0;
+    }
+    if (!capw) return PPP_OK; /* the windows of this cloud do not fit a workgroup's LDS */
+    const int NB = WIN_CLASSES * NBc;
+    /* threads of a slice workgroup: a left point per thread in the pairing, four lanes per waypoint in the pose stage */
+    int T = 64 * (int)std::ceil(std::max(1.05 * el_expect, 4.0 * (double)h->cnt_est) / 64.0);
+    T = std::max(T, 64 * ((capw + 64 * WIN_EMAX - 1) / (64 * WIN_EMAX)));
+    T = std::max(T, 64 * ((cap_el + 64 * 4 - 1) / (64 * 4)));
+    T = std::max(256, T);
+    if (T > 1024) {
+        T = 1024;
+        if (capw > WIN_EMAX * T || cap_el > 4 * T) return PPP_OK;
+    }
+    const int n_src = h->use_part ? h->n_part : (int)h->n;
+    h->win_ppt = n_src > PPP_PPT16_FROM ? 16 : (n_src > PPP_PPT8_FROM ? 8 : 4);
+    h->win_gs = std::max(1, (n_src + h->win_ppt * WSC_T - 1) / (h->win_ppt * WSC_T));
+    h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
+    h->win_stride = std::max(1, (int)per);
+    h->win_first_kept = h->P.drop_ends ? 1 : 0;
+    h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
+    h->win_px0 = px[0];
+    HIPCHK(h, h->win_px.ensure((size_t)S)); HIPCHK(h, h->win_cnt.ensure((size_t)S)); HIPCHK(h, h->win_part.ensure((size_t)h->win_gs));
+    HIPCHK(h, h->win_pts.ensure((size_t)S * (size_t)capw));
+    const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
+    HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
+    HIPCHK(h, hipMemcpyAsync(h->win_px.p, px.data(), sizeof(float) * (size_t)S, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S, h->stream)); /* every pass leaves the counts cleared again */
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->win_path = true;
+    return PPP_OK;
+}
+
+/* the arguments of the three window launches for this handle */
+WinArgs win_args(const ppp_handle h)
+{
+    WinArgs A;
+    memset(&A, 0, sizeof(A));
+    A.m = h->meta.p; A.P = dev_params(h);
+    A.X = h->use_part ? h->Xp.p : h->X.p; A.Y = h->use_part ? h->Yp.p : h->Y.p; A.Z = h->use_part ? h->Zp.p : h->Z.p;
+    A.idmap = h->use_part ? h->part_idx.p : ((h->part_given && h->part_has_idx) ? h->part_idx.p : nullptr);
+    A.n = h->use_part ? h->n_part : (int)h->n;
+    A.plan_px = h->win_px.p;
+    A.S = h->S_cap; A.sb = h->sb; A.se = h->se; A.first_kept = h->win_first_kept; A.nkept = h->win_nkept;
+    A.pad = h->win_pad; A.px0 = h->win_px0; A.inv_step = 1.0f / (float)std::max(1, (int)(h->P.tool_radius * 2));
+    A.y0 = h->h_mn[1];
+    { const float yr = h->h_mx[1] - h->h_mn[1]; A.yscale = yr > 0.f ? (float)h->win_NBc / yr : 0.f; }
+    for (int d = 0; d < 3; ++d) { A.plan_mn[d] = h->h_mn[d]; A.plan_mx[d] = h->h_mx[d]; }
+    A.plan_nvalid = h->h_nvalid;
+    A.capw = h->win_capw; A.cap_el = h->win_cap_el; A.NB = h->win_NB; A.NBc = h->win_NBc; A.stride = h->win_stride;
+    A.W_cap = h->W_cap; A.node_cap = h->node_cap;
+    A.g_scatter = h->win_gs; A.g_slice = std::max(0, h->se - h->sb); A.g_finish = h->sm_tiles;
+    A.finish = h->ranged ? 0 : 1;
+    A.win_cnt = h->win_cnt.p; A.win_pts = h->win_pts.p; A.win_part = h->win_part.p;
+    A.px = h->px.p; A.lo = h->lo.p; A.hi = h->hi.p;
+    A.node_x = h->node_x.p; A.node_y = h->node_y.p; A.node_z = h->node_z.p;
+    A.node_start = h->node_start.p; A.node_cnt = h->node_cnt.p; A.band_cnt = h->band_cnt.p;
+    A.wp_cnt = h->wp_cnt.p; A.wp_off = h->wp_off.p; A.tail = h->tail.p;
+    A.wps_xyz = h->wps_xyz.p; A.wps_normal = h->wps_normal.p; A.wps_nn = h->wps_nn.p; A.wps_pre = h->wps_pre.p;
+    A.wp_pre = h->wp_pre.p; A.wp_smooth = h->wp_smooth.p; A.wp_out = h->wp_out.p; A.out2 = h->out2; A.out2_cap = h->out2_cap;
+    return A;
+}
+size_t win_slice_lds(const ppp_handle h)
+{   /* (the checking workgroup of the launch keeps the walk and its scratch there) */
+    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, h->win_NB), sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
+}
+
+/* GenPath on the window path: bounds + binning, then the per-slice kernel (which also does getPath's per-waypoint half) */
+int enqueue_window_gen(ppp_handle h)
+{
+    const WinArgs A = win_args(h);
+    const size_t scat_lds = 8 * (size_t)A.S;
+    if (h->win_ppt == 16) LAUNCH(h, "k_win_scatter", k_win_scatter<16>, A.g_scatter, WSC_T, scat_lds, A);
+    else if (h->win_ppt == 8) LAUNCH(h, "k_win_scatter", k_win_scatter<8>, A.g_scatter, WSC_T, scat_lds, A);
+    else LAUNCH(h, "k_win_scatter", k_win_scatter<4>, A.g_scatter, WSC_T, scat_lds, A);
+    const int T = h->win_threads;
+    const size_t lds = win_slice_lds(h);
+    if (T <= 256) LAUNCH(h, "k_win_slice", k_win_slice<256>, A.g_slice + 1, T, lds, A);
+    else if (T <= 512) LAUNCH(h, "k_win_slice", k_win_slice<512>, A.g_slice + 1, T, lds, A);
+    else if (T <= 768) LAUNCH(h, "k_win_slice", k_win_slice<768>, A.g_slice + 1, T, lds, A);
+    else LAUNCH(h, "k_win_slice", k_win_slice<1024>, A.g_slice + 1, T, lds, A);
+    h->stage_compact = false;
+    return PPP_OK;
+}
+/* the rest of getPath: offsets, compaction, postion_smooth / reduceRPY / flange */
+int enqueue_window_finish(ppp_handle h)
+{
+    const WinArgs A = win_args(h);
+    LAUNCH(h, "k_win_finish", k_win_finish, A.g_finish, SMF_T, sizeof(int) * ((size_t)A.nkept + 2), A);
     return PPP_OK;
 }
 
@@ -537,6 +689,8 @@ int make_plan(ppp_handle h)
     HIPCHK(h, h->wp_pre.ensure(6 * (size_t)h->W_cap)); HIPCHK(h, h->wp_smooth.ensure(6 * (size_t)h->W_cap));
     HIPCHK(h, h->wp_out.ensure(6 * (size_t)h->W_cap));
     h->sm_tiles = smooth_tiles(h->W_cap);
+    { int rcw = plan_window(h, S, per); if (rcw) return rcw; }
+    h->stage_compact = true;
     h->planned = true;
     h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
     h->drop_graph(); /* buffer addresses and launch geometry are baked into the captured graph */
@@ -561,6 +715,7 @@ int enqueue_index(ppp_handle h)
     const float *sX = h->use_part ? h->Xp.p : h->X.p, *sY = h->use_part ? h->Yp.p : h->Y.p, *sZ = h->use_part ? h->Zp.p : h->Z.p;
     const int *idmap = h->use_part ? h->part_idx.p : ((h->part_given && h->part_has_idx) ? h->part_idx.p : nullptr);
     DevParams D = dev_params(h);
+    D.keep_run_state = (h->win_path && h->gen_done) ? 1 : 0; /* an API mirror asks for the slab index behind a finished window pass */
     size_t hist_lds = sizeof(int) * (size_t)h->B;
     /* slab grid from the bounds cached when the cloud was set (identical to what k_minmax finds) */
     const float slab_x0 = h->h_mn[0];
@@ -705,6 +860,8 @@ int map_dev_err(ppp_handle h)
 {
     if (!h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0))
         return fail(h, PPP_ERR_CAPACITY, "a slab or band exceeds the LDS capacity: re-run (the arena passes are now enabled)");
+    if (h->win_path && h->hmeta.win_flag)
+        return fail(h, PPP_ERR_CAPACITY, "the window path handed this pass back (window overflow / reach / stale plan): re-run (the slab-index path is now selected)");
     switch (h->hmeta.err) {
     case DERR_NONE: return PPP_OK;
     case DERR_SLICE: {
@@ -725,9 +882,17 @@ int map_dev_err(ppp_handle h)
 int rerun_with_arena(ppp_handle h)
 {
     const bool had_path = h->path_done;
-    h->big_path = true;
-    h->drop_graph();
-    HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max<size_t>(h->n, 1) + (1u << 20)));
+    if (h->win_path && h->hmeta.win_flag) {
+        /* the window path's capacities or reach did not hold for this cloud: the same cloud and parameters on the slab index
+           from now on (a new cloud or new parameters try the window path again) */
+        h->win_disabled = true;
+        int rcp = make_plan(h);
+        if (rcp) return rcp;
+    } else {
+        h->big_path = true;
+        h->drop_graph();
+        HIPCHK(h, h->arena.ensure((size_t)64 * (size_t)std::max<size_t>(h->n, 1) + (1u << 20)));
+    }
     ++h->internal;
     int rc = ppp_gen_path_async(h);
     /* a member of a batch: the re-planned list must land where the batch put the first one (the caller's gather buffer) */
@@ -742,6 +907,7 @@ int rerun_with_arena(ppp_handle h)
 bool overflowed_fast_path(ppp_handle h)
 {
     /* (a GenPath on its own leaves no error behind: the slices parked for the arena pass are simply not planned yet) */
+    if (h->win_path && h->hmeta.win_flag) return true; /* the window path handed the pass back */
     return !h->big_path && (h->hmeta.big_slabs > 0 || h->hmeta.big_slices > 0);
 }
 
@@ -754,7 +920,8 @@ int ensure_ready(ppp_handle h, bool need_gen, bool need_path)
     if (need_path && !h->path_done) return fail(h, PPP_ERR_ARG, "call ppp_get_path_async first");
     int rc = fetch_meta(h);
     if (rc) return rc;
-    if (overflowed_fast_path(h)) return rerun_with_arena(h);
+    /* a pass handed back by the window path runs on the slab index, whose LDS fast path may overflow in turn (arena passes) */
+    for (int tries = 0; tries < 2 && overflowed_fast_path(h); ++tries) { rc = rerun_with_arena(h); if (rc) return rc; }
     return PPP_OK;
 }
 
@@ -798,6 +965,8 @@ int refresh_bounds_and_plan(ppp_handle h)
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
     h->normals_valid = false;
+    h->win_disabled = false;
+    h->big_path = false; /* (the plan turns the arena passes on again where this cloud needs them) */
     return make_plan(h);
 }
 
@@ -890,6 +1059,20 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_pts, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     (void)hipFuncSetAttribute((const void *)k_dyn_adjust_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute((const void *)k_band_indices, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_win_slice<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice<768>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice_b<256>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice_b<768>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_slice_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
     (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
     /* none of the opt-ins above is fatal (the launches check for themselves): leave no stale error behind for the next HIP
        user of this thread (a framework that reads hipGetLastError after its own calls would trip over it) */
@@ -918,6 +1101,7 @@ int ppp_set_params(ppp_handle h, const ppp_params *p)
     if (rescale) return fail(h, PPP_ERR_ARG, "ChangeRange changed after the cloud was set: set the cloud again");
     const ppp_params before = h->P;
     h->P = *p;
+    h->win_disabled = false;
     if (h->have_cloud) {
         HIPCHK(h, hipSetDevice(h->device));
         int rcs = settle(h);
@@ -1000,6 +1184,8 @@ int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_
     h->h_nvalid = (int)n_valid_total;
     if (!h->h_nvalid) for (int d = 0; d < 3; ++d) { h->h_mn[d] = 3.402823466e+38f; h->h_mx[d] = -3.402823466e+38f; }
     h->part_given = true; h->part_lo = part_lo; h->part_hi = part_hi;
+    h->win_disabled = false;
+    h->big_path = false;
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
     h->normals_valid = false;
@@ -1378,6 +1564,14 @@ int ppp_gen_path_async(ppp_handle h)
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->internal) { h->last_out2 = nullptr; h->last_out2_cap = 0; } /* a plain call: the list stays in the handle */
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    if (h->win_path) { /* bounds + binning into the slices' windows, then everything per slice in one launch (ppp_window.h) */
+        int rcw = enqueue_window_gen(h);
+        if (rcw) return rcw;
+        h->gen_done = true;
+        h->path_done = false;
+        if (h->chain_calls) return PPP_OK;
+        return enqueue_meta_copy(h);
+    }
     if (!slice_lds_ok(h, h->capb)) return fail(h, PPP_ERR_CAPACITY, "band capacity exceeds the LDS of this device");
     int rc = enqueue_index(h);
     if (rc) return rc;
@@ -1426,6 +1620,13 @@ int ppp_get_path_async(ppp_handle h)
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
+    if (h->win_path) { /* the per-waypoint half ran with the slices: offsets, compaction and getPath's list-wide second half */
+        int rcw = enqueue_window_finish(h);
+        if (rcw) return rcw;
+        h->path_done = true;
+        h->list_final = !h->ranged;
+        return enqueue_meta_copy(h);
+    }
     DevParams D = dev_params(h);
     int nk = std::max(1, h->S_cap);
     PoseBack PB;
@@ -1455,6 +1656,7 @@ int ppp_get_path_async(ppp_handle h)
     }
     h->path_done = true;
     h->list_final = false;
+    h->stage_compact = true;
     /* a slice-range handle stops here: postion_smooth couples the slices of different handles */
     if (!h->ranged) {
         int rc = enqueue_finish(h, D); /* publishes the meta block itself */
@@ -1474,7 +1676,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if ((W && !pre6_dev) || (nkept && !counts)) return fail(h, PPP_ERR_ARG, "bad arguments");
     if (W > (size_t)h->W_cap || nkept > (size_t)h->S_cap) return fail(h, PPP_ERR_CAPACITY, "the list is larger than this handle's plan (other cloud or parameters?)");
-    if (!h->index_built) { int rc = enqueue_index(h); if (rc) return rc; } /* the meta block is initialised by k_setup */
+    if (!h->index_built && !h->win_path) { int rc = enqueue_index(h); if (rc) return rc; } /* the meta block is initialised by k_setup (k_count_given sets what the finish reads) */
     DevParams D = dev_params(h);
     if (nkept) HIPCHK(h, hipMemcpyAsync(h->wp_cnt.p, counts, nkept * sizeof(int), hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "k_count_given", k_count_given, 1, 1024, 0, h->meta.p, D, (int)nkept, (int)W, h->wp_cnt.p, h->wp_off.p, h->tail.p, h->W_cap);
@@ -1482,6 +1684,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
     int rc = enqueue_finish(h, D);
     if (rc) return rc;
     h->gen_done = true; h->path_done = true; h->list_final = true;
+    h->stage_compact = true; /* (no per-waypoint stage lists belong to a list finished from gathered blocks) */
     return PPP_OK;
 }
 
@@ -1527,7 +1730,9 @@ int ppp_run_async(ppp_handle h)
         if (e != hipSuccess) { h->drop_graph(); return fail(h, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     }
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
-    h->index_built = true; h->gen_done = true; h->path_done = true;
+    if (!h->win_path) h->index_built = true;
+    h->stage_compact = !h->win_path;
+    h->gen_done = true; h->path_done = true;
     h->list_final = !h->ranged;
     h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
     h->meta_from_batch = false;
@@ -1617,6 +1822,32 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
     return PPP_OK;
 }
 
+/* the window path's records (ppp_window.h): every member's three launches become three launches for the batch */
+int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t *offset_rows, const size_t *cap_rows)
+{
+    const size_t count = bg->hs.size();
+    std::vector<WinArgs> mem(count);
+    bg->win_ppt = 4; bg->win_threads = 256; bg->win_lds = 0; bg->win_scat_lds = 0; bg->win_fin_lds = 0;
+    bg->gx_scat = 1; bg->gx_slice = 1; bg->gx_wfin = 1;
+    for (size_t i = 0; i < count; ++i) bg->win_ppt = std::max(bg->win_ppt, bg->hs[i]->win_ppt);
+    for (size_t i = 0; i < count; ++i) {
+        ppp_handle h = bg->hs[i];
+        h->out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
+        h->out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
+        WinArgs &A = mem[i];
+        A = win_args(h);
+        h->out2 = nullptr; h->out2_cap = 0;
+        A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (<= the member's own: its partials fit) */
+        bg->win_threads = std::max(bg->win_threads, h->win_threads);
+        bg->win_lds = std::max(bg->win_lds, win_slice_lds(h));
+        bg->win_scat_lds = std::max(bg->win_scat_lds, 8 * (size_t)A.S);
+        bg->win_fin_lds = std::max(bg->win_fin_lds, sizeof(int) * ((size_t)A.nkept + 2));
+        bg->gx_scat = std::max(bg->gx_scat, A.g_scatter); bg->gx_slice = std::max(bg->gx_slice, A.g_slice + 1); bg->gx_wfin = std::max(bg->gx_wfin, A.g_finish);
+    }
+    HIPCHK(lead, copy_sync(lead, bg->wmembers.p, mem.data(), sizeof(WinArgs) * count, hipMemcpyHostToDevice));
+    return PPP_OK;
+}
+
 /* one launch per stage over all members (blockIdx.y = member); ends with ONE copy of all meta blocks */
 /* the stage launches over members [first, first + n) of a batch, on `strm` (timers: the lead's, eager runs only) */
 static int enqueue_batched_stages(ppp_handle lead, BatchGraph *bg, hipStream_t strm, size_t first, size_t n)
@@ -1625,6 +1856,19 @@ static int enqueue_batched_stages(ppp_handle lead, BatchGraph *bg, hipStream_t s
     const int gx_mm = bg->gx_mm, gx_scat = bg->gx_scat, gx_sort = bg->gx_sort, gx_slice = bg->gx_slice, gx_pose = bg->gx_pose, gx_smooth = bg->gx_smooth;
     const bool full_slabs = bg->full_slabs, ppt8 = bg->ppt8;
     const unsigned gy = (unsigned)n;
+    if (bg->win) { /* the window path: bounds + binning, the per-slice kernel, the finish -- three launches for the whole batch */
+        const WinArgs *wm = bg->wmembers.p + first;
+        if (bg->win_ppt == 16) LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<16>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        else if (bg->win_ppt == 8) LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<8>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        else LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<4>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        const int T = bg->win_threads;
+        if (T <= 256) LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<256>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);
+        else if (T <= 512) LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<512>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);
+        else if (T <= 768) LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<768>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);
+        else LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<1024>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);
+        LAUNCHB(lead, strm, "k_win_finish_b", k_win_finish_b, dim3(bg->gx_wfin, gy), SMF_T, bg->win_fin_lds, wm);
+        return PPP_OK;
+    }
     const BatchMember *mem = bg->members.p + first;
     const size_t hist_lds = sizeof(int) * (size_t)maxB;
     LAUNCHB(lead, strm, "k_minmax_b", k_minmax_b, dim3(gx_mm, gy), MM_T, hist_lds, mem);
@@ -1667,7 +1911,8 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
         HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->hs[0]->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, lead->stream));
         return PPP_OK;
     }
-    LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta, dim3((unsigned)count), 64, 0, bg->members.p, (int)count, bg->metas.p);
+    if (bg->win) LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta_win, dim3((unsigned)count), 64, 0, bg->wmembers.p, (int)count, bg->metas.p);
+    else LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta, dim3((unsigned)count), 64, 0, bg->members.p, (int)count, bg->metas.p);
     HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->metas.p, sizeof(DevMeta) * count, hipMemcpyDeviceToHost, lead->stream));
     return PPP_OK;
 }
@@ -1682,7 +1927,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     if (dst_dev && (!offset_rows || !cap_rows)) return fail(lead, PPP_ERR_ARG, "offset_rows / cap_rows are needed with a destination");
     if (count > 65535) return fail(lead, PPP_ERR_CAPACITY, "a batch holds at most 65535 workpieces (one grid row each)");
     HIPCHK(lead, hipSetDevice(lead->device));
-    bool plain = false, batched = true;
+    bool plain = false, batched = true, allwin = true;
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = hs[i];
         if (!h) return fail(lead, PPP_ERR_ARG, "null handle in the batch");
@@ -1694,7 +1939,13 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         if (!h->planned) { rc = make_plan(h); if (rc) { lead->err = h->err; return rc; } }
         plain = plain || h->timing;
         batched = batched && batch_eligible(h);
+        allwin = allwin && h->win_path;
     }
+    /* A member's list must not depend on the company it is planned in: the two paths differ in the last bits of the normals'
+       float sums, so a batch runs as rows of batched launches only when ALL members are on the window path or NONE is
+       (mixed batches take one graph branch per member, each on its own path). */
+    if (allwin) batched = true;
+    else for (size_t i = 0; i < count; ++i) if (hs[i]->win_path) batched = false;
     auto remember_dst = [&](size_t i) { /* where a re-run after an LDS overflow must put the list (rerun_with_arena) */
         hs[i]->last_out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
         hs[i]->last_out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
@@ -1717,7 +1968,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     }
     BatchGraph *bg = nullptr;
     for (BatchGraph *cand : lead->batches) {
-        bool same = cand && cand->hs.size() == count && cand->dst == dst_dev && cand->batched == batched && cand->eager == eager;
+        bool same = cand && cand->hs.size() == count && cand->dst == dst_dev && cand->batched == batched && cand->eager == eager && cand->win == allwin;
         for (size_t i = 0; same && i < count; ++i)
             same = cand->hs[i] == hs[i] && cand->epochs[i] == hs[i]->epoch && (!dst_dev || (cand->off[i] == offset_rows[i] && cand->cap[i] == cap_rows[i]));
         if (same) { bg = cand; break; }
@@ -1734,6 +1985,7 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         bg->hs.assign(hs, hs + count);
         bg->dst = dst_dev;
         bg->batched = batched;
+        bg->win = allwin;
         bg->eager = eager;
         if (dst_dev) { bg->off.assign(offset_rows, offset_rows + count); bg->cap.assign(cap_rows, cap_rows + count); }
         auto discard = [&]() { delete lead->batches[slot]; lead->batches[slot] = nullptr; };
@@ -1743,11 +1995,12 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         if (batched) {
             /* ONE launch per stage over all members.  Records and meta array first, outside the capture. */
             hipError_t ea = bg->members.ensure(count);
+            if (ea == hipSuccess) ea = bg->wmembers.ensure(count);
             if (ea == hipSuccess) ea = bg->metas.ensure(count);
             bg->hmetas = std::make_shared<BatchMetas>();
             if (ea == hipSuccess) ea = hipHostMalloc((void **)&bg->hmetas->pinned, sizeof(DevMeta) * count, hipHostMallocDefault);
             if (ea != hipSuccess) { discard(); return fail(lead, PPP_ERR_HIP, std::string("batch buffers: ") + hipGetErrorString(ea)); }
-            rc = upload_members(lead, bg, dst_dev, offset_rows, cap_rows);
+            rc = bg->win ? upload_members_win(lead, bg, dst_dev, offset_rows, cap_rows) : upload_members(lead, bg, dst_dev, offset_rows, cap_rows);
             if (rc != PPP_OK) { discard(); return rc; }
             if (!eager && count >= PPP_BATCH_SPLIT_FROM) { /* the two halves of a large batch run side by side (enqueue_batched) */
                 bg->join.resize(1, nullptr);
@@ -1809,7 +2062,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
     else HIPCHK(lead, hipGraphLaunch(bg->ge, lead->stream));
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = hs[i];
-        h->index_built = true; h->gen_done = true; h->path_done = true;
+        if (!(bg->batched && bg->win) && !(!bg->batched && h->win_path)) h->index_built = true;
+        h->stage_compact = !((bg->batched && bg->win) || (!bg->batched && h->win_path));
+        h->gen_done = true; h->path_done = true;
         h->list_final = !h->ranged;
         h->meta_in_flight = true;
         h->meta_from_batch = bg->batched;
@@ -1909,7 +2164,7 @@ int ppp_sync(ppp_handle h)
     HIPCHK(h, hipSetDevice(h->device));
     int rc = fetch_meta(h);
     if (rc) return rc;
-    if (overflowed_fast_path(h)) {
+    for (int tries = 0; tries < 2 && overflowed_fast_path(h); ++tries) {
         rc = rerun_with_arena(h);
         if (rc) return rc;
     }
@@ -2033,9 +2288,19 @@ int ppp_copy_stage_to_device(ppp_handle h, int stage, float *dst_dev, size_t cap
     return PPP_OK;
 }
 
+/* bounds and slice tables of the resident cloud: left by the last window pass (its checking workgroup), else by the slab index */
+static int bounds_ready(ppp_handle h)
+{
+    if (h && h->have_cloud && h->planned && h->win_path && h->gen_done) {
+        HIPCHK(h, hipSetDevice(h->device));
+        return PPP_OK;
+    }
+    return ensure_index(h);
+}
+
 int ppp_minmax(ppp_handle h, float mn[3], float mx[3])
 {
-    int rc = ensure_index(h);
+    int rc = bounds_ready(h);
     if (rc) return rc;
     rc = fetch_meta(h);
     if (rc) return rc;
@@ -2045,7 +2310,7 @@ int ppp_minmax(ppp_handle h, float mn[3], float mx[3])
 
 int ppp_get_slice_positions(ppp_handle h, float *px, size_t cap, size_t *S)
 {
-    int rc = ensure_index(h);
+    int rc = bounds_ready(h);
     if (rc) return rc;
     rc = fetch_meta(h);
     if (rc) return rc;
@@ -2280,12 +2545,23 @@ int ppp_nearest(ppp_handle h, const float *q_xyz, size_t k, int *idx)
     return PPP_OK;
 }
 
+/* a window pass leaves the per-waypoint stage lists in per-slice slots: into list order when somebody asks */
+static int ensure_stage_lists(ppp_handle h)
+{
+    if (h->stage_compact || !h->win_path) return PPP_OK;
+    const WinArgs A = win_args(h);
+    if (A.nkept > 0) LAUNCH(h, "k_win_gather_stage", k_win_gather_stage, A.nkept, 256, 0, A, h->wp_xyz.p, h->wp_nn.p, h->wp_normal.p);
+    h->stage_compact = true;
+    return PPP_OK;
+}
+
 int ppp_get_stage(ppp_handle h, int stage, void *out, size_t cap_bytes, size_t *count)
 {
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
     rc = map_dev_err(h);
     if (rc) return rc;
+    if (stage == PPP_STAGE_WP_XYZ || stage == PPP_STAGE_WP_NN || stage == PPP_STAGE_WP_NORMAL) { rc = ensure_stage_lists(h); if (rc) return rc; }
     size_t W = (size_t)h->hmeta.W;
     if (count) *count = W;
     if (!out || !cap_bytes || !W) return PPP_OK;
@@ -2415,6 +2691,30 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps)
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
     *sweeps = h->hmeta.sweeps;
+    return PPP_OK;
+}
+
+int ppp_set_fast_path(ppp_handle h, int on)
+{
+    if (!h) return PPP_ERR_ARG;
+    const bool want = on != 0;
+    if (want == h->win_allowed) return PPP_OK;
+    h->win_allowed = want;
+    if (h->have_cloud) {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rcs = settle(h);
+        if (rcs) return rcs;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return make_plan(h);
+    }
+    return PPP_OK;
+}
+
+int ppp_get_fast_path(ppp_handle h, int *active)
+{
+    if (!h || !active) return PPP_ERR_ARG;
+    if (h->have_cloud && !h->planned) { int rc = make_plan(h); if (rc) return rc; }
+    *active = (h->have_cloud && h->win_path) ? 1 : 0;
     return PPP_OK;
 }
 

@@ -34,6 +34,7 @@ struct DevMeta {
     float incl_lo, incl_hi;  /* x interval of the points this handle indexes */
     int n_sorted;            /* points in the slab index */
     float ytab_scale;        /* y-bucket table of the slabs: bucket(y) = (int)((y - mn[1]) * ytab_scale), clamped to [0, YTB) */
+    int win_flag;            /* window path (ppp_window.h): non-zero = this pass must be repeated on the slab-index path */
 };
 
 struct DevParams {
@@ -50,6 +51,9 @@ struct DevParams {
        gives the reference, and what the walk and the slab grid are built from) come with the plan */
     int bounds_given, g_nvalid;
     float g_mn[3], g_mx[3];
+    /* the slab index is being built on demand (an API mirror) behind a finished window-path pass: the set-up keeps that
+       pass's run state (W, errors, knot cursor) in the meta block instead of resetting it */
+    int keep_run_state;
 };
 
 #define SCAT_COARSE_SHIFT 6 /* two-pass scatter of large clouds: 64 neighbouring slabs form a coarse bin */
@@ -356,7 +360,11 @@ __device__ __forceinline__ void setup_body(DevMeta *m, const DevParams &P, const
         r.n_valid = c;
         r.W = 0; r.err = 0; r.err_slice = 0x7fffffff; r.sweeps = 0; r.any_short = 0; r.rpy_oob = 0;
         r.node_cursor = 0; r.api_cnt = 0; r.api_flag = 0; r.smooth_done = -1; r.emit_ticket = 0;
-        r.big_slabs = 0; r.big_slices = 0; r.arena_cursor = 0;
+        r.big_slabs = 0; r.big_slices = 0; r.arena_cursor = 0; r.win_flag = 0;
+        if (P.keep_run_state) {
+            r.W = m->W; r.err = m->err; r.err_slice = m->err_slice; r.any_short = m->any_short; r.rpy_oob = m->rpy_oob;
+            r.node_cursor = m->node_cursor; r.smooth_done = m->smooth_done; r.win_flag = m->win_flag;
+        }
         int S = 0;
         s_nfront = -1;
         const int istep = (int)(P.tool_radius * 2);

@@ -1,0 +1,910 @@
+/*
+ * ppp_window.h -- the WINDOW path of the hot path: three launches instead of six.
+ *
+ *   k_win_scatter   every point is read ONCE (12 B): bounds (a2) + binning straight into the window of the slice it can
+ *                   matter to -- [Px - pad, Px + pad], pad = band half-width / nearest-neighbour ball / normal radius;
+ *                   the ~1/3 of the cloud between two windows is never written.  Plan-sized window capacity, a count per
+ *                   window (overflow -> the run falls back to the slab-index path), no separate histogram pass.
+ *   k_win_slice     one workgroup per slice: the window staged once into LDS and bucket-sorted there on (class, y, index)
+ *                   (classes = the x intervals left of the band | Er | on the plane | El | right of the band); on the same
+ *                   staged points: rangedX_index + insert_point (path_slicing_alg.cpp:152-237), OnePath's map flattening
+ *                   (:240-267), getPath's sampling (path_translation_alg.cpp:156-169), nearest point + PCL normal + pose +
+ *                   HandEyeTransform (:178-211).  The bucket table of the sort doubles as the y index of every search.
+ *                   Waypoints go to per-slice slots; one more workgroup re-derives the slice walk (a3) from the bounds
+ *                   and checks the plan it was launched with.
+ *   k_win_finish    scans the per-slice waypoint counts, compacts the list and runs postion_smooth / reduceRPY /
+ *                   TransFlangeposition (:212-214) as k_smooth_solve does.
+ *
+ * The slab index (k_minmax .. k_slab_sort, ppp_kernels.h) stays: it serves the API mirrors, the dynamic adjustment, brute
+ * pairing, alignment, overlapping windows (small tools) and every run the window path hands back (DevMeta.win_flag).
+ *
+ * Speculation, and how it is checked: the launches are sized by the PLAN (slice positions from the bounds cached when the
+ * cloud was set -- the same values the slab path's grid comes from).  The bounds and the walk are recomputed in every
+ * pass (a2, a3 stay inside the timed region) and compared with the plan; a difference raises WIN_FLAG_STALE and the run is
+ * repeated on the slab path.  Every nearest-neighbour ball and normal neighbourhood is checked to lie inside its window.
+ */
+#pragma once
+#include "ppp_kernels.h"
+
+/* DevMeta.win_flag: why this pass must be repeated on the slab-index path (not an error of the input) */
+enum { WIN_FLAG_OVERFLOW = 1,  /* a window or its left side holds more points than the plan's LDS capacity      */
+       WIN_FLAG_REACH = 2,     /* a nearest-neighbour ball or a normal neighbourhood reaches beyond its window  */
+       WIN_FLAG_STALE = 4 };   /* bounds or slice walk of this pass differ from the plan the launches were sized by */
+__device__ inline void win_flag(DevMeta *m, int why) { atomicOr(&m->win_flag, why); }
+
+#define WIN_CLASSES 5
+#define WIN_EMAX 8 /* staged points per thread at most (capw <= WIN_EMAX * blockDim) */
+
+struct WinArgs {
+    DevMeta *m;
+    DevParams P;
+    const float *X, *Y, *Z;
+    const int *idmap;
+    int n;
+    const float *plan_px; /* the plan's slice positions (host walk over the cached bounds) */
+    int S, sb, se, first_kept, nkept;
+    float pad, px0, inv_step, y0, yscale; /* bucket(y) = (int)((y - y0) * yscale), clamped to [0, NBc) */
+    float plan_mn[3], plan_mx[3];
+    int plan_nvalid;
+    int capw, cap_el, NB, NBc, stride, W_cap, node_cap;
+    int g_scatter, g_slice, g_finish; /* workgroups of this workpiece per launch */
+    int finish; /* 0: a slice-range handle stops after HandEyeTransform (the list is compacted only) */
+    int *win_cnt;
+    float4 *win_pts;
+    MinMaxPart *win_part;
+    float *px, *lo, *hi;
+    float *node_x, *node_y, *node_z;
+    int *node_start, *node_cnt, *band_cnt;
+    int *wp_cnt, *wp_off, *tail;
+    float4 *wps_xyz, *wps_normal;
+    int *wps_nn;
+    float *wps_pre;
+    float *wp_pre, *wp_smooth, *wp_out, *out2;
+    int out2_cap;
+};
+
+__host__ __device__ inline size_t win_slice_lds_bytes(int capw, int cap_el, int NB)
+{
+    return (size_t)capw * 16 + (((size_t)NB + 1) * 4 + 15) / 16 * 16 + (size_t)cap_el * 16 + 16;
+}
+
+/* ------------------------------------------------------------------ */
+/* launch 1: bounds + window binning                                    */
+/* ------------------------------------------------------------------ */
+#ifndef WSC_T
+#define WSC_T 1024
+#endif
+template <int PPT>
+__device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    float *s_px = (float *)s_dyn;       /* S plane positions */
+    int *s_cnt = s_dyn + A.S;           /* S counts, then bases */
+    __shared__ float s_mn[3][WSC_T / 64], s_mx[3][WSC_T / 64];
+    __shared__ int s_n[WSC_T / 64];
+    const int S = A.S, n = A.n;
+    const int i0 = bx * (PPT * (int)blockDim.x);
+    float4 p[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int i = i0 + threadIdx.x + k * (int)blockDim.x;
+        if (i < n) p[k] = make_float4(A.X[i], A.Y[i], A.Z[i], __int_as_float(A.idmap ? A.idmap[i] : i));
+        else p[k] = make_float4(NAN, 0.f, 0.f, 0.f);
+    }
+    for (int s = threadIdx.x; s < S; s += blockDim.x) { s_px[s] = A.plan_px[s]; s_cnt[s] = 0; }
+    if (bx == 0 && threadIdx.x == 0) { /* the run state of this pass: nothing else in this launch touches the meta block */
+        DevMeta *m = A.m;
+        m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
+        m->node_cursor = 0; m->smooth_done = -1; m->emit_ticket = 0; m->big_slabs = 0; m->big_slices = 0; m->arena_cursor = 0; m->win_flag = 0;
+    }
+    __syncthreads();
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    int pw[PPT], pr[PPT]; /* window (or -1) and rank inside this workgroup's run */
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const float x = p[k].x;
+        pw[k] = -1; pr[k] = 0;
+        if (x == x) {
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], p[k].y); mx[1] = fmaxf(mx[1], p[k].y);
+            mn[2] = fminf(mn[2], p[k].z); mx[2] = fmaxf(mx[2], p[k].z);
+            cnt++;
+            /* the slice whose plane is nearest: within one of the lattice guess (the planes are `step` apart up to the
+               rounding of the float walks and the off-lattice centre plane of the centre-out integer walk) */
+            const float fj = fminf(fmaxf(floorf((x - A.px0) * A.inv_step + 0.5f), 0.f), (float)(S - 1));
+            const int j = (int)fj;
+            const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
+            const float da = fabsf(x - s_px[ja]), dj = fabsf(x - s_px[j]), db = fabsf(x - s_px[jb]);
+            int w = -1;
+            if (dj <= A.pad) w = j; else if (da <= A.pad) w = ja; else if (db <= A.pad) w = jb; /* windows are disjoint (plan) */
+            if (w >= A.sb && w < A.se) { pw[k] = w; pr[k] = atomicAdd(&s_cnt[w], 1); }
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const int c = s_cnt[s];
+        if (c) s_cnt[s] = atomicAdd(&A.win_cnt[s], c); /* this workgroup's run inside the window */
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (pw[k] >= 0) {
+            const int pos = s_cnt[pw[k]] + pr[k];
+            if (pos < A.capw) A.win_pts[(size_t)pw[k] * A.capw + pos] = p[k]; /* beyond: the slice sees count > capw and hands the run back */
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_n[wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPart r;
+        r.cnt = 0; r.pad = 0;
+        const int nw = (int)(blockDim.x >> 6);
+        for (int w = 0; w < nw; ++w) r.cnt += s_n[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < nw; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            r.mn[d] = a; r.mx[d] = b;
+        }
+        A.win_part[bx] = r;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* launch 2: the per-slice kernel                                       */
+/* ------------------------------------------------------------------ */
+struct WinView {
+    const float4 *pts;
+    const int *tab; /* tab[b] = end of bucket b */
+    int NBc;
+    float y0, yscale;
+    int cs[WIN_CLASSES + 1]; /* class c = pts[cs[c], cs[c + 1]) */
+    __device__ inline int ybucket(float y) const
+    {
+        int q = (int)((y - y0) * yscale);
+        q = q < 0 ? 0 : q;
+        return q >= NBc ? NBc - 1 : q;
+    }
+    /* first position of class c whose y >= qy (cs[c + 1] when there is none): one table look-up, then the bucket's few points */
+    __device__ inline int lower_bound(int c, float qy) const
+    {
+        const int b = c * NBc + ybucket(qy);
+        int lo = b ? tab[b - 1] : 0;
+        const int hi = tab[b];
+        while (lo < hi && pts[lo].y < qy) ++lo;
+        return lo;
+    }
+};
+
+/* one direction of one class: candidates in the reference's order of decreasing promise, four reads in flight */
+template <typename Visit>
+__device__ __forceinline__ void win_walk(const WinView &V, int c, int p, bool up, Visit visit)
+{
+    const int s0 = V.cs[c], s1 = V.cs[c + 1];
+    if (up) {
+        for (int i = p; i < s1; i += 4) {
+            const int e = s1 - 1;
+            const float4 c0 = V.pts[i], c1 = V.pts[min(i + 1, e)], c2 = V.pts[min(i + 2, e)], c3 = V.pts[min(i + 3, e)];
+            if (!visit(c0, i)) break;
+            if (i + 1 > e || !visit(c1, i + 1)) break;
+            if (i + 2 > e || !visit(c2, i + 2)) break;
+            if (i + 3 > e || !visit(c3, i + 3)) break;
+        }
+    } else {
+        for (int i = p - 1; i >= s0; i -= 4) {
+            const float4 c0 = V.pts[i], c1 = V.pts[max(i - 1, s0)], c2 = V.pts[max(i - 2, s0)], c3 = V.pts[max(i - 3, s0)];
+            if (!visit(c0, i)) break;
+            if (i - 1 < s0 || !visit(c1, i - 1)) break;
+            if (i - 2 < s0 || !visit(c2, i - 2)) break;
+            if (i - 3 < s0 || !visit(c3, i - 3)) break;
+        }
+    }
+}
+
+/* kd-tree 1-NN of q inside ONE class (insert_point's per-side trees): ties -> lowest cloud index.  Returns the position. */
+__device__ inline int win_nn_class(const WinView &V, int c, const float4 q)
+{
+    float best = INFINITY;
+    int bidx = 0x7fffffff, bj = V.cs[c];
+    auto visit = [&](const float4 &k, int i) {
+        const float dy = q.y - k.y;
+        if (dy * dy > best) return false;
+        const float d = dist2_flann(q.x, q.y, q.z, k.x, k.y, k.z);
+        const int id = idx_of(k);
+        if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bj = i; }
+        return true;
+    };
+    const int p = V.lower_bound(c, q.y);
+    win_walk(V, c, p, true, visit);
+    win_walk(V, c, p, false, visit);
+    return bj;
+}
+
+/* units of a waypoint's two searches: (class, direction), inner classes first.  Lane g of the 4 lanes of a waypoint takes
+   unit g of every round; a round's partial results are combined by the same shuffle tree whatever the launch geometry. */
+__device__ __forceinline__ int win_unit_class(int round, int g) { return round == 0 ? (g < 2 ? 1 : 3) : (round == 1 ? (g < 2 ? 0 : 4) : 2); }
+
+#ifndef WSL_T
+#define WSL_T 1024
+#endif
+
+template <int TMAX>
+__device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    __shared__ int s_scr[17];
+    __shared__ int s_cs[WIN_CLASSES + 1];
+    __shared__ int s_m, s_base, s_nk, s_cnt;
+    DevMeta *m = A.m;
+    const DevParams &P = A.P;
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    const int capw = A.capw, cap_el = A.cap_el, NB = A.NB, NBc = A.NBc;
+    float4 *pts = (float4 *)s_raw;
+    int *tab = (int *)(pts + capw);
+    char *scr = (char *)tab + (((size_t)NB + 1) * 4 + 15) / 16 * 16;
+    float *cz = (float *)scr;                 /* z of the node candidate of the i-th El point */
+    u64 *ckeys = (u64 *)(cz + cap_el);        /* candidates sorted by y; later the knots as (y, z) pairs */
+    int *hc = (int *)(ckeys + cap_el);        /* histogram of that sort, then the kept candidates */
+    float2 *knot = (float2 *)ckeys;
+
+    const int s = A.sb + bx;
+    if (s >= A.se) return;
+    const int k = s - A.first_kept; /* index among the kept slices (getPath drops the first and the last, :149-150) */
+    const bool kept = k >= 0 && k < A.nkept;
+    const float Px = A.plan_px[s];
+    const int position = (int)Px;   /* rangedX_index(int position), path_slicing_alg.cpp:152,247 */
+    const float blo = (float)(-2 + position), bhi = (float)(2 + position);
+    auto slice_fails = [&](int code) { /* code < 0: not the slice's fault -- hand the pass back (-code = WIN_FLAG_*) */
+        if (tid == 0) {
+            if (code < 0) win_flag(m, -code); else set_err(m, code, s);
+            A.node_start[s] = 0; A.node_cnt[s] = 0; if (kept) A.wp_cnt[k] = 0;
+        }
+    };
+    /* ---- stage the window: points to registers, class + bucket, bucket sort into LDS ---- */
+    const int n = A.win_cnt[s];
+    __syncthreads(); /* every thread has read the count ... */
+    if (tid == 0) A.win_cnt[s] = 0; /* ... this workgroup is its only reader: cleared for the next pass */
+    if (n > capw) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
+    float4 pr[WIN_EMAX];
+    int pb[WIN_EMAX];
+    const float4 *src = A.win_pts + (size_t)s * capw;
+#pragma unroll
+    for (int e = 0; e < WIN_EMAX; ++e) {
+        const int i = tid + e * T;
+        pb[e] = -1;
+        if (i < n) pr[e] = src[i];
+    }
+    for (int b = tid; b <= NB; b += T) tab[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < WIN_EMAX; ++e) {
+        const int i = tid + e * T;
+        if (i < n) {
+            const float4 p = pr[e];
+            int c;
+            if (p.x < blo) c = 0;
+            else if (p.x > bhi) c = 4;
+            else {
+                const float distance2plane = (p.x - Px) * 1.f + (p.y - 0.f) * 0.f + (p.z - 0.f) * 0.f; /* path_slicing_alg.cpp:179 */
+                c = distance2plane > 0 ? 3 : (distance2plane < 0 ? 1 : 2);
+            }
+            int q = (int)((p.y - A.y0) * A.yscale);
+            q = q < 0 ? 0 : (q >= NBc ? NBc - 1 : q);
+            pb[e] = c * NBc + q;
+            atomicAdd(&tab[pb[e]], 1);
+        }
+    }
+    __syncthreads();
+    {   /* exclusive scan of the histogram */
+        const int per = (NB + T - 1) / T;
+        const int b0 = tid * per;
+        int sum = 0;
+        for (int q = 0; q < per; ++q) if (b0 + q < NB) sum += tab[b0 + q];
+        int total;
+        int pre = block_exscan(sum, s_scr, &total);
+        for (int q = 0; q < per; ++q) if (b0 + q < NB) { const int c = tab[b0 + q]; tab[b0 + q] = pre; pre += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) pts[atomicAdd(&tab[pb[e]], 1)] = pr[e];
+    __syncthreads();
+    /* tab[b] is now the END of bucket b; every bucket (a handful of points) is finished on (y, cloud index) */
+    for (int b = tid; b < NB; b += T) {
+        const int s0 = b ? tab[b - 1] : 0, e = tab[b];
+        for (int p = s0 + 1; p < e; ++p) {
+            const float4 kp = pts[p];
+            int q = p - 1;
+            while (q >= s0) {
+                const float4 o = pts[q];
+                if (!(kp.y < o.y || (kp.y == o.y && idx_of(kp) < idx_of(o)))) break;
+                pts[q + 1] = o; --q;
+            }
+            pts[q + 1] = kp;
+        }
+    }
+    if (tid <= WIN_CLASSES) s_cs[tid] = 0;
+    __syncthreads();
+    if (tid < WIN_CLASSES) s_cs[tid + 1] = tab[(tid + 1) * NBc - 1];
+    __syncthreads();
+    WinView V;
+    V.pts = pts; V.tab = tab; V.NBc = NBc; V.y0 = A.y0; V.yscale = A.yscale;
+#pragma unroll
+    for (int c = 0; c <= WIN_CLASSES; ++c) V.cs[c] = s_cs[c];
+    const int nEr = V.cs[2] - V.cs[1], nEl = V.cs[4] - V.cs[3];
+    if (tid == 0) A.band_cnt[s] = V.cs[4] - V.cs[1]; /* |rangedX_index| */
+    if (nEl == 0 || nEr == 0) { slice_fails(DERR_SLICE); return; }  /* empty map -> < 3 knots; empty FLANN tree */
+    if (nEl > cap_el) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
+    /* ---- insert_point, kd flavour (path_slicing_alg.cpp:184-233): for every left point the nearest right point, for
+       that one the nearest left point, the pair interpolated onto the plane ---- */
+    constexpr int CE = 4; /* candidates per thread at most (cap_el <= CE * blockDim is checked by the plan) */
+    u64 kr[CE];
+    int kb[CE];
+    int NBcand = next_pow2(max(nEl, 64)); /* about a candidate per bucket, as many as the histogram's cap_el + 1 slots allow */
+    while (NBcand > cap_el) NBcand >>= 1;
+    const float yr_scale = A.yscale * (float)NBcand / (float)NBc; /* NBcand buckets over the same y range */
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const int i = tid + e * T;
+        kb[e] = -1; kr[e] = 0;
+        if (i < nEl) {
+            const float4 q = pts[V.cs[3] + i];
+            const float4 R = pts[win_nn_class(V, 1, q)];
+            const float4 Lp = pts[win_nn_class(V, 3, R)];
+            const float t = (Px - R.x) / (Lp.x - R.x);
+            float y = R.y + t * (Lp.y - R.y);
+            const float z = R.z + t * (Lp.z - R.z);
+            if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
+            cz[i] = z;
+            kr[e] = YK_MAKE(y, i);
+            int q2 = (int)((y - A.y0) * yr_scale);
+            kb[e] = q2 < 0 ? 0 : (q2 >= NBcand ? NBcand - 1 : q2);
+        }
+    }
+    /* ---- std::map by y: bucket sort of the candidates (keys made once, kept in registers) ---- */
+    for (int b = tid; b <= NBcand; b += T) hc[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) atomicAdd(&hc[kb[e]], 1);
+    __syncthreads();
+    {
+        const int per = (NBcand + T - 1) / T;
+        const int b0 = tid * per;
+        int sum = 0;
+        for (int q = 0; q < per; ++q) if (b0 + q < NBcand) sum += hc[b0 + q];
+        int total;
+        int pre = block_exscan(sum, s_scr, &total);
+        for (int q = 0; q < per; ++q) if (b0 + q < NBcand) { const int c = hc[b0 + q]; hc[b0 + q] = pre; pre += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) ckeys[atomicAdd(&hc[kb[e]], 1)] = kr[e];
+    __syncthreads();
+    for (int b = tid; b < NBcand; b += T) {
+        const int s0 = b ? hc[b - 1] : 0, e = hc[b];
+        for (int p = s0 + 1; p < e; ++p) {
+            const u64 kp = ckeys[p];
+            int q = p - 1;
+            while (q >= s0 && kp < ckeys[q]) { ckeys[q + 1] = ckeys[q]; --q; }
+            ckeys[q + 1] = kp;
+        }
+    }
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    /* one knot per distinct y: Node[y] = ... is overwritten by every later writer and El is walked in ascending cloud index,
+       so the z kept is the one of the candidate with the highest cloud index inside the run of equal keys.  The knots take
+       the place of the sorted keys: everything a chunk needs of them is read before the scan's barriers, written after. */
+    for (int base = 0; base < nEl; base += T) {
+        const int j = base + tid;
+        int keep = 0;
+        float ky = 0.f, kz = 0.f;
+        if (j < nEl) {
+            const u64 kj = ckeys[j];
+            keep = (j == nEl - 1) || (YK_Y(ckeys[j + 1]) != YK_Y(kj));
+            if (keep) {
+                int best_i = YK_POS(kj);
+                int best_idx = idx_of(pts[V.cs[3] + best_i]);
+                for (int q = j - 1; q >= 0 && YK_Y(ckeys[q]) == YK_Y(kj); --q) {
+                    const int ci = YK_POS(ckeys[q]);
+                    const int id = idx_of(pts[V.cs[3] + ci]);
+                    if (id > best_idx) { best_idx = id; best_i = ci; }
+                }
+                ky = ord2f(YK_Y(kj)); kz = cz[best_i];
+            }
+        }
+        int tot;
+        const int pre = block_exscan(keep, s_scr, &tot);
+        const int o = s_m;
+        __syncthreads();
+        if (keep) knot[o + pre] = make_float2(ky, kz);
+        if (tid == 0) s_m = o + tot;
+        __syncthreads();
+    }
+    const int mm = s_m;
+    if (tid == 0) {
+        int tot = mm;
+        int base = atomicAdd(&m->node_cursor, tot);
+        if (base + tot > A.node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
+        s_base = base; s_nk = tot;
+        A.node_start[s] = base; A.node_cnt[s] = tot;
+        if (tot < 3) set_err(m, DERR_SLICE, s); /* gsl_spline_alloc needs >= 3 knots */
+        int cnt = 0;
+        if (kept && tot >= 1) cnt = sample_count((double)knot[0].x, (double)knot[tot - 1].x, P.trim, P.path_resolution, A.stride);
+        if (cnt > A.stride) { set_err(m, DERR_CAPACITY, s); cnt = 0; }
+        if (tot < 3) cnt = 0;
+        s_cnt = cnt;
+        if (kept) A.wp_cnt[k] = cnt;
+    }
+    __syncthreads();
+    const int nknots = s_nk, cnt = s_cnt;
+    for (int i = tid; i < nknots; i += T) {
+        const float2 kn = knot[i];
+        A.node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
+        A.node_y[s_base + i] = kn.x;
+        A.node_z[s_base + i] = kn.y;
+    }
+    if (cnt == 0) return;
+    /* ---- getPath for this slice: sampling (:156-169), nearest point, PCL normal, frame, Euler, hand-eye (:178-208) ---- */
+    auto Yf = [&](int i) { return (double)knot[i].x; };
+    auto Zf = [&](int i) { return (double)knot[i].y; };
+    const double ystart = (double)knot[0].x + P.trim;
+    const double yfirst = (double)knot[0].x, ylast = (double)knot[mm - 1].x;
+    const double inv_span = ylast > yfirst ? (double)(mm - 1) / (ylast - yfirst) : 0.0;
+    const bool dy_closed_form = sums_exact(ystart, P.path_resolution, (double)cnt);
+    float HE[3][3];
+    handeye_rotation(P.handeye, HE);
+    const int g = tid & 3, per = T >> 2;
+    const int rounds = (cnt + per - 1) / per;
+    const int per_round = (cnt + rounds - 1) / rounds; /* the waypoints spread evenly over the rounds */
+    const bool has_plane_class = V.cs[3] > V.cs[2];
+    const float r2 = P.normal_radius * P.normal_radius;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int lt = tid >> 2;
+        const int t = rd * per_round + lt;
+        const bool act = lt < per_round && t < cnt;
+        double dy = ystart;
+        if (dy_closed_form) dy = ystart + (double)(act ? t : 0) * P.path_resolution; /* every partial sum is exact: same bits */
+        else for (int r = 0; r < (act ? t : 0); ++r) dy += P.path_resolution;       /* the reference accumulates */
+        /* gsl_interp_bsearch's interval -- the largest i <= mm - 2 with y_i <= dy, 0 below the first knot -- from a guess and a short walk */
+        int iv;
+        {
+            int gi = (int)((dy - yfirst) * inv_span);
+            gi = gi < 0 ? 0 : (gi > mm - 2 ? mm - 2 : gi);
+            int steps = 0;
+            while (gi > 0 && Yf(gi) > dy && steps < 12) { --gi; ++steps; }
+            while (gi < mm - 2 && Yf(gi + 1) <= dy && steps < 12) { ++gi; ++steps; }
+            iv = gi;
+            if (steps >= 12) iv = gsl_bsearch(mm, dy, Yf);
+        }
+        /* x: every knot lies on its plane, so the y -> x spline is that constant, exactly (all slopes zero) */
+        const double zd = steffen_eval_at(iv, mm, dy, Yf, Zf);
+        const float4 q = make_float4((float)(double)Px, (float)dy, (float)zd, 1.f);
+        const bool finite = q.y == q.y && q.z == q.z;
+        const bool on = act && finite;
+        /* -- kdtree.nearestKSearch(q, 1) (:189): inner classes first, the outer ones are closed by their x gap almost always -- */
+        float best = P.nn_hint2;
+        int bidx = 0x7fffffff;
+        float4 bp = make_float4(NAN, NAN, NAN, 0.f);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int round = 0; round < 3; ++round) {
+                if (round == 2 && !has_plane_class) break;
+                const int c = win_unit_class(round, g);
+                const bool up = (g & 1) == 0;
+                const bool mine = on && !(round == 2 && g >= 2);
+                if (mine) {
+                    /* every point of class 0 lies left of the band, of class 4 right of it */
+                    const float gap = c == 0 ? q.x - blo : (c == 4 ? bhi - q.x : 0.f);
+                    if (!(gap > 0.f && gap * gap > best)) {
+                        const int p0 = V.lower_bound(c, q.y);
+                        win_walk(V, c, p0, up, [&](const float4 &kk, int) {
+                            const float dyy = q.y - kk.y;
+                            if (dyy * dyy > best) return false;
+                            const float d = dist2_flann(q.x, q.y, q.z, kk.x, kk.y, kk.z);
+                            const int id = idx_of(kk);
+                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = kk; }
+                            return true;
+                        });
+                    }
+                }
+                for (int o = 2; o > 0; o >>= 1) { /* minimum of the four lanes on (distance, cloud index) */
+                    const float od = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bidx, o, 64);
+                    const float ox = __shfl_xor(bp.x, o, 64), oy = __shfl_xor(bp.y, o, 64), oz = __shfl_xor(bp.z, o, 64), ow = __shfl_xor(bp.w, o, 64);
+                    if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bp = make_float4(ox, oy, oz, ow); }
+                }
+            }
+            if (__all(bidx != 0x7fffffff || !on)) break;
+            best = INFINITY; /* nothing within the hint: the same search without a bound */
+        }
+        const bool found = on && bidx != 0x7fffffff;
+        /* the window holds every point within `pad` of the plane: the answers are the whole cloud's as long as the ball that
+           proves the nearest neighbour and the normal's radius search stay inside it */
+        if (on && g == 0) {
+            bool ok = found;
+            if (found) {
+                const float dq = sqrtf(best) * 1.0001f + 1.0e-4f;
+                ok = dq <= A.pad && fabsf(bp.x - Px) + P.normal_radius * 1.0001f + 1.0e-4f <= A.pad;
+            }
+            if (!ok) win_flag(m, WIN_FLAG_REACH);
+        }
+        /* -- pcl::NormalEstimation at that point (path_slicing_alg.cpp:141-150): radius search, covariance about the point -- */
+        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int count = 0;
+        const float4 c0 = bp;
+        for (int round = 0; round < 3; ++round) {
+            if (round == 2 && !has_plane_class) break;
+            float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            int cn = 0;
+            const int c = win_unit_class(round, g);
+            const bool up = (g & 1) == 0;
+            if (found && !(round == 2 && g >= 2)) {
+                const float gap = c == 0 ? c0.x - blo : (c == 4 ? bhi - c0.x : 0.f);
+                if (!(gap > 0.f && gap * gap > r2)) {
+                    const int p0 = V.lower_bound(c, c0.y);
+                    win_walk(V, c, p0, up, [&](const float4 &kk, int) {
+                        const float dyy = c0.y - kk.y;
+                        if (dyy * dyy > r2) return false;
+                        if (dist2_flann(c0.x, c0.y, c0.z, kk.x, kk.y, kk.z) <= r2) {
+                            const float x = kk.x - c0.x, y = kk.y - c0.y, z = kk.z - c0.z;
+                            a[0] += x * x; a[1] += x * y; a[2] += x * z;
+                            a[3] += y * y; a[4] += y * z; a[5] += z * z;
+                            a[6] += x; a[7] += y; a[8] += z;
+                            cn++;
+                        }
+                        return true;
+                    });
+                }
+            }
+            for (int o = 1; o < 4; o <<= 1) { /* (up + down) of a class, then the two classes of the round: a fixed tree */
+#pragma unroll
+                for (int i = 0; i < 9; ++i) a[i] += __shfl_xor(a[i], o, 64);
+                cn += __shfl_xor(cn, o, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += a[i];
+            count += cn;
+        }
+        if (act && g == 0) {
+            float n4[4] = {NAN, NAN, NAN, NAN};
+            if (found && count >= 3) {
+                const float cntf = (float)count;
+                for (int i = 0; i < 9; ++i) acc[i] /= cntf;
+                float cov[9];
+                cov[0] = acc[0] - acc[6] * acc[6];
+                cov[1] = acc[1] - acc[6] * acc[7];
+                cov[2] = acc[2] - acc[6] * acc[8];
+                cov[4] = acc[3] - acc[7] * acc[7];
+                cov[5] = acc[4] - acc[7] * acc[8];
+                cov[8] = acc[5] - acc[8] * acc[8];
+                cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+                float ev, nn[3];
+                pcl_eigen33_smallest<false>(cov, &ev, nn); /* continuous outputs only: the device float trig is enough */
+                const float eig_sum = cov[0] + cov[4] + cov[8];
+                const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+                const float vx = P.viewpoint[0] - c0.x, vy = P.viewpoint[1] - c0.y, vz = P.viewpoint[2] - c0.z;
+                if (vx * nn[0] + vy * nn[1] + vz * nn[2] < 0) { nn[0] *= -1; nn[1] *= -1; nn[2] *= -1; }
+                n4[0] = nn[0]; n4[1] = nn[1]; n4[2] = nn[2]; n4[3] = curv;
+            }
+            if (!finite) set_err(m, DERR_QUERY, -1);
+            float wp[6], rpy[3];
+            pose_from_normal(n4, rpy);
+            if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
+            else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
+            wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
+            handeye_apply(HE, P.handeye, wp);
+            /* Vector4f(point), std::reverse on every second slice (:166-168) */
+            const size_t slot = (size_t)k * A.stride + (size_t)((k & 1) ? (cnt - 1 - t) : t);
+            A.wps_xyz[slot] = q;
+            A.wps_nn[slot] = found ? bidx : -1;
+            A.wps_normal[slot] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+#pragma unroll
+            for (int d = 0; d < 6; ++d) A.wps_pre[6 * slot + d] = wp[d];
+        }
+    }
+}
+
+/* the extra workgroup of launch 2: a2 finished (the scatter's partials reduced), a3 (the slice walk) recomputed from those
+   bounds, both compared with the plan the launches were sized by; the meta block and the slice tables for the host */
+__device__ __forceinline__ void win_verify_body(const WinArgs &A)
+{
+    extern __shared__ __attribute__((aligned(16))) char s_raw[];
+    float *s_px = (float *)s_raw;              /* S floats, then 2048 of scratch for the walk (the launch's dynamic LDS covers both) */
+    float *s_front = s_px + A.S;
+    __shared__ float s_mn[3][WSL_T / 64], s_mx[3][WSL_T / 64];
+    __shared__ int s_cnt[WSL_T / 64];
+    __shared__ int s_S, s_bad;
+    DevMeta *m = A.m;
+    const DevParams &P = A.P;
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int i = tid; i < A.g_scatter; i += T) {
+        const MinMaxPart r = A.win_part[i];
+        cnt += r.cnt;
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], r.mn[d]); mx[d] = fmaxf(mx[d], r.mx[d]); }
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        const int nw = T >> 6;
+        for (int w = 0; w < nw; ++w) c += s_cnt[w];
+        float rmn[3], rmx[3];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < nw; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            rmn[d] = c ? a : 3.402823466e+38f; /* getMinMax3D starts from +-FLT_MAX */
+            rmx[d] = c ? b : -3.402823466e+38f;
+        }
+        int bad = 0;
+        if (P.bounds_given) { /* this handle saw its part of the cloud only: the whole cloud's bounds came with it; the part must lie inside */
+            for (int d = 0; d < 3; ++d) { if (c && (rmn[d] < P.g_mn[d] || rmx[d] > P.g_mx[d])) bad = 1; rmn[d] = P.g_mn[d]; rmx[d] = P.g_mx[d]; }
+            c = P.g_nvalid;
+        }
+        for (int d = 0; d < 3; ++d) if (rmn[d] != A.plan_mn[d] || rmx[d] != A.plan_mx[d]) bad = 1;
+        if (c != A.plan_nvalid) bad = 1;
+        int S = c ? slice_walk_device(P.walk, rmn[0], rmx[0], P.tool_radius, s_px, A.S, s_front, 2048) : 0;
+        if (S != A.S) bad = 1;
+        for (int d = 0; d < 3; ++d) { m->mn[d] = rmn[d]; m->mx[d] = rmx[d]; m->mn_ord[d] = f2ord(rmn[d]); m->mx_ord[d] = f2ord(rmx[d]); }
+        m->n_valid = c;
+        m->S = S > A.S ? A.S : S;
+        m->first_kept = P.drop_ends ? 1 : 0;
+        { const int nk = P.drop_ends ? S - 2 : S; m->nkept = nk < 0 ? 0 : nk; }
+        m->sb = A.sb; m->se = A.se;
+        m->incl_lo = P.incl_lo; m->incl_hi = P.incl_hi;
+        s_S = S > A.S ? A.S : S;
+        if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    const int S = s_S;
+    int bad = 0;
+    for (int s = tid; s < S; s += T) {
+        const float v = s_px[s];
+        if (v != A.plan_px[s]) bad = 1;
+        const int position = (int)v;
+        A.px[s] = v; A.lo[s] = (float)(-2 + position); A.hi[s] = (float)(2 + position);
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (tid == 0 && s_bad) win_flag(m, WIN_FLAG_STALE);
+}
+
+/* ------------------------------------------------------------------ */
+/* launch 3: offsets + compaction + postion_smooth / reduceRPY / flange */
+/* ------------------------------------------------------------------ */
+#define WIN_S_MAX 8192 /* slices of a plan on this path (plane table and counters of the scatter, offsets of the finish live in LDS) */
+__device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_off[]; /* nkept + 1 offsets */
+    __shared__ float s_x[3][SMF_M];
+    __shared__ int s_scan[17];
+    __shared__ int s_run, s_short, s_last, s_err;
+    __shared__ double s_rp[SMF_END];
+    __shared__ double s_e[2][3];
+    DevMeta *m = A.m;
+    const DevParams &P = A.P;
+    const int nk = A.nkept, tid = (int)threadIdx.x;
+    if (tid == 0) { s_err = m->err; s_run = 0; s_short = 0; }
+    __syncthreads();
+    if (s_err) return;
+    /* a9 bookkeeping: every workgroup scans the waypoint counts of all kept slices (left by the slice workgroups) */
+    const int res_i = (int)P.rpy_resolution;
+    for (int base = 0; base < nk; base += blockDim.x) {
+        const int k2 = base + tid;
+        int c2 = 0;
+        if (k2 < nk) {
+            const int s2 = k2 + A.first_kept;
+            if (s2 >= A.sb && s2 < A.se) c2 = A.wp_cnt[k2];
+        }
+        int tot;
+        const int pre = block_exscan(c2, s_scan, &tot);
+        const int run = s_run;
+        if (k2 < nk) {
+            s_off[k2] = run + pre;
+            if (P.rpy_resolution > 2 && c2 <= res_i) s_short = 1; /* App. B.6: reduceRPY reads past a slice this short */
+        }
+        __syncthreads();
+        if (tid == 0) s_run = run + tot;
+        __syncthreads();
+    }
+    const int W = s_run;
+    if (tid == 0) s_off[nk] = W;
+    __syncthreads();
+    if (W > A.W_cap) { if (bx == 0 && tid == 0) { set_err(m, DERR_CAPACITY, -1); m->W = 0; } return; }
+    if (bx == 0) { /* TailIndex.push_back(WayPointsList.size() - 1), the offsets, W: for the host and for the in-order finish */
+        for (int k2 = tid; k2 < nk; k2 += blockDim.x) {
+            A.wp_off[k2] = s_off[k2]; A.tail[k2] = s_off[k2 + 1] - 1;
+            const int s2 = k2 + A.first_kept;
+            if (s2 < A.sb || s2 >= A.se) A.wp_cnt[k2] = 0; /* another handle's slice */
+        }
+        if (tid == 0) { A.wp_off[nk] = W; m->W = W; m->any_short = s_short; m->sweeps = 0; m->smooth_done = 0; }
+    }
+    const int ntiles = smooth_tiles(W);
+    const int tile = bx;
+    if (W == 0 || tile >= ntiles) return;
+    /* list index -> slot of the per-slice layout */
+    auto slice_of = [&](int g) { int lo = 0, hi = nk - 1; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= g) lo = mid; else hi = mid - 1; } return lo; };
+    auto row_of = [&](int g) { const int kk = slice_of(g); return (size_t)kk * A.stride + (size_t)(g - s_off[kk]); };
+    const double wd = 0.65, ws = 1 - wd, dg = wd + 2 * ws;
+    const double r = (dg - sqrt(dg * dg - 4 * ws * ws)) / (2 * ws), c = wd / (dg - 2 * ws * r);
+    const int t0 = tile * SMF_T;
+    const int base = t0 - SMF_K;
+    const bool solve = A.finish && P.smooth && W > 2;
+    if (A.finish) {
+        for (int l = tid; l < SMF_M; l += blockDim.x) {
+            const int g = base + l;
+            const bool src = g >= 1 && g <= W - 2;
+            size_t row = 0;
+            if (src) row = row_of(g);
+            for (int j = 0; j < 3; ++j) s_x[j][l] = src ? A.wps_pre[6 * row + j] : 0.f;
+        }
+    }
+    const bool in_order = A.finish && P.rpy_resolution > 2 && s_short;
+    const bool copy2 = A.finish && A.out2 != nullptr && W <= A.out2_cap;
+    if (A.finish && A.out2 != nullptr && W > A.out2_cap && tile == 0 && tid == 0) set_err(m, DERR_CAPACITY, -1);
+    const bool near_end = solve && (t0 < SMF_END || t0 + SMF_T - 1 > W - 1 - SMF_END);
+    if (near_end) {
+        if (tid < SMF_END) s_rp[tid] = smooth_rpow(r, tid);
+        const int j = tid >> 6, lane = tid & 63;
+        if (j < 3) {
+            const int kq = (lane & 31) + 1;
+            const int gq = lane < 32 ? kq : W - 1 - kq;
+            double v = (gq >= 1 && gq <= W - 2) ? (double)A.wps_pre[6 * row_of(gq) + j] * smooth_rpow(r, kq) : 0.0;
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((lane & 31) == 0) s_e[lane >> 5][j] = (double)A.wps_pre[6 * row_of(lane < 32 ? 0 : W - 1) + j] - c * v;
+        }
+    }
+    __syncthreads();
+    const int g = t0 + tid;
+    if (g < W) {
+        const int kk = slice_of(g);
+        const size_t rowbase = (size_t)kk * A.stride - (size_t)s_off[kk]; /* row of list index w of this slice = rowbase + w */
+        float p[6];
+        for (int d = 0; d < 6; ++d) p[d] = A.wps_pre[6 * (rowbase + g) + d];
+        for (int d = 0; d < 6; ++d) A.wp_pre[6 * (size_t)g + d] = p[d]; /* the compact list after HandEyeTransform */
+        if (A.finish) {
+            if (solve) {
+                const int l = g - base;
+                double y[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double acc = (double)s_x[j][l - SMF_K] + (double)s_x[j][l + SMF_K];
+#pragma unroll 8
+                    for (int q = SMF_K - 1; q >= 1; --q) acc = ((double)s_x[j][l - q] + (double)s_x[j][l + q]) + r * acc;
+                    y[j] = c * ((double)s_x[j][l] + r * acc);
+                }
+                if (near_end) {
+                    const double D = W - 1 < SMF_END ? s_rp[W - 1] : 0.0;
+                    const double r0 = g < SMF_END ? s_rp[g] : 0.0, r1 = W - 1 - g < SMF_END ? s_rp[W - 1 - g] : 0.0;
+                    const double det = 1.0 - D * D;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double e0 = s_e[0][j], e1 = s_e[1][j];
+                        const double Aa = (e0 - D * e1) / det, Bb = (e1 - D * e0) / det;
+                        y[j] = y[j] + (Aa * r0 + Bb * r1);
+                    }
+                }
+                if (g >= 1 && g <= W - 2) { p[0] = (float)y[0]; p[1] = (float)y[1]; p[2] = (float)y[2]; }
+            }
+            for (int d = 0; d < 6; ++d) A.wp_smooth[6 * (size_t)g + d] = p[d];
+            if (!in_order) {
+                /* reduceRPY for one waypoint (see finish_one_waypoint): the slice of g is known, no search over TailIndex */
+                if (P.rpy_resolution > 2) {
+                    const int res = res_i;
+                    const int p0 = s_off[kk], tl = s_off[kk + 1] - 1;
+                    const int nfull = (tl - p0) / res;
+                    const int lastkey = p0 + nfull * res;
+                    const int rr = g - p0;
+                    const float *src = A.wps_pre + 6 * rowbase;
+                    if (g > lastkey) {
+                        for (int D = 3; D < 6; ++D) p[D] = src[6 * (size_t)lastkey + D];
+                    } else if (rr % res != 0) {
+                        const int pre = p0 + (rr / res) * res, last = pre + res, wi = g - pre;
+                        for (int D = 3; D < 6; D++) {
+                            const float a = src[6 * (size_t)last + D], bb = src[6 * (size_t)pre + D];
+                            double dr;
+                            if (a * bb >= 0) {
+                                dr = (double)((a - bb) / res);
+                            } else {
+                                double no1, no2;
+                                if (a < 0) { no2 = bb; no1 = 2 * M_PI + a; }
+                                else { no2 = 2 * M_PI + bb; no1 = a; }
+                                dr = (double)fabsf(a - bb) < fabs(no1 - no2) ? (double)(a - bb) : (no1 - no2);
+                                dr /= res;
+                            }
+                            float v = bb;
+                            for (int q = 1; q <= wi; ++q) v = (float)(dr + v); /* the reference accumulates in float */
+                            p[D] = v;
+                        }
+                    }
+                    for (int D = 3; D < 6; ++D) p[D] = (double)p[D] > M_PI ? (float)((double)p[D] - 2 * M_PI) : p[D];
+                }
+                float R[3][3];
+                rot_zyx(p[3], p[4], p[5], R);
+                const float ee[3] = {0.f, 0.f, -P.ee_length};
+                float t[3];
+                for (int i = 0; i < 3; ++i) t[i] = R[i][0] * ee[0] + R[i][1] * ee[1] + R[i][2] * ee[2] + p[i] * 1.f;
+                p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+            }
+            for (int d = 0; d < 6; ++d) A.wp_out[6 * (size_t)g + d] = p[d];
+            if (copy2 && !in_order) for (int d = 0; d < 6; ++d) A.out2[6 * (size_t)g + d] = p[d];
+        }
+    }
+    if (in_order) { /* App. B.6: a slice shorter than RPYres + 1 -- the last tile to arrive finishes the whole list in order */
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&m->emit_ticket, 1) == ntiles - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (tid == 0) { finish_list_in_order(m, P, A.tail, A.wp_out); m->emit_ticket = 0; }
+            __threadfence();
+            __syncthreads();
+            if (copy2) for (size_t i = tid; i < 6 * (size_t)W; i += blockDim.x) A.out2[i] = A.wp_out[i];
+        }
+    }
+}
+
+/* the per-waypoint stage lists (sampled point, nearest cloud index, normal) from the per-slice slots into list order: only
+   when a caller asks for them (ppp_get_stage) */
+__global__ void __launch_bounds__(256) k_win_gather_stage(WinArgs A, float4 *wp_xyz, int *wp_nn, float4 *wp_normal)
+{
+    const int k = blockIdx.x;
+    if (k >= A.nkept) return;
+    const int s = k + A.first_kept;
+    if (s < A.sb || s >= A.se) return;
+    const int off = A.wp_off[k], cnt = A.wp_cnt[k];
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        const size_t slot = (size_t)k * A.stride + t;
+        wp_xyz[off + t] = A.wps_xyz[slot];
+        wp_nn[off + t] = A.wps_nn[slot];
+        wp_normal[off + t] = A.wps_normal[slot];
+    }
+}
+
+/* ---- launch forms: single (arguments by value) and batched (blockIdx.y = member of the batch) ---- */
+template <int PPT>
+__global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A) { win_scatter_body<PPT>(A, blockIdx.x); }
+template <int PPT>
+__global__ void __launch_bounds__(WSC_T) k_win_scatter_b(const WinArgs *__restrict__ mem)
+{
+    const WinArgs &A = mem[blockIdx.y];
+    if ((int)blockIdx.x >= A.g_scatter) return;
+    win_scatter_body<PPT>(A, blockIdx.x);
+}
+template <int TMAX>
+__global__ void __launch_bounds__(TMAX) k_win_slice(WinArgs A)
+{
+    if ((int)blockIdx.x == A.g_slice) { win_verify_body(A); return; }
+    win_slice_body<TMAX>(A, blockIdx.x);
+}
+template <int TMAX>
+__global__ void __launch_bounds__(TMAX) k_win_slice_b(const WinArgs *__restrict__ mem)
+{
+    const WinArgs &A = mem[blockIdx.y];
+    if ((int)blockIdx.x > A.g_slice) return;
+    if ((int)blockIdx.x == A.g_slice) { win_verify_body(A); return; }
+    win_slice_body<TMAX>(A, blockIdx.x);
+}
+__global__ void __launch_bounds__(SMF_T) k_win_finish(WinArgs A) { win_finish_body(A, blockIdx.x); }
+__global__ void __launch_bounds__(SMF_T) k_win_finish_b(const WinArgs *__restrict__ mem)
+{
+    const WinArgs &A = mem[blockIdx.y];
+    if ((int)blockIdx.x >= A.g_finish) return;
+    win_finish_body(A, blockIdx.x);
+}
+/* the members' meta blocks side by side, so that ONE copy publishes the batch to the host */
+__global__ void __launch_bounds__(64) k_collect_meta_win(const WinArgs *__restrict__ mem, int count, DevMeta *out)
+{
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int *src = (const int *)mem[i].m;
+    int *dst = (int *)(out + i);
+    for (int q = threadIdx.x; q < (int)(sizeof(DevMeta) / sizeof(int)); q += blockDim.x) dst[q] = src[q];
+}

@@ -79,6 +79,7 @@ EXPORTS = [
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
+    "ppp_set_fast_path", "ppp_get_fast_path",
 ]
 
 
@@ -169,6 +170,8 @@ def lib():
         L.ppp_spline_eval.argtypes = [vp, dp, sz, dp]
         L.ppp_spline_range.argtypes = [vp, dp, dp, szp]
         L.ppp_spline_destroy.argtypes = [vp]
+        L.ppp_set_fast_path.argtypes = [vp, C.c_int]
+        L.ppp_get_fast_path.argtypes = [vp, ip]
         _lib = L
     return _lib
 
@@ -311,7 +314,7 @@ class Spline:
 class Engine:
     """One planner handle on one MI355X (one HIP stream, one resident cloud)."""
 
-    def __init__(self, device=0, params=None, **kw):
+    def __init__(self, device=0, params=None, fast_path=True, **kw):
         self.L = lib()
         self.h = C.c_void_p()
         rc = self.L.ppp_create(int(device), C.byref(self.h))
@@ -320,6 +323,18 @@ class Engine:
             raise PPPError(rc, "ppp_create failed (no gfx950 device? there is no CPU fallback)")
         self.params = params if params is not None else default_params(**kw)
         self._chk(self.L.ppp_set_params(self.h, C.byref(self.params)))
+        if not fast_path:
+            self.set_fast_path(False)
+
+    def set_fast_path(self, on=True):
+        """ppp_set_fast_path: False keeps this handle on the slab-index launch sequence (the window path is the default where it applies)."""
+        self._chk(self.L.ppp_set_fast_path(self.h, 1 if on else 0))
+
+    def fast_path(self):
+        """True when the current plan runs the window path (three launches), False for the slab-index path."""
+        a = C.c_int()
+        self._chk(self.L.ppp_get_fast_path(self.h, C.byref(a)))
+        return bool(a.value)
 
     def _chk(self, rc):
         if rc:

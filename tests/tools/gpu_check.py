@@ -17,7 +17,7 @@ def check(name, pairing=0, walk=1, verbose=True):
     e.enable_timing(True)
     t0 = time.time(); e.gen_path_async(); e.get_path_async(); e.sync(); t_gpu = time.time() - t0
     S = e.num_slices(); W = e.num_waypoints()
-    print(f"== {name} pairing={pairing} walk={walk}: N={len(pts)} S gpu/oracle {S}/{So}  W {W}/{Wo}  oracle {t_or:.3f}s gpu(first) {t_gpu*1e3:.2f}ms")
+    print(f"== {name} pairing={pairing} walk={walk}: N={len(pts)} S gpu/oracle {S}/{So}  W {W}/{Wo}  oracle {t_or:.3f}s gpu(first) {t_gpu*1e3:.2f}ms  path: {'window' if e.fast_path() else 'slab index'}")
     ok = (S == So) and (W == Wo)
     mn, mx = e.minmax(); omn, omx = o.minmax()
     ok &= np.array_equal(mn, omn) and np.array_equal(mx, omx)
