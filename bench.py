@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=None,
                     help="also report the step time over K distinct resident clouds planned round-robin (K x working set beyond "
                          "the 256 MiB Infinity Cache) and the cold time of a never-seen cloud; 0 = off, the default run uses 8")
+    ap.add_argument("--no-dynamic", action="store_true", help="skip the Dynamic_adjustment = true measurement that the default one-GPU run reports beside the headline")
     ap.add_argument("--dynamic", action="store_true",
                     help="plan with Dynamic_adjustment = true (the reference's config.txt default; SURVEY.md 8f rank 1): the same "
                          "workload through the slice-to-slice chains -- a measurement beside the headline, not the headline")
@@ -76,6 +77,12 @@ def main():
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything touches the GPU (a
     # process that has initialised HIP must never exec or fork GPU children), relay rank 0's JSON line and exit code.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # ... and never from under a profiler: its preloaded library has initialised the GPU in THIS process already, so starting
+        # the launcher from here would be exactly the hop this pool forbids (profile the one-rank rehearsal instead)
+        preload = os.environ.get("LD_PRELOAD", "")
+        if "rocprof" in preload or any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in os.environ):
+            raise SystemExit("bench.py --gpus %d under a profiler: start the ranks with torch.distributed.run yourself, or profile "
+                             "the single-rank rehearsal (PPP_BENCH_FORCE_DIST=1 --gpus 1)" % args.gpus)
         import socket
         import subprocess
         with socket.socket() as sk:
@@ -196,6 +203,29 @@ def main():
     w_total = float(ww.item())
     value = w_total * args.steps / elapsed
 
+    # ---- N > 1: how many ranks took part (as torch.distributed and as the RCCL communicator itself see it), every rank's
+    # waypoint count, and what the gather alone costs per step (untimed, after the timed region) ----
+    multi = None
+    if world > 1 or force_dist:
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # every rank of the communicator adds one
+        wl = torch.zeros(max(world, 1), dtype=torch.float64, device=dev)
+        wl[rank] = float(w_local)
+        dist.all_reduce(wl, op=dist.ReduceOp.SUM)
+        reps = max(5, min(args.steps, 20))
+        torch.cuda.synchronize(); dist.barrier()
+        tg0 = time.perf_counter()
+        for _ in range(reps):
+            gatherers[0].gather()
+        torch.cuda.synchronize(); dist.barrier()
+        tg = torch.tensor([(time.perf_counter() - tg0) / reps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        multi = {"n_ranks_seen": {"torch_distributed_world_size": int(dist.get_world_size()), "rccl_allreduce_of_ones": int(round(float(ones.item())))},
+                 "waypoints_per_rank": [int(round(float(x))) for x in wl.cpu().tolist()],
+                 "gather_ms_per_step_alone": float(tg.item()),
+                 "note": "gather_ms_per_step_alone: the collective back to back with a host wait around the loop; inside the timed loop it "
+                         "overlaps the next step's planning"}
+
     out = None
     if rank == 0:
         # ---- the last step's assembled robot path (untimed check): rank 0's own block is its engine's list, every
@@ -210,13 +240,10 @@ def main():
         eng.enable_timing(True)
         acc, launches = {}, {}
         for _ in range(args.profile_passes):
-            if args.batch > 1:      # the batched launches (one per stage over all members), eagerly, events on the lead's stream
-                engine.run_batch_async(engines, gatherers[0].send.data_ptr(), offs, w_all)
-                engine.sync_batch(engines)
-            else:
-                eng.gen_path_async()
-                eng.get_path_async()
-                eng.sync()
+            # the launches of the timed loop (ppp_run_batch_async: one launch per stage over the step's workpieces), enqueued
+            # directly instead of as a graph replay so that HIP events on the engine's own stream bracket each of them
+            engine.run_batch_async(engines, gatherers[0].send.data_ptr(), offs, w_all)
+            engine.sync_batch(engines)
             kt, kl = eng.kernel_times(with_launches=True)
             for k, v in kt.items():
                 acc.setdefault(k, []).append(v)
@@ -229,7 +256,8 @@ def main():
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
         workload_key = args.config + ("_b%d" % args.batch if args.batch > 1 else "") + ("_dyn" if args.dynamic else "")
         traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), workload_key)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": dom, "launch_path": "window (3 launches)" if eng.fast_path() else "slab index (6 launches)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_pass": launches.get(dom, 1),
@@ -291,6 +319,12 @@ def main():
             else:
                 err = {"waypoints_equal": False, "gpu": int(gw.shape[0]), "oracle": int(ow.shape[0])}
 
+        # ---- the reference's DEFAULT mode (config.txt:13 Dynamic_adjustment = true) on the same cloud: a second line of the
+        # record, not the headline (the slice-to-slice chains are a launch chain) ----
+        dynamic = None
+        if world == 1 and args.batch == 1 and not args.dynamic and not args.no_dynamic:
+            dynamic = measure_dynamic(args, engine, cfg, pts, local_rank, None if args.no_cpu_baseline else "oracle")
+
         out = {
             "metric": "polishing waypoints/sec for 1M-pt cloud, 256 slices; path L2 err vs ref",
             "value": value, "unit": "waypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -306,6 +340,8 @@ def main():
             "path_l2_err": err,
             "assembled_path": assembled,
             "latency": latency,
+            "dynamic": dynamic,
+            "multi_gpu": multi,
             "exchange": ("torch.distributed gather to rank 0 over RCCL (direct send/recv of padded blocks), asynchronous behind each "
                          "step in the planner's stream order" if gatherers[0].dist else None),
         }
@@ -313,6 +349,41 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def measure_dynamic(args, engine, cfg, pts, local_rank, check):
+    """The same cloud planned with Dynamic_adjustment = true (path_dynamic_alg.cpp:183-334): ms per step as a hipGraph replay,
+    waypoints/s, and the path error against the oracle's own dynamic adjustment (the oracle with its kd index: a check, not a
+    timed baseline)."""
+    e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], dynamic_adjustment=1)
+    e.set_cloud(pts)
+    e.gen_path()
+    W = e.get_path()
+    steps = max(3, min(args.steps, 10))
+    for _ in range(2):
+        e.run_async()
+    e.sync()
+    t = time.perf_counter()
+    for _ in range(steps):
+        e.run_async()
+    e.sync()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    out = {"ms_per_step": ms, "waypoints_per_s": W / (ms * 1e-3), "waypoints": int(W), "steps": steps,
+           "note": "Dynamic_adjustment = true (the reference's config.txt default): slice s is re-fitted against the boundary of slice s-1, "
+                   "so the slices form a chain of dependent launches"}
+    if check == "oracle":
+        from oracle import ppo
+        o = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], dynamic_adjustment=1)
+        o.gen_path()
+        o.get_path()
+        gw, ow = e.waypoints(), o.waypoints()
+        if gw.shape == ow.shape and len(gw):
+            d = np.linalg.norm(gw[:, :3] - ow[:, :3], axis=1)
+            out["path_l2_err"] = {"max_m": float(d.max()), "rms_m": float(np.sqrt((d ** 2).mean())), "waypoints_equal": True}
+        else:
+            out["path_l2_err"] = {"waypoints_equal": False, "gpu": int(gw.shape[0]), "oracle": int(ow.shape[0])}
+    e.close()
     return out
 
 
@@ -377,7 +448,7 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
     # the share of the file each of them read (here: a contiguous 1/N of the point array), in the planner's units (x 1000 in float)
     n_all = int(pts.shape[0])
     share = (pts[rank * n_all // world:(rank + 1) * n_all // world] * np.float32(1000)).astype(np.float32)
-    fin = np.isfinite(share).all(axis=1)
+    fin = np.isfinite(share).all(axis=1)   # the engine's own count: ingest turns a point with ANY non-finite coordinate into NaN NaN NaN and bounds / counts skip those
     t_mn = torch.from_numpy(share[fin].min(axis=0) if fin.any() else np.full(3, np.inf, np.float32)).to(dev)
     t_mx = torch.from_numpy(share[fin].max(axis=0) if fin.any() else np.full(3, -np.inf, np.float32)).to(dev)
     t_n = torch.tensor([int(fin.sum())], dtype=torch.int64, device=dev)
@@ -473,6 +544,8 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0 and not out["assembled_path"]["sharded_list_equals_unsharded_handle"]:
+        raise SystemExit("bench.py --mode slices: the list assembled from the slice ranges differs from the unsharded handle's")
     return out
 
 

@@ -193,6 +193,30 @@ __device__ inline int block_exscan(int v, int *scratch, int *total)
     return pre;
 }
 
+/* The same scan with two barriers and no serial part: every wave adds up the waves' totals for itself (a shuffle scan over
+   at most 16 values) instead of waiting for thread 0 to walk them.  scratch: >= 16 ints of LDS. */
+__device__ inline int block_exscan_w(int v, int *scratch, int *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wid] = inc;
+    __syncthreads();
+    const int part = lane < nw ? scratch[lane] : 0;
+    int incw = part;
+    for (int o = 1; o < 16; o <<= 1) {
+        int t = __shfl_up(incw, o, 64);
+        if (lane >= o) incw += t;
+    }
+    const int wave_off = __shfl(incw - part, wid, 64);
+    *total = __shfl(incw, nw - 1, 64);
+    return wave_off + inc - v;
+}
+
 /* ---------------------------------------------------------------------- */
 /* Block sort of 256*E 64-bit keys held in registers (blocked layout: thread */
 /* t owns elements t*E .. t*E+E-1), ascending, for a 256-thread workgroup.   */

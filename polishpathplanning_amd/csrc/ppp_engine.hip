@@ -150,7 +150,7 @@ struct ppp_handle_s {
     bool stage_compact = true;  /* wp_xyz / wp_nn / wp_normal hold the list order (a window pass leaves them in per-slice slots) */
     float win_pad = 4.f;
     int win_capw = 0, win_cap_el = 0, win_NB = 0, win_NBc = 0, win_stride = 1, win_threads = 256, win_ppt = 4, win_gs = 1;
-    int win_nkept = 0, win_first_kept = 0;
+    int win_nkept = 0, win_first_kept = 0, win_el_expect = 0;
     float win_px0 = 0.f;
     DevBuf<float> win_px;
     DevBuf<int> win_cnt;
@@ -399,6 +399,34 @@ int enqueue_normals(ppp_handle h)
     return PPP_OK;
 }
 
+/* Threads of a slice workgroup for a launch of `wgs` of them.  The kernel holds 116 VGPRs, i.e. 16 waves per CU.  While a
+   launch has fewer workgroups than the device has room for, a workgroup is as wide as its work can use (a left point per
+   thread in the pairing, 4 .. 8 lanes per waypoint in the pose stage): the launch ends with its slowest workgroup.  A launch
+   of several rounds of workgroups (batches, cfg 5) is about throughput: as many workgroups per CU as the LDS allows, the 16
+   waves shared between them (measured, 64 x 250 k points: 256 threads 0.42 ms, 320 .. 512 threads 0.58 .. 0.64 ms). */
+int win_pick_threads(const ppp_handle h, long long wgs)
+{
+    const int capw = h->win_capw, cap_el = h->win_cap_el;
+    int tmin = std::max(128, 64 * ((capw + 64 * WIN_EMAX - 1) / (64 * WIN_EMAX)));
+    tmin = std::max(tmin, 64 * ((cap_el + 64 * 4 - 1) / (64 * 4)));
+    if (tmin > 1024) return 0;
+    const int wide = std::min(1024, std::max(256, 64 * (int)std::ceil(std::max(1.05 * (double)h->win_el_expect, 4.0 * (double)h->cnt_est) / 64.0)));
+    const size_t lds = std::max(win_slice_lds_bytes(capw, cap_el, h->win_NB), sizeof(float) * ((size_t)h->S_cap + 2048) + 64) + 1024;
+    const int by_lds = (int)std::max<size_t>(1, (size_t)h->max_lds / lds);
+    const long long per_cu = (wgs + h->num_cus - 1) / std::max(1, h->num_cus);
+    int T = wide;
+    if (per_cu > 1) { /* several workgroups per CU, at once or one after the other */
+        const int conc = (int)std::min<long long>(by_lds, per_cu);
+        T = std::min(wide, 64 * std::max(1, 16 / conc));
+    }
+    T = std::max(T, tmin);
+    if (const char *ev = getenv("PPP_WIN_T")) { /* tuning runs only */
+        const int tv = atoi(ev);
+        if (tv >= tmin && tv <= 1024 && tv % 64 == 0) T = tv;
+    }
+    return T;
+}
+
 /* The window path (ppp_window.h) for this plan, when it applies: kd pairing without dynamic adjustment or alignment, windows
    [Px - pad, Px + pad] that do not overlap (tool steps of about 2 pad + 2 mm and more) and that fit a workgroup's LDS.  Everything
    else -- and every pass the window path hands back -- runs on the slab index.  Sizes come from the cached bounds, as the slab
@@ -418,53 +446,52 @@ int plan_window(ppp_handle h, int S, double per)
     const float pad = (float)std::max(3.0, (double)h->P.normal_radius + std::max(1.5, spacing));
     std::vector<float> px((size_t)S);
     ppp_slice_walk(h->P.walk, h->h_mn[0], h->h_mx[0], h->P.tool_radius, px.data(), S);
-    double el_w = 0.0; /* widest left side of a band: bhi - Px */
     for (int s = 0; s < S; ++s) {
         if (!(std::fabs((double)px[s]) < 1.0e7)) return PPP_OK;
         if (s + 1 < S && !((double)px[s + 1] - (double)px[s] > 2.0 * pad + 1.0e-2)) return PPP_OK; /* windows would overlap */
-        const double bhi = (double)(float)(2 + (int)px[s]), blo = (double)(float)(-2 + (int)px[s]);
-        el_w = std::max(el_w, std::max(bhi - (double)px[s], (double)px[s] - blo));
     }
-    const double expect = rx > 2.0 * pad ? (double)h->h_nvalid * 2.0 * pad / rx : (double)h->h_nvalid;
-    const double el_expect = expect * el_w / (2.0 * pad);
+    /* exact populations of the windows of this handle's slices and of their band sides: one pass over the x coordinates at plan time */
+    const int n_src = h->use_part ? h->n_part : (int)h->n;
+    HIPCHK(h, h->win_px.ensure((size_t)S)); HIPCHK(h, h->win_cnt.ensure(std::max<size_t>(3, WIN_CNT_STRIDE) * (size_t)S));
+    HIPCHK(h, hipMemcpyAsync(h->win_px.p, px.data(), sizeof(float) * (size_t)S, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * 3 * (size_t)S, h->stream));
+    std::vector<int> census(3 * (size_t)S, 0);
+    if (n_src > 0) {
+        LAUNCH(h, "k_win_census", k_win_census, std::max(1, std::min((n_src + 255) / 256, 4096)), 256, 0, h->use_part ? h->Xp.p : h->X.p, n_src, h->win_px.p, S,
+               px[0], 1.0f / (float)step, pad, h->win_cnt.p, h->win_cnt.p + S, h->win_cnt.p + 2 * (size_t)S);
+        HIPCHK(h, hipMemcpyAsync(census.data(), h->win_cnt.p, sizeof(int) * 3 * (size_t)S, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int max_w = 0, max_el = 0;
+    for (int s2 = h->sb; s2 < h->se; ++s2) { max_w = std::max(max_w, census[s2]); max_el = std::max(max_el, census[(size_t)S + s2]); }
+    const double expect = std::max(1, max_w);
     int NBc = 16;
     while (NBc < expect / 10.0 && NBc < 4096) NBc <<= 1;
-    /* capacities: 10 % and a few dozen points over the mean where LDS allows, never less than 3 % */
+    /* capacities = this cloud's own maxima (rounded up to 64 points); what gives way under LDS pressure is the bucket table */
     const size_t budget = (size_t)h->max_lds - 2048;
-    int capw = 0, cap_el = 0;
-    for (double f = 1.0; f >= 0.0; f -= 0.125) {
-        const double mw = 1.03 + 0.07 * f, aw = 32 + 160 * f;
-        capw = 64 * (int)std::ceil((mw * expect + aw) / 64.0);
-        cap_el = 64 * (int)std::ceil((mw * el_expect + aw / 2) / 64.0);
-        while (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget && NBc > 64 && f < 0.5) NBc >>= 1;
-        if (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) <= budget) break;
-        capw = 0;
-    }
+    int capw = 64 * ((max_w + 63) / 64 + 0), cap_el = 64 * ((max_el + 63) / 64);
+    capw = std::max(capw, 64); cap_el = std::max(cap_el, 64);
+    while (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget && NBc > 32) NBc >>= 1;
+    if (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget) capw = 0;
     if (!capw) return PPP_OK; /* the windows of this cloud do not fit a workgroup's LDS */
     const int NB = WIN_CLASSES * NBc;
-    /* threads of a slice workgroup: a left point per thread in the pairing, four lanes per waypoint in the pose stage */
-    int T = 64 * (int)std::ceil(std::max(1.05 * el_expect, 4.0 * (double)h->cnt_est) / 64.0);
-    T = std::max(T, 64 * ((capw + 64 * WIN_EMAX - 1) / (64 * WIN_EMAX)));
-    T = std::max(T, 64 * ((cap_el + 64 * 4 - 1) / (64 * 4)));
-    T = std::max(256, T);
-    if (T > 1024) {
-        T = 1024;
-        if (capw > WIN_EMAX * T || cap_el > 4 * T) return PPP_OK;
-    }
-    const int n_src = h->use_part ? h->n_part : (int)h->n;
+    h->win_el_expect = max_el;
+    h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB;
+    int T = win_pick_threads(h, std::max(1, h->se - h->sb));
+    if (!T) return PPP_OK;
     h->win_ppt = n_src > PPP_PPT16_FROM ? 16 : (n_src > PPP_PPT8_FROM ? 8 : 4);
+    if (const char *ev = getenv("PPP_WIN_PPT")) { const int pv = atoi(ev); if (pv == 4 || pv == 8 || pv == 16) h->win_ppt = pv; }
     h->win_gs = std::max(1, (n_src + h->win_ppt * WSC_T - 1) / (h->win_ppt * WSC_T));
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
     h->win_first_kept = h->P.drop_ends ? 1 : 0;
     h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
     h->win_px0 = px[0];
-    HIPCHK(h, h->win_px.ensure((size_t)S)); HIPCHK(h, h->win_cnt.ensure((size_t)S)); HIPCHK(h, h->win_part.ensure((size_t)h->win_gs));
+    HIPCHK(h, h->win_part.ensure((size_t)h->win_gs));
     HIPCHK(h, h->win_pts.ensure((size_t)S * (size_t)capw));
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
     HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
-    HIPCHK(h, hipMemcpyAsync(h->win_px.p, px.data(), sizeof(float) * (size_t)S, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S, h->stream)); /* every pass leaves the counts cleared again */
+    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * WIN_CNT_STRIDE, h->stream)); /* the passes' counters (a line each): every pass leaves them cleared again */
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->win_path = true;
     return PPP_OK;
@@ -1829,6 +1856,7 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
     std::vector<WinArgs> mem(count);
     bg->win_ppt = 4; bg->win_threads = 256; bg->win_lds = 0; bg->win_scat_lds = 0; bg->win_fin_lds = 0;
     bg->gx_scat = 1; bg->gx_slice = 1; bg->gx_wfin = 1;
+    long long slices_total = 0;
     for (size_t i = 0; i < count; ++i) bg->win_ppt = std::max(bg->win_ppt, bg->hs[i]->win_ppt);
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = bg->hs[i];
@@ -1838,11 +1866,18 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
         A = win_args(h);
         h->out2 = nullptr; h->out2_cap = 0;
         A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (<= the member's own: its partials fit) */
-        bg->win_threads = std::max(bg->win_threads, h->win_threads);
+        slices_total += A.g_slice;
         bg->win_lds = std::max(bg->win_lds, win_slice_lds(h));
         bg->win_scat_lds = std::max(bg->win_scat_lds, 8 * (size_t)A.S);
         bg->win_fin_lds = std::max(bg->win_fin_lds, sizeof(int) * ((size_t)A.nkept + 2));
         bg->gx_scat = std::max(bg->gx_scat, A.g_scatter); bg->gx_slice = std::max(bg->gx_slice, A.g_slice + 1); bg->gx_wfin = std::max(bg->gx_wfin, A.g_finish);
+    }
+    /* one thread count for the launch: what the widest member needs, for the launch's total of slice workgroups */
+    bg->win_threads = 128;
+    for (size_t i = 0; i < count; ++i) {
+        const int t = win_pick_threads(bg->hs[i], slices_total);
+        if (!t) return fail(lead, PPP_ERR_CAPACITY, "window path: a member's windows do not fit a workgroup");
+        bg->win_threads = std::max(bg->win_threads, t);
     }
     HIPCHK(lead, copy_sync(lead, bg->wmembers.p, mem.data(), sizeof(WinArgs) * count, hipMemcpyHostToDevice));
     return PPP_OK;

@@ -33,6 +33,13 @@ enum { WIN_FLAG_OVERFLOW = 1,  /* a window or its left side holds more points th
 __device__ inline void win_flag(DevMeta *m, int why) { atomicOr(&m->win_flag, why); }
 
 #define WIN_CLASSES 5
+#ifndef WIN_CNT_STRIDE
+#define WIN_CNT_STRIDE 1 /* ints between two windows' counters (a 128-byte line each, stride 32, changed nothing: 10 M points / 1024
+                            windows 98 .. 107 us packed, 116 padded -- the scatter's bill is its 16-byte stores, not the atomics) */
+#endif
+#ifndef WIN_POSE_LANES
+#define WIN_POSE_LANES 4
+#endif
 #define WIN_EMAX 8 /* staged points per thread at most (capw <= WIN_EMAX * blockDim) */
 
 struct WinArgs {
@@ -124,7 +131,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
     __syncthreads();
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         const int c = s_cnt[s];
-        if (c) s_cnt[s] = atomicAdd(&A.win_cnt[s], c); /* this workgroup's run inside the window */
+        if (c) s_cnt[s] = atomicAdd(&A.win_cnt[(size_t)s * WIN_CNT_STRIDE], c); /* this workgroup's run inside the window */
     }
     __syncthreads();
 #pragma unroll
@@ -161,7 +168,7 @@ struct WinView {
     const int *tab; /* tab[b] = end of bucket b */
     int NBc;
     float y0, yscale;
-    int cs[WIN_CLASSES + 1]; /* class c = pts[cs[c], cs[c + 1]) */
+    const int *cs; /* LDS: class c = pts[cs[c], cs[c + 1]) (a private array indexed by a run-time class would live in scratch memory) */
     __device__ inline int ybucket(float y) const
     {
         int q = (int)((y - y0) * yscale);
@@ -173,7 +180,8 @@ struct WinView {
     {
         const int b = c * NBc + ybucket(qy);
         int lo = b ? tab[b - 1] : 0;
-        const int hi = tab[b];
+        int hi = tab[b];
+        while (hi - lo > 4) { const int mid = (lo + hi) >> 1; if (pts[mid].y < qy) lo = mid + 1; else hi = mid; } /* (dense windows: buckets of a dozen points) */
         while (lo < hi && pts[lo].y < qy) ++lo;
         return lo;
     }
@@ -223,9 +231,16 @@ __device__ inline int win_nn_class(const WinView &V, int c, const float4 q)
     return bj;
 }
 
-/* units of a waypoint's two searches: (class, direction), inner classes first.  Lane g of the 4 lanes of a waypoint takes
-   unit g of every round; a round's partial results are combined by the same shuffle tree whatever the launch geometry. */
-__device__ __forceinline__ int win_unit_class(int round, int g) { return round == 0 ? (g < 2 ? 1 : 3) : (round == 1 ? (g < 2 ? 0 : 4) : 2); }
+/* Units of a waypoint's two searches: (class, direction) -- the two band sides (up, down), the two outer classes (up, down),
+   the points on the plane.  A waypoint has G = 4 or 8 lanes: with 4 the band sides go first and the outer classes second
+   (the nearest-neighbour search has closed them by their x gap by then, almost always), with 8 -- when the workgroup has the
+   threads to spare -- both at once.  Partial sums are combined by one fixed tree, ((Er_up + Er_down) + (El_up + El_down)) +
+   ((L_up + L_down) + (R_up + R_down)), then + (plane_up + plane_down): the same bits for either G. */
+__device__ __forceinline__ int win_unit_class(int G, int round, int g)
+{
+    if (G == 8) return round == 0 ? (g < 4 ? (g < 2 ? 1 : 3) : (g < 6 ? 0 : 4)) : 2;
+    return round == 0 ? (g < 2 ? 1 : 3) : (round == 1 ? (g < 2 ? 0 : 4) : 2);
+}
 
 #ifndef WSL_T
 #define WSL_T 1024
@@ -264,9 +279,10 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         }
     };
     /* ---- stage the window: points to registers, class + bucket, bucket sort into LDS ---- */
-    const int n = A.win_cnt[s];
+    STAMP_BEGIN();
+    const int n = A.win_cnt[(size_t)s * WIN_CNT_STRIDE];
     __syncthreads(); /* every thread has read the count ... */
-    if (tid == 0) A.win_cnt[s] = 0; /* ... this workgroup is its only reader: cleared for the next pass */
+    if (tid == 0) A.win_cnt[(size_t)s * WIN_CNT_STRIDE] = 0; /* ... this workgroup is its only reader: cleared for the next pass */
     if (n > capw) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
     float4 pr[WIN_EMAX];
     int pb[WIN_EMAX];
@@ -279,6 +295,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     }
     for (int b = tid; b <= NB; b += T) tab[b] = 0;
     __syncthreads();
+    STAMP(6, 0); /* window load issued, table cleared */
 #pragma unroll
     for (int e = 0; e < WIN_EMAX; ++e) {
         const int i = tid + e * T;
@@ -304,37 +321,48 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         int sum = 0;
         for (int q = 0; q < per; ++q) if (b0 + q < NB) sum += tab[b0 + q];
         int total;
-        int pre = block_exscan(sum, s_scr, &total);
+        int pre = block_exscan_w(sum, s_scr, &total);
         for (int q = 0; q < per; ++q) if (b0 + q < NB) { const int c = tab[b0 + q]; tab[b0 + q] = pre; pre += c; }
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) pts[atomicAdd(&tab[pb[e]], 1)] = pr[e];
     __syncthreads();
-    /* tab[b] is now the END of bucket b; every bucket (a handful of points) is finished on (y, cloud index) */
-    for (int b = tid; b < NB; b += T) {
-        const int s0 = b ? tab[b - 1] : 0, e = tab[b];
-        for (int p = s0 + 1; p < e; ++p) {
-            const float4 kp = pts[p];
-            int q = p - 1;
-            while (q >= s0) {
-                const float4 o = pts[q];
-                if (!(kp.y < o.y || (kp.y == o.y && idx_of(kp) < idx_of(o)))) break;
-                pts[q + 1] = o; --q;
+    STAMP(6, 1); /* histogram, scan, placement */
+    /* tab[b] is now the END of bucket b.  Inside a bucket (a point or two, a dozen in the densest windows) the points stand in
+       arrival order: every point counts the members of its bucket that precede it on (y, cloud index) -- independent reads, no
+       chain of dependent moves as in an insertion sort -- and takes that place. */
+#pragma unroll
+    for (int e = 0; e < WIN_EMAX; ++e) {
+        const int b = pb[e];
+        pb[e] = -1;
+        if (b >= 0) {
+            const int s0 = b ? tab[b - 1] : 0, s1 = tab[b];
+            if (s1 - s0 > 1) {
+                const float my = pr[e].y;
+                const int mi = idx_of(pr[e]);
+                int rank = 0;
+                for (int q = s0; q < s1; ++q) {
+                    const float4 o = pts[q];
+                    rank += (o.y < my || (o.y == my && idx_of(o) < mi)) ? 1 : 0;
+                }
+                pb[e] = s0 + rank;
             }
-            pts[q + 1] = kp;
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) pts[pb[e]] = pr[e];
     if (tid <= WIN_CLASSES) s_cs[tid] = 0;
     __syncthreads();
+    STAMP(6, 2); /* buckets finished */
     if (tid < WIN_CLASSES) s_cs[tid + 1] = tab[(tid + 1) * NBc - 1];
     __syncthreads();
     WinView V;
-    V.pts = pts; V.tab = tab; V.NBc = NBc; V.y0 = A.y0; V.yscale = A.yscale;
-#pragma unroll
-    for (int c = 0; c <= WIN_CLASSES; ++c) V.cs[c] = s_cs[c];
-    const int nEr = V.cs[2] - V.cs[1], nEl = V.cs[4] - V.cs[3];
-    if (tid == 0) A.band_cnt[s] = V.cs[4] - V.cs[1]; /* |rangedX_index| */
+    V.pts = pts; V.tab = tab; V.NBc = NBc; V.y0 = A.y0; V.yscale = A.yscale; V.cs = s_cs;
+    const int el0 = s_cs[3];
+    const int nEr = s_cs[2] - s_cs[1], nEl = s_cs[4] - el0;
+    if (tid == 0) A.band_cnt[s] = s_cs[4] - s_cs[1]; /* |rangedX_index| */
     if (nEl == 0 || nEr == 0) { slice_fails(DERR_SLICE); return; }  /* empty map -> < 3 knots; empty FLANN tree */
     if (nEl > cap_el) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
     /* ---- insert_point, kd flavour (path_slicing_alg.cpp:184-233): for every left point the nearest right point, for
@@ -350,7 +378,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         const int i = tid + e * T;
         kb[e] = -1; kr[e] = 0;
         if (i < nEl) {
-            const float4 q = pts[V.cs[3] + i];
+            const float4 q = pts[el0 + i];
             const float4 R = pts[win_nn_class(V, 1, q)];
             const float4 Lp = pts[win_nn_class(V, 3, R)];
             const float t = (Px - R.x) / (Lp.x - R.x);
@@ -366,6 +394,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     /* ---- std::map by y: bucket sort of the candidates (keys made once, kept in registers) ---- */
     for (int b = tid; b <= NBcand; b += T) hc[b] = 0;
     __syncthreads();
+    STAMP(6, 3); /* pairing: two nearest-neighbour queries per left point + lerp */
 #pragma unroll
     for (int e = 0; e < CE; ++e) if (kb[e] >= 0) atomicAdd(&hc[kb[e]], 1);
     __syncthreads();
@@ -375,24 +404,32 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         int sum = 0;
         for (int q = 0; q < per; ++q) if (b0 + q < NBcand) sum += hc[b0 + q];
         int total;
-        int pre = block_exscan(sum, s_scr, &total);
+        int pre = block_exscan_w(sum, s_scr, &total);
         for (int q = 0; q < per; ++q) if (b0 + q < NBcand) { const int c = hc[b0 + q]; hc[b0 + q] = pre; pre += c; }
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < CE; ++e) if (kb[e] >= 0) ckeys[atomicAdd(&hc[kb[e]], 1)] = kr[e];
     __syncthreads();
-    for (int b = tid; b < NBcand; b += T) {
-        const int s0 = b ? hc[b - 1] : 0, e = hc[b];
-        for (int p = s0 + 1; p < e; ++p) {
-            const u64 kp = ckeys[p];
-            int q = p - 1;
-            while (q >= s0 && kp < ckeys[q]) { ckeys[q + 1] = ckeys[q]; --q; }
-            ckeys[q + 1] = kp;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { /* buckets finished by rank, as above (the keys are all different: they carry the candidate's number) */
+        const int b = kb[e];
+        kb[e] = -1;
+        if (b >= 0) {
+            const int s0 = b ? hc[b - 1] : 0, s1 = hc[b];
+            if (s1 - s0 > 1) {
+                int rank = 0;
+                for (int q = s0; q < s1; ++q) rank += ckeys[q] < kr[e] ? 1 : 0;
+                kb[e] = s0 + rank;
+            }
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) ckeys[kb[e]] = kr[e];
     if (tid == 0) s_m = 0;
     __syncthreads();
+    STAMP(6, 4); /* candidate sort */
     /* one knot per distinct y: Node[y] = ... is overwritten by every later writer and El is walked in ascending cloud index,
        so the z kept is the one of the candidate with the highest cloud index inside the run of equal keys.  The knots take
        the place of the sorted keys: everything a chunk needs of them is read before the scan's barriers, written after. */
@@ -405,17 +442,17 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             keep = (j == nEl - 1) || (YK_Y(ckeys[j + 1]) != YK_Y(kj));
             if (keep) {
                 int best_i = YK_POS(kj);
-                int best_idx = idx_of(pts[V.cs[3] + best_i]);
+                int best_idx = idx_of(pts[el0 + best_i]);
                 for (int q = j - 1; q >= 0 && YK_Y(ckeys[q]) == YK_Y(kj); --q) {
                     const int ci = YK_POS(ckeys[q]);
-                    const int id = idx_of(pts[V.cs[3] + ci]);
+                    const int id = idx_of(pts[el0 + ci]);
                     if (id > best_idx) { best_idx = id; best_i = ci; }
                 }
                 ky = ord2f(YK_Y(kj)); kz = cz[best_i];
             }
         }
         int tot;
-        const int pre = block_exscan(keep, s_scr, &tot);
+        const int pre = block_exscan_w(keep, s_scr, &tot);
         const int o = s_m;
         __syncthreads();
         if (keep) knot[o + pre] = make_float2(ky, kz);
@@ -439,6 +476,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     }
     __syncthreads();
     const int nknots = s_nk, cnt = s_cnt;
+    STAMP(6, 5); /* map flattening, knot count, waypoint count */
     for (int i = tid; i < nknots; i += T) {
         const float2 kn = knot[i];
         A.node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
@@ -455,13 +493,17 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     const bool dy_closed_form = sums_exact(ystart, P.path_resolution, (double)cnt);
     float HE[3][3];
     handeye_rotation(P.handeye, HE);
-    const int g = tid & 3, per = T >> 2;
+    /* (8 lanes per waypoint -- both pairs of classes at once -- give the same bits but were slower where tried: 1 M points /
+       256 slices 39.6 us against 35.0 with 4; twice the waves run the double-precision spline and the pose arithmetic) */
+    const int G = WIN_POSE_LANES, gshift = G == 8 ? 3 : 2;
+    const int g = tid & (G - 1), per = T >> gshift;
+    const int plane_round = G == 8 ? 1 : 2; /* the unit round of the on-plane class */
     const int rounds = (cnt + per - 1) / per;
     const int per_round = (cnt + rounds - 1) / rounds; /* the waypoints spread evenly over the rounds */
-    const bool has_plane_class = V.cs[3] > V.cs[2];
+    const bool has_plane_class = s_cs[3] > s_cs[2];
     const float r2 = P.normal_radius * P.normal_radius;
     for (int rd = 0; rd < rounds; ++rd) {
-        const int lt = tid >> 2;
+        const int lt = tid >> gshift;
         const int t = rd * per_round + lt;
         const bool act = lt < per_round && t < cnt;
         double dy = ystart;
@@ -483,16 +525,17 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         const float4 q = make_float4((float)(double)Px, (float)dy, (float)zd, 1.f);
         const bool finite = q.y == q.y && q.z == q.z;
         const bool on = act && finite;
+        STAMP(6, 6); /* knots out, dy, interval, Steffen */
         /* -- kdtree.nearestKSearch(q, 1) (:189): inner classes first, the outer ones are closed by their x gap almost always -- */
         float best = P.nn_hint2;
         int bidx = 0x7fffffff;
         float4 bp = make_float4(NAN, NAN, NAN, 0.f);
         for (int pass = 0; pass < 2; ++pass) {
-            for (int round = 0; round < 3; ++round) {
-                if (round == 2 && !has_plane_class) break;
-                const int c = win_unit_class(round, g);
+            for (int round = 0; round <= plane_round; ++round) {
+                if (round == plane_round && !has_plane_class) break;
+                const int c = win_unit_class(G, round, g);
                 const bool up = (g & 1) == 0;
-                const bool mine = on && !(round == 2 && g >= 2);
+                const bool mine = on && !(round == plane_round && g >= 2);
                 if (mine) {
                     /* every point of class 0 lies left of the band, of class 4 right of it */
                     const float gap = c == 0 ? q.x - blo : (c == 4 ? bhi - q.x : 0.f);
@@ -508,7 +551,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
                         });
                     }
                 }
-                for (int o = 2; o > 0; o >>= 1) { /* minimum of the four lanes on (distance, cloud index) */
+                for (int o = G >> 1; o > 0; o >>= 1) { /* minimum of the waypoint's lanes on (distance, cloud index) */
                     const float od = __shfl_xor(best, o, 64);
                     const int oi = __shfl_xor(bidx, o, 64);
                     const float ox = __shfl_xor(bp.x, o, 64), oy = __shfl_xor(bp.y, o, 64), oz = __shfl_xor(bp.z, o, 64), ow = __shfl_xor(bp.w, o, 64);
@@ -519,6 +562,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             best = INFINITY; /* nothing within the hint: the same search without a bound */
         }
         const bool found = on && bidx != 0x7fffffff;
+        STAMP(6, 7); /* nearest point */
         /* the window holds every point within `pad` of the plane: the answers are the whole cloud's as long as the ball that
            proves the nearest neighbour and the normal's radius search stay inside it */
         if (on && g == 0) {
@@ -533,13 +577,13 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int count = 0;
         const float4 c0 = bp;
-        for (int round = 0; round < 3; ++round) {
-            if (round == 2 && !has_plane_class) break;
+        for (int round = 0; round <= plane_round; ++round) {
+            if (round == plane_round && !has_plane_class) break;
             float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             int cn = 0;
-            const int c = win_unit_class(round, g);
+            const int c = win_unit_class(G, round, g);
             const bool up = (g & 1) == 0;
-            if (found && !(round == 2 && g >= 2)) {
+            if (found && !(round == plane_round && g >= 2)) {
                 const float gap = c == 0 ? c0.x - blo : (c == 4 ? bhi - c0.x : 0.f);
                 if (!(gap > 0.f && gap * gap > r2)) {
                     const int p0 = V.lower_bound(c, c0.y);
@@ -557,7 +601,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
                     });
                 }
             }
-            for (int o = 1; o < 4; o <<= 1) { /* (up + down) of a class, then the two classes of the round: a fixed tree */
+            for (int o = 1; o < G; o <<= 1) { /* (up + down) of a class, then the two classes of a side pair, then (8 lanes) the two pairs: a fixed tree */
 #pragma unroll
                 for (int i = 0; i < 9; ++i) a[i] += __shfl_xor(a[i], o, 64);
                 cn += __shfl_xor(cn, o, 64);
@@ -566,6 +610,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             for (int i = 0; i < 9; ++i) acc[i] += a[i];
             count += cn;
         }
+        STAMP(6, 8); /* normal: radius search + covariance */
         if (act && g == 0) {
             float n4[4] = {NAN, NAN, NAN, NAN};
             if (found && count >= 3) {
@@ -602,6 +647,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
 #pragma unroll
             for (int d = 0; d < 6; ++d) A.wps_pre[6 * slot + d] = wp[d];
         }
+        STAMP(6, 9); /* eigen33, frame, Euler, hand-eye, stores */
     }
 }
 
@@ -703,7 +749,7 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
             if (s2 >= A.sb && s2 < A.se) c2 = A.wp_cnt[k2];
         }
         int tot;
-        const int pre = block_exscan(c2, s_scan, &tot);
+        const int pre = block_exscan_w(c2, s_scan, &tot);
         const int run = s_run;
         if (k2 < nk) {
             s_off[k2] = run + pre;
@@ -728,21 +774,44 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
     const int ntiles = smooth_tiles(W);
     const int tile = bx;
     if (W == 0 || tile >= ntiles) return;
-    /* list index -> slot of the per-slice layout */
-    auto slice_of = [&](int g) { int lo = 0, hi = nk - 1; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= g) lo = mid; else hi = mid - 1; } return lo; };
+    /* list index -> kept slice: the counts are nearly equal, so a proportional guess lands within a slice or two; a short
+       walk settles it (bounded: a binary search takes over on very uneven lists) */
+    auto slice_of = [&](int g) {
+        int kk = (int)(((long long)g * (long long)nk) / (long long)W);
+        kk = kk < 0 ? 0 : (kk > nk - 1 ? nk - 1 : kk);
+        int steps = 0;
+        while (kk > 0 && s_off[kk] > g && steps < 6) { --kk; ++steps; }
+        while (kk < nk - 1 && s_off[kk + 1] <= g && steps < 6) { ++kk; ++steps; }
+        if (steps >= 6) { int lo = 0, hi = nk - 1; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= g) lo = mid; else hi = mid - 1; } kk = lo; }
+        return kk;
+    };
     auto row_of = [&](int g) { const int kk = slice_of(g); return (size_t)kk * A.stride + (size_t)(g - s_off[kk]); };
     const double wd = 0.65, ws = 1 - wd, dg = wd + 2 * ws;
     const double r = (dg - sqrt(dg * dg - 4 * ws * ws)) / (2 * ws), c = wd / (dg - 2 * ws * r);
     const int t0 = tile * SMF_T;
     const int base = t0 - SMF_K;
     const bool solve = A.finish && P.smooth && W > 2;
+    /* this thread's waypoint: its slice and its six values, requested once; the position part also fills the filter's tile */
+    const int g = t0 + tid;
+    int kk = 0;
+    size_t rowbase = 0;
+    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g < W) {
+        kk = slice_of(g);
+        rowbase = (size_t)kk * A.stride - (size_t)s_off[kk]; /* row of list index w of this slice = rowbase + w */
+#pragma unroll
+        for (int d = 0; d < 6; ++d) p[d] = A.wps_pre[6 * (rowbase + g) + d];
+    }
     if (A.finish) {
-        for (int l = tid; l < SMF_M; l += blockDim.x) {
-            const int g = base + l;
-            const bool src = g >= 1 && g <= W - 2;
+        const bool src = g >= 1 && g <= W - 2; /* the sources are the INTERIOR waypoints: the two fixed ends enter through A and B */
+        for (int j = 0; j < 3; ++j) s_x[j][tid + SMF_K] = src ? p[j] : 0.f;
+        if (tid < 2 * SMF_K) { /* the halo: SMF_K waypoints either side of the tile */
+            const int l = tid < SMF_K ? tid : SMF_T + tid;
+            const int g2 = base + l;
+            const bool src2 = g2 >= 1 && g2 <= W - 2;
             size_t row = 0;
-            if (src) row = row_of(g);
-            for (int j = 0; j < 3; ++j) s_x[j][l] = src ? A.wps_pre[6 * row + j] : 0.f;
+            if (src2) row = row_of(g2);
+            for (int j = 0; j < 3; ++j) s_x[j][l] = src2 ? A.wps_pre[6 * row + j] : 0.f;
         }
     }
     const bool in_order = A.finish && P.rpy_resolution > 2 && s_short;
@@ -761,12 +830,7 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
         }
     }
     __syncthreads();
-    const int g = t0 + tid;
     if (g < W) {
-        const int kk = slice_of(g);
-        const size_t rowbase = (size_t)kk * A.stride - (size_t)s_off[kk]; /* row of list index w of this slice = rowbase + w */
-        float p[6];
-        for (int d = 0; d < 6; ++d) p[d] = A.wps_pre[6 * (rowbase + g) + d];
         for (int d = 0; d < 6; ++d) A.wp_pre[6 * (size_t)g + d] = p[d]; /* the compact list after HandEyeTransform */
         if (A.finish) {
             if (solve) {
@@ -865,6 +929,34 @@ __global__ void __launch_bounds__(256) k_win_gather_stage(WinArgs A, float4 *wp_
         wp_xyz[off + t] = A.wps_xyz[slot];
         wp_nn[off + t] = A.wps_nn[slot];
         wp_normal[off + t] = A.wps_normal[slot];
+    }
+}
+
+
+/* ------------------------------------------------------------------ */
+/* plan time (once per cloud + parameters, not part of a pass): the exact population of every window and of its left band   */
+/* side, so that the LDS capacities of the slice workgroups are the cloud's own maxima instead of a density guess (a jittered */
+/* grid puts 5 or 6 columns of points into an 8 mm window: +-12 % around the mean).                                            */
+/* ------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X, int n, const float *__restrict__ px, int S, float px0,
+                                                    float inv_step, float pad, int *cnt_win, int *cnt_el, int *cnt_er)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = X[i];
+        if (!(x == x)) continue;
+        const float fj = fminf(fmaxf(floorf((x - px0) * inv_step + 0.5f), 0.f), (float)(S - 1));
+        const int j = (int)fj;
+        const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
+        int w = -1;
+        if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
+        if (w < 0) continue;
+        atomicAdd(&cnt_win[w], 1);
+        const float Px = px[w];
+        const int position = (int)Px;
+        if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
+            const float d = (x - Px) * 1.f;
+            if (d > 0) atomicAdd(&cnt_el[w], 1); else if (d < 0) atomicAdd(&cnt_er[w], 1);
+        }
     }
 }
 

@@ -1427,3 +1427,24 @@ def test_gather_waypoints_multi_rank_pattern_through_a_recording_rccl(tmp_path):
     assert d["send_log"][1].startswith("send buf=") and d["send_log"][1].endswith("count=%d " % (6 * W) + tail % (2, stream))
     assert d["fail_raised"] and "ncclResult 5" in d["fail_msg"]
     assert d["fail_log"][0] == "group_start" and d["fail_log"][-1] == "group_end" and len(d["fail_log"]) == 3   # no second recv after the failure
+
+
+def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):
+    """bench.py's N > 1 path on one GPU (PPP_BENCH_FORCE_DIST=1: a one-rank RCCL group): the JSON line carries the ranks the
+    communicator saw, every rank's waypoint count and the gather's own time per step, next to the usual fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(PPP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "small_40k", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--rotate", "0", "--no-dynamic", "--profile-passes", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1])
+    m = d["multi_gpu"]
+    assert m["n_ranks_seen"] == {"torch_distributed_world_size": 1, "rccl_allreduce_of_ones": 1}
+    assert m["waypoints_per_rank"] == [d["config"]["waypoints_per_workpiece"]] and m["gather_ms_per_step_alone"] > 0
+    assert d["assembled_path"]["rank0_block_equals_its_list"] and d["roofline"]["kernel"].startswith("k_")

@@ -496,3 +496,16 @@ def test_gather_exchange_call_pattern(tmp_path):
     assert _gather_drive(d, 1, 3, 0, 0, 4, 4, 4) == ["group_start", "rc=2 nccl=2"]
     # the root's own copy fails before any group call
     assert _gather_drive(d, 0, 3, 0, 200, 4, 4, 4)[1:] == ["rc=1 nccl=0"]
+
+
+def test_bench_refuses_to_start_ranks_from_under_a_profiler():
+    """`bench.py --gpus N` starts its own ranks -- but never from a process a profiler's preload has already
+    given a GPU context (rocprofv3 sets ROCP_* / ROCPROFILER_* and LD_PRELOAD for its child)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ROCP_TOOL_LIBRARIES"] = "/opt/rocm/lib/librocprofiler-sdk-tool.so"
+    env["PPP_BENCH_ECHO_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "under a profiler" in out and "rank 0 of 2" not in out

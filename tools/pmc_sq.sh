@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --rotate 0 --profile-passes 3 > $OUT/log.txt 2>&1 || echo failed
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dynamic --rotate 0 --profile-passes 3 "$@" > $OUT/log.txt 2>&1 || echo failed
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/pmc_sq/**/*counter_collection.csv', recursive=True)

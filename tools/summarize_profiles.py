@@ -25,12 +25,21 @@ def kernel_key(name):
 
 
 def pmc(sub, name):
+    """mean counter value per launch, keyed by kernel -- and by grid size where one kernel is launched with several (a batch
+    split into two halves beside a full-width roofline launch must not be averaged into one figure)"""
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
-                acc[kernel_key(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+                acc[(kernel_key(r["Kernel_Name"]), r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+    grids = collections.defaultdict(set)
+    for (k, g) in acc:
+        grids[k].add(g)
+    vals, cnts = {}, {}
+    for (k, g), v in acc.items():
+        key = k if len(grids[k]) == 1 else "%s@grid%s" % (k, g)
+        vals[key] = sum(v) / len(v); cnts[key] = len(v)
+    return vals, cnts
 
 
 fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
