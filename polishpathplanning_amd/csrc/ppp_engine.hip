@@ -149,6 +149,7 @@ struct ppp_handle_s {
     bool win_path = false;      /* the current plan runs the window path */
     bool stage_compact = true;  /* wp_xyz / wp_nn / wp_normal hold the list order (a window pass leaves them in per-slice slots) */
     float win_pad = 4.f;
+    int win_NBc_thr = 0; /* y-buckets per class in launches of several workgroups per CU: the most that cost no workgroup its place in the LDS */
     int win_capw = 0, win_cap_el = 0, win_NB = 0, win_NBc = 0, win_stride = 1, win_threads = 256, win_ppt = 4, win_gs = 1;
     int win_nkept = 0, win_first_kept = 0, win_el_expect = 0;
     float win_px0 = 0.f;
@@ -404,6 +405,13 @@ int enqueue_normals(ppp_handle h)
    thread in the pairing, 4 .. 8 lanes per waypoint in the pose stage): the launch ends with its slowest workgroup.  A launch
    of several rounds of workgroups (batches, cfg 5) is about throughput: as many workgroups per CU as the LDS allows, the 16
    waves shared between them (measured, 64 x 250 k points: 256 threads 0.42 ms, 320 .. 512 threads 0.58 .. 0.64 ms). */
+size_t win_slice_lds_for(const ppp_handle h, int NBc)
+{   /* (the checking workgroup of the launch keeps the walk and its scratch there) */
+    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, WIN_CLASSES * NBc), sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
+}
+/* several workgroups per CU, at once or one after the other? */
+bool win_throughput_launch(const ppp_handle h, long long wgs) { return wgs > (long long)h->num_cus; }
+
 int win_pick_threads(const ppp_handle h, long long wgs)
 {
     const int capw = h->win_capw, cap_el = h->win_cap_el;
@@ -411,11 +419,11 @@ int win_pick_threads(const ppp_handle h, long long wgs)
     tmin = std::max(tmin, 64 * ((cap_el + 64 * 4 - 1) / (64 * 4)));
     if (tmin > 1024) return 0;
     const int wide = std::min(1024, std::max(256, 64 * (int)std::ceil(std::max(1.05 * (double)h->win_el_expect, 4.0 * (double)h->cnt_est) / 64.0)));
-    const size_t lds = std::max(win_slice_lds_bytes(capw, cap_el, h->win_NB), sizeof(float) * ((size_t)h->S_cap + 2048) + 64) + 1024;
+    const size_t lds = win_slice_lds_for(h, win_throughput_launch(h, wgs) ? h->win_NBc_thr : h->win_NBc) + 1024;
     const int by_lds = (int)std::max<size_t>(1, (size_t)h->max_lds / lds);
     const long long per_cu = (wgs + h->num_cus - 1) / std::max(1, h->num_cus);
     int T = wide;
-    if (per_cu > 1) { /* several workgroups per CU, at once or one after the other */
+    if (win_throughput_launch(h, wgs)) {
         const int conc = (int)std::min<long long>(by_lds, per_cu);
         T = std::min(wide, 64 * std::max(1, 16 / conc));
     }
@@ -465,8 +473,8 @@ int plan_window(ppp_handle h, int S, double per)
     int max_w = 0, max_el = 0;
     for (int s2 = h->sb; s2 < h->se; ++s2) { max_w = std::max(max_w, census[s2]); max_el = std::max(max_el, census[(size_t)S + s2]); }
     const double expect = std::max(1, max_w);
-    int NBc = 16;
-    while (NBc < expect / 10.0 && NBc < 4096) NBc <<= 1;
+    int NBc = 16; /* y-buckets per class: about two per point of a class where the LDS allows (most buckets then hold one point or none) */
+    while (NBc < expect / 5.0 && NBc < 4096) NBc <<= 1;
     /* capacities = this cloud's own maxima (rounded up to 64 points); what gives way under LDS pressure is the bucket table */
     const size_t budget = (size_t)h->max_lds - 2048;
     int capw = 64 * ((max_w + 63) / 64 + 0), cap_el = 64 * ((max_el + 63) / 64);
@@ -474,9 +482,14 @@ int plan_window(ppp_handle h, int S, double per)
     while (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget && NBc > 32) NBc >>= 1;
     if (win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) > budget) capw = 0;
     if (!capw) return PPP_OK; /* the windows of this cloud do not fit a workgroup's LDS */
+    /* ... and for launches with several workgroups per CU half as many (about one per point: the table's LDS is worth more as
+       room for another workgroup; measured on 64 x 250 k points: 256 buckets per class and 4 workgroups per CU 0.42 ms, 512 and
+       3 workgroups 0.62 ms, 128 and 5 workgroups 0.49 ms) */
+    h->win_NBc_thr = std::max(16, NBc / 2);
+    while (h->win_NBc_thr * 2 <= NBc && h->win_NBc_thr < expect / 10.0) h->win_NBc_thr <<= 1;
     const int NB = WIN_CLASSES * NBc;
     h->win_el_expect = max_el;
-    h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB;
+    h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc;
     int T = win_pick_threads(h, std::max(1, h->se - h->sb));
     if (!T) return PPP_OK;
     h->win_ppt = n_src > PPP_PPT16_FROM ? 16 : (n_src > PPP_PPT8_FROM ? 8 : 4);
@@ -489,11 +502,20 @@ int plan_window(ppp_handle h, int S, double per)
     h->win_px0 = px[0];
     HIPCHK(h, h->win_part.ensure((size_t)h->win_gs));
     HIPCHK(h, h->win_pts.ensure((size_t)S * (size_t)capw));
+    {   /* the knot arrays hold a cap_el segment per slice on this path */
+        const double need = (double)S * (double)cap_el;
+        if (need > 1.0e9) return PPP_OK;
+        h->node_cap = std::max(h->node_cap, (int)need);
+        HIPCHK(h, h->node_x.ensure(h->node_cap)); HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
+    }
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
     HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
     HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * WIN_CNT_STRIDE, h->stream)); /* the passes' counters (a line each): every pass leaves them cleared again */
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->win_path = true;
+    if (getenv("PPP_WIN_DEBUG"))
+        fprintf(stderr, "[ppp] window plan: S %d [%d,%d) pad %.2f capw %d cap_el %d NBc %d (throughput %d) threads %d ppt %d lds %zu B max window %d max left side %d\n",
+                S, h->sb, h->se, pad, capw, cap_el, NBc, h->win_NBc_thr, T, h->win_ppt, win_slice_lds_for(h, NBc), max_w, max_el);
     return PPP_OK;
 }
 
@@ -526,21 +548,27 @@ WinArgs win_args(const ppp_handle h)
     A.wp_pre = h->wp_pre.p; A.wp_smooth = h->wp_smooth.p; A.wp_out = h->wp_out.p; A.out2 = h->out2; A.out2_cap = h->out2_cap;
     return A;
 }
-size_t win_slice_lds(const ppp_handle h)
-{   /* (the checking workgroup of the launch keeps the walk and its scratch there) */
-    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, h->win_NB), sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
+size_t win_slice_lds(const ppp_handle h) { return win_slice_lds_for(h, h->win_NBc); }
+/* the same arguments with the bucket table of a many-workgroups-per-CU launch */
+void win_args_throughput(const ppp_handle h, WinArgs &A)
+{
+    A.NBc = h->win_NBc_thr; A.NB = WIN_CLASSES * A.NBc;
+    const float yr = h->h_mx[1] - h->h_mn[1];
+    A.yscale = yr > 0.f ? (float)A.NBc / yr : 0.f;
 }
 
 /* GenPath on the window path: bounds + binning, then the per-slice kernel (which also does getPath's per-waypoint half) */
 int enqueue_window_gen(ppp_handle h)
 {
-    const WinArgs A = win_args(h);
+    WinArgs A = win_args(h);
+    const bool thr = win_throughput_launch(h, A.g_slice);
+    if (thr) win_args_throughput(h, A);
     const size_t scat_lds = 8 * (size_t)A.S;
     if (h->win_ppt == 16) LAUNCH(h, "k_win_scatter", k_win_scatter<16>, A.g_scatter, WSC_T, scat_lds, A);
     else if (h->win_ppt == 8) LAUNCH(h, "k_win_scatter", k_win_scatter<8>, A.g_scatter, WSC_T, scat_lds, A);
     else LAUNCH(h, "k_win_scatter", k_win_scatter<4>, A.g_scatter, WSC_T, scat_lds, A);
     const int T = h->win_threads;
-    const size_t lds = win_slice_lds(h);
+    const size_t lds = win_slice_lds_for(h, A.NBc);
     if (T <= 256) LAUNCH(h, "k_win_slice", k_win_slice<256>, A.g_slice + 1, T, lds, A);
     else if (T <= 512) LAUNCH(h, "k_win_slice", k_win_slice<512>, A.g_slice + 1, T, lds, A);
     else if (T <= 768) LAUNCH(h, "k_win_slice", k_win_slice<768>, A.g_slice + 1, T, lds, A);
@@ -1867,7 +1895,7 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
         h->out2 = nullptr; h->out2_cap = 0;
         A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (<= the member's own: its partials fit) */
         slices_total += A.g_slice;
-        bg->win_lds = std::max(bg->win_lds, win_slice_lds(h));
+        /* (NB / NBc / yscale of the launch kind are set below, once the launch's total of slices is known) */
         bg->win_scat_lds = std::max(bg->win_scat_lds, 8 * (size_t)A.S);
         bg->win_fin_lds = std::max(bg->win_fin_lds, sizeof(int) * ((size_t)A.nkept + 2));
         bg->gx_scat = std::max(bg->gx_scat, A.g_scatter); bg->gx_slice = std::max(bg->gx_slice, A.g_slice + 1); bg->gx_wfin = std::max(bg->gx_wfin, A.g_finish);
@@ -1875,10 +1903,14 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
     /* one thread count for the launch: what the widest member needs, for the launch's total of slice workgroups */
     bg->win_threads = 128;
     for (size_t i = 0; i < count; ++i) {
+        if (win_throughput_launch(bg->hs[i], slices_total)) win_args_throughput(bg->hs[i], mem[i]);
+        bg->win_lds = std::max(bg->win_lds, win_slice_lds_for(bg->hs[i], mem[i].NBc));
         const int t = win_pick_threads(bg->hs[i], slices_total);
         if (!t) return fail(lead, PPP_ERR_CAPACITY, "window path: a member's windows do not fit a workgroup");
         bg->win_threads = std::max(bg->win_threads, t);
     }
+    if (getenv("PPP_WIN_DEBUG"))
+        fprintf(stderr, "[ppp] window batch: %zu members, %lld slices, threads %d, NBc %d, lds %zu B, ppt %d\n", count, slices_total, bg->win_threads, mem[0].NBc, bg->win_lds, bg->win_ppt);
     HIPCHK(lead, copy_sync(lead, bg->wmembers.p, mem.data(), sizeof(WinArgs) * count, hipMemcpyHostToDevice));
     return PPP_OK;
 }

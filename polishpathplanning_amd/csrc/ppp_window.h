@@ -280,19 +280,21 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     };
     /* ---- stage the window: points to registers, class + bucket, bucket sort into LDS ---- */
     STAMP_BEGIN();
-    const int n = A.win_cnt[(size_t)s * WIN_CNT_STRIDE];
-    __syncthreads(); /* every thread has read the count ... */
-    if (tid == 0) A.win_cnt[(size_t)s * WIN_CNT_STRIDE] = 0; /* ... this workgroup is its only reader: cleared for the next pass */
-    if (n > capw) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
+    /* the window's points are requested together with its count (slots beyond the count hold leftovers of earlier passes and
+       are ignored below): one round trip to memory instead of two */
     float4 pr[WIN_EMAX];
     int pb[WIN_EMAX];
     const float4 *src = A.win_pts + (size_t)s * capw;
+    const int n = A.win_cnt[(size_t)s * WIN_CNT_STRIDE];
 #pragma unroll
     for (int e = 0; e < WIN_EMAX; ++e) {
         const int i = tid + e * T;
         pb[e] = -1;
-        if (i < n) pr[e] = src[i];
+        if (i < capw) pr[e] = src[i];
     }
+    __syncthreads(); /* every thread has read the count ... */
+    if (tid == 0) A.win_cnt[(size_t)s * WIN_CNT_STRIDE] = 0; /* ... this workgroup is its only reader: cleared for the next pass */
+    if (n > capw) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
     for (int b = tid; b <= NB; b += T) tab[b] = 0;
     __syncthreads();
     STAMP(6, 0); /* window load issued, table cleared */
@@ -462,8 +464,10 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     const int mm = s_m;
     if (tid == 0) {
         int tot = mm;
-        int base = atomicAdd(&m->node_cursor, tot);
-        if (base + tot > A.node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
+        /* the slice's knots go to its own segment of the knot arrays (cap_el each: a knot per left point at most) -- reserving
+           a segment with an atomic on one shared cursor put a round trip to memory on every workgroup's critical path */
+        int base = s * cap_el;
+        if ((long long)base + tot > (long long)A.node_cap) { set_err(m, DERR_CAPACITY, s); base = 0; tot = 0; }
         s_base = base; s_nk = tot;
         A.node_start[s] = base; A.node_cnt[s] = tot;
         if (tot < 3) set_err(m, DERR_SLICE, s); /* gsl_spline_alloc needs >= 3 knots */
