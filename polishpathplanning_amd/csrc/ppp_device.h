@@ -511,10 +511,14 @@ __device__ inline void pcl_eigen33_smallest(const float cov[9], float *eigenvalu
     for (int d = 0; d < 3; ++d) ev[d] = cp[idx][d] / len[idx];
 }
 
-/* Eigen: Quaternionf from AngleAxisf about a unit axis, product, toRotationMatrix */
+/* Eigen: Quaternionf from AngleAxisf about a unit axis, product, toRotationMatrix.
+   The translation unit is compiled -ffp-contract=off because the reference's DECISIONS (band membership, nearest neighbours, map
+   keys, waypoint counts) must see one rounding per written operation.  The frame / Euler / hand-eye arithmetic below and the
+   smoothing filter feed continuous outputs only (compared at 1e-6 m / 1e-4 rad): they re-enable contraction locally -- contract(on): only a product and a sum written in ONE expression fuse, a decision of the front end, so the batched and the single launch forms of a kernel body carry the same bits (contract(fast) lets the optimiser fuse across statements, and two instantiations of one body came out one bit apart). */
 struct Quatf { float w, x, y, z; };
 __device__ __forceinline__ Quatf quat_axis(float angle, int axis)
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     float ha = 0.5f * angle;
     float s, c;
     sincosf(ha, &s, &c); /* (one argument reduction for both) */
@@ -525,6 +529,7 @@ __device__ __forceinline__ Quatf quat_axis(float angle, int axis)
 }
 __device__ __forceinline__ Quatf quat_mul(const Quatf &a, const Quatf &b)
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     Quatf r;
     r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
     r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
@@ -534,6 +539,7 @@ __device__ __forceinline__ Quatf quat_mul(const Quatf &a, const Quatf &b)
 }
 __device__ __forceinline__ void quat_to_mat(const Quatf &q, float R[3][3])
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     const float tx = 2.f * q.x, ty = 2.f * q.y, tz = 2.f * q.z;
     const float twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
     const float txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
@@ -551,6 +557,7 @@ __device__ __forceinline__ void rot_zyx(float rx, float ry, float rz, float R[3]
 /* Matrix3f::eulerAngles(2,1,0) -> (yaw, pitch, roll) */
 __device__ __forceinline__ void euler_zyx(const float m[3][3], float e[3])
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     const float kPi = 3.14159265358979323846f;
     e[0] = atan2f(m[1][0], m[0][0]);
     float c2 = sqrtf(m[2][2] * m[2][2] + m[2][1] * m[2][1]);
@@ -569,6 +576,7 @@ __device__ __forceinline__ void euler_zyx(const float m[3][3], float e[3])
 __device__ __forceinline__ void handeye_rotation(const float he[6], float HE[3][3]) { rot_zyx(he[3], he[4], he[5], HE); }
 __device__ __forceinline__ void handeye_apply(const float HE[3][3], const float he[6], float wp[6])
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     float P[3][3];
     rot_zyx(wp[3], wp[4], wp[5], P);
     float R[3][3], t[3];
@@ -591,6 +599,7 @@ __device__ __forceinline__ void handeye_transform(const float he[6], float wp[6]
 /* Approach / Orientation / Normal frame, path_translation_alg.cpp:192-202 */
 __device__ __forceinline__ void pose_from_normal(const float n[3], float rpy[3])
 {
+#pragma clang fp contract(on) /* continuous output only (no decision hangs on it): fused multiply-adds allowed */
     float A[3] = {-n[0], -n[1], -n[2]};
     const float X[3] = {1.f, 0.f, 0.f};
     float O[3], Nn[3];

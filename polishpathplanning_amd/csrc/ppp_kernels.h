@@ -2290,6 +2290,7 @@ __device__ inline void rpy_segment(float *W6, int n, int &preId, int tailId, int
 __device__ __forceinline__ void finish_one_waypoint(const DevMeta *m, const DevParams &P, const int *__restrict__ tail,
                                            const float *__restrict__ src, int w, float p[6])
 {
+#pragma clang fp contract(on) /* continuous output only; the same text runs inside win_finish_body's contracted region */
     const bool reduce = P.rpy_resolution > 2;
     if (reduce) {
         const int res = (int)P.rpy_resolution;
@@ -2447,6 +2448,7 @@ __device__ __forceinline__ void smooth_solve_body(DevMeta *m, const DevParams &P
     __syncthreads();
     const int g = t0 + threadIdx.x;
     if (g < W) {
+#pragma clang fp contract(on) /* the 65-tap filter and the flange offset: continuous output only (same text as win_finish_body, so a list finished from gathered blocks carries the same bits) */
         float p[6];
         for (int d = 0; d < 6; ++d) p[d] = wp_pre[6 * (size_t)g + d];
         if (solve) {

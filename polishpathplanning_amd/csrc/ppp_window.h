@@ -835,6 +835,7 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
     }
     __syncthreads();
     if (g < W) {
+#pragma clang fp contract(on) /* the 65-tap filter and the flange offset: continuous output only (same text as smooth_solve_body) */
         for (int d = 0; d < 6; ++d) A.wp_pre[6 * (size_t)g + d] = p[d]; /* the compact list after HandEyeTransform */
         if (A.finish) {
             if (solve) {
