@@ -42,8 +42,16 @@ def load_traffic(kernel, launches_per_pass, config):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload", "cfg2_1m_s256") == config and kernel in d.get("kernels", {}):
-            best = (d["kernels"][kernel]["hbm_bytes_per_launch"] * launches_per_pass, os.path.basename(f))
+        ks = d.get("kernels", {})
+        if d.get("workload", "cfg2_1m_s256") != config:
+            continue
+        if kernel in ks:
+            best = (ks[kernel]["hbm_bytes_per_launch"] * launches_per_pass, os.path.basename(f))
+        else:   # one kernel launched with several grids (a batch as two halves in the timed loop, full width under the event timers):
+            #     the summary keeps them apart as <kernel>@grid<threads>; the roofline launch is the widest one
+            wide = sorted((int(k.split("@grid")[1]), k) for k in ks if k.startswith(kernel + "@grid") and k.split("@grid")[1].isdigit())
+            if wide:
+                best = (ks[wide[-1][1]]["hbm_bytes_per_launch"] * launches_per_pass, os.path.basename(f) + " (" + wide[-1][1] + ")")
     return best if best else (None, None)
 
 

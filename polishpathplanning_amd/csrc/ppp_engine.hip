@@ -147,6 +147,7 @@ struct ppp_handle_s {
     bool win_allowed = true;    /* ppp_set_fast_path */
     bool win_disabled = false;  /* a pass was handed back (overflow / reach / stale plan): this cloud + parameters stay on the slab path */
     bool win_path = false;      /* the current plan runs the window path */
+    bool win_staged = false;    /* the binning launch writes through LDS in window order (large clouds, ppp_window.h) */
     bool stage_compact = true;  /* wp_xyz / wp_nn / wp_normal hold the list order (a window pass leaves them in per-slice slots) */
     float win_pad = 4.f;
     int win_NBc_thr = 0; /* y-buckets per class in launches of several workgroups per CU: the most that cost no workgroup its place in the LDS */
@@ -237,6 +238,7 @@ struct BatchGraph {
     bool win = false;              /* every member runs the window path: the three k_win_*_b launches */
     DevBuf<WinArgs> wmembers;
     int win_ppt = 4, win_threads = 256, gx_wfin = 1;
+    bool win_staged = false;
     size_t win_lds = 0, win_scat_lds = 0, win_fin_lds = 0;
     DevBuf<DevMeta> metas;
     std::shared_ptr<BatchMetas> hmetas;
@@ -465,8 +467,13 @@ int plan_window(ppp_handle h, int S, double per)
     HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * 3 * (size_t)S, h->stream));
     std::vector<int> census(3 * (size_t)S, 0);
     if (n_src > 0) {
-        LAUNCH(h, "k_win_census", k_win_census, std::max(1, std::min((n_src + 255) / 256, 4096)), 256, 0, h->use_part ? h->Xp.p : h->X.p, n_src, h->win_px.p, S,
-               px[0], 1.0f / (float)step, pad, h->win_cnt.p, h->win_cnt.p + S, h->win_cnt.p + 2 * (size_t)S);
+        const float *cx = h->use_part ? h->Xp.p : h->X.p;
+        if (S <= 4096) /* the counters fit a workgroup's LDS: a few hundred workgroups, each flushing its non-zero counters once */
+            LAUNCH(h, "k_win_census", k_win_census<true>, std::max(1, std::min((n_src + 4095) / 4096, 512)), 256, sizeof(int) * 3 * (size_t)S, cx, n_src,
+                   h->win_px.p, S, px[0], 1.0f / (float)step, pad, h->win_cnt.p, h->win_cnt.p + S, h->win_cnt.p + 2 * (size_t)S);
+        else
+            LAUNCH(h, "k_win_census", k_win_census<false>, std::max(1, std::min((n_src + 255) / 256, 4096)), 256, 0, cx, n_src,
+                   h->win_px.p, S, px[0], 1.0f / (float)step, pad, h->win_cnt.p, h->win_cnt.p + S, h->win_cnt.p + 2 * (size_t)S);
         HIPCHK(h, hipMemcpyAsync(census.data(), h->win_cnt.p, sizeof(int) * 3 * (size_t)S, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -494,14 +501,26 @@ int plan_window(ppp_handle h, int S, double per)
     if (!T) return PPP_OK;
     /* points per thread of the binning launch: 8 from half a million points on (16 was slower at 10 M points: 107 against 100 us) */
     h->win_ppt = n_src > PPP_PPT8_FROM ? 8 : 4;
-    if (const char *ev = getenv("PPP_WIN_PPT")) { const int pv = atoi(ev); if (pv == 4 || pv == 8 || pv == 16) h->win_ppt = pv; }
+    /* large clouds leave the binning launch through LDS in window order (write amplification 2.1 -> ~1.3 at 10 M points), with
+       as many points per thread as the stage has room for */
+    {
+        int from = PPP_PPT16_FROM;
+        if (const char *ev = getenv("PPP_WIN_STAGE_FROM")) from = atoi(ev); /* tuning runs only */
+        h->win_staged = n_src > from && !getenv("PPP_WIN_NO_STAGE");
+    }
+    if (h->win_staged) {
+        h->win_ppt = 8;
+        if (win_scatter_lds_bytes(S, 8, WSC_T, true) + 2048 > (size_t)h->max_lds) h->win_ppt = 4;
+        if (win_scatter_lds_bytes(S, h->win_ppt, WSC_T, true) + 2048 > (size_t)h->max_lds) { h->win_staged = false; h->win_ppt = 8; }
+    }
+    if (const char *ev = getenv("PPP_WIN_PPT")) { const int pv = atoi(ev); if ((pv == 4 || pv == 8) && !h->win_staged) h->win_ppt = pv; } /* tuning runs only */
     h->win_gs = std::max(1, (n_src + h->win_ppt * WSC_T - 1) / (h->win_ppt * WSC_T));
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
     h->win_first_kept = h->P.drop_ends ? 1 : 0;
     h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
     h->win_px0 = px[0];
-    HIPCHK(h, h->win_part.ensure((size_t)h->win_gs));
+    HIPCHK(h, h->win_part.ensure((size_t)std::max(h->win_gs, (n_src + 4 * WSC_T - 1) / (4 * WSC_T)))); /* (a batch may bin with 4 points per thread) */
     HIPCHK(h, h->win_pts.ensure((size_t)S * (size_t)capw));
     {   /* the knot arrays hold a cap_el segment per slice on this path */
         const double need = (double)S * (double)cap_el;
@@ -564,10 +583,11 @@ int enqueue_window_gen(ppp_handle h)
     WinArgs A = win_args(h);
     const bool thr = win_throughput_launch(h, A.g_slice);
     if (thr) win_args_throughput(h, A);
-    const size_t scat_lds = 8 * (size_t)A.S;
-    if (h->win_ppt == 16) LAUNCH(h, "k_win_scatter", k_win_scatter<16>, A.g_scatter, WSC_T, scat_lds, A);
-    else if (h->win_ppt == 8) LAUNCH(h, "k_win_scatter", k_win_scatter<8>, A.g_scatter, WSC_T, scat_lds, A);
-    else LAUNCH(h, "k_win_scatter", k_win_scatter<4>, A.g_scatter, WSC_T, scat_lds, A);
+    const size_t scat_lds = win_scatter_lds_bytes(A.S, h->win_ppt, WSC_T, h->win_staged);
+    if (h->win_staged && h->win_ppt == 8) LAUNCH(h, "k_win_scatter", (k_win_scatter<8, true>), A.g_scatter, WSC_T, scat_lds, A);
+    else if (h->win_staged) LAUNCH(h, "k_win_scatter", (k_win_scatter<4, true>), A.g_scatter, WSC_T, scat_lds, A);
+    else if (h->win_ppt == 8) LAUNCH(h, "k_win_scatter", (k_win_scatter<8, false>), A.g_scatter, WSC_T, scat_lds, A);
+    else LAUNCH(h, "k_win_scatter", (k_win_scatter<4, false>), A.g_scatter, WSC_T, scat_lds, A);
     const int T = h->win_threads;
     const size_t lds = win_slice_lds_for(h, A.NBc);
     if (T <= 256) LAUNCH(h, "k_win_slice", k_win_slice<256>, A.g_slice + 1, T, lds, A);
@@ -1123,13 +1143,14 @@ int ppp_create(int device_id, ppp_handle *out)
     (void)hipFuncSetAttribute((const void *)k_win_slice_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
     (void)hipFuncSetAttribute((const void *)k_win_slice_b<768>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
     (void)hipFuncSetAttribute((const void *)k_win_slice_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
-    (void)hipFuncSetAttribute((const void *)k_insert_api, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 1024);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * WIN_S_MAX);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
+    (void)hipFuncSetAttribute((const void *)k_win_scatter_b<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, h->max_lds - 2048);
     /* none of the opt-ins above is fatal (the launches check for themselves): leave no stale error behind for the next HIP
        user of this thread (a framework that reads hipGetLastError after its own calls would trip over it) */
     (void)hipGetLastError();
@@ -1886,7 +1907,17 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
     bg->win_ppt = 4; bg->win_threads = 256; bg->win_lds = 0; bg->win_scat_lds = 0; bg->win_fin_lds = 0;
     bg->gx_scat = 1; bg->gx_slice = 1; bg->gx_wfin = 1;
     long long slices_total = 0;
+    /* one form of the binning launch for the batch: staged when any member is, with the points per thread all staged members have room for */
+    bg->win_staged = false;
+    for (size_t i = 0; i < count; ++i) bg->win_staged = bg->win_staged || bg->hs[i]->win_staged;
     for (size_t i = 0; i < count; ++i) bg->win_ppt = std::max(bg->win_ppt, bg->hs[i]->win_ppt);
+    if (bg->win_staged) {
+        int smax = 1;
+        for (size_t i = 0; i < count; ++i) smax = std::max(smax, bg->hs[i]->S_cap);
+        bg->win_ppt = 8;
+        if (win_scatter_lds_bytes(smax, 8, WSC_T, true) + 2048 > (size_t)lead->max_lds) bg->win_ppt = 4;
+        if (win_scatter_lds_bytes(smax, bg->win_ppt, WSC_T, true) + 2048 > (size_t)lead->max_lds) { bg->win_staged = false; bg->win_ppt = 8; }
+    }
     for (size_t i = 0; i < count; ++i) {
         ppp_handle h = bg->hs[i];
         h->out2 = dst_dev ? dst_dev + 6 * offset_rows[i] : nullptr;
@@ -1894,10 +1925,10 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
         WinArgs &A = mem[i];
         A = win_args(h);
         h->out2 = nullptr; h->out2_cap = 0;
-        A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (<= the member's own: its partials fit) */
+        A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (the members' partials are sized for 4 points per thread) */
         slices_total += A.g_slice;
         /* (NB / NBc / yscale of the launch kind are set below, once the launch's total of slices is known) */
-        bg->win_scat_lds = std::max(bg->win_scat_lds, 8 * (size_t)A.S);
+        bg->win_scat_lds = std::max(bg->win_scat_lds, win_scatter_lds_bytes(A.S, bg->win_ppt, WSC_T, bg->win_staged));
         bg->win_fin_lds = std::max(bg->win_fin_lds, sizeof(int) * ((size_t)A.nkept + 2));
         bg->gx_scat = std::max(bg->gx_scat, A.g_scatter); bg->gx_slice = std::max(bg->gx_slice, A.g_slice + 1); bg->gx_wfin = std::max(bg->gx_wfin, A.g_finish);
     }
@@ -1926,9 +1957,10 @@ static int enqueue_batched_stages(ppp_handle lead, BatchGraph *bg, hipStream_t s
     const unsigned gy = (unsigned)n;
     if (bg->win) { /* the window path: bounds + binning, the per-slice kernel, the finish -- three launches for the whole batch */
         const WinArgs *wm = bg->wmembers.p + first;
-        if (bg->win_ppt == 16) LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<16>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
-        else if (bg->win_ppt == 8) LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<8>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
-        else LAUNCHB(lead, strm, "k_win_scatter_b", k_win_scatter_b<4>, dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        if (bg->win_staged && bg->win_ppt == 8) LAUNCHB(lead, strm, "k_win_scatter_b", (k_win_scatter_b<8, true>), dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        else if (bg->win_staged) LAUNCHB(lead, strm, "k_win_scatter_b", (k_win_scatter_b<4, true>), dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        else if (bg->win_ppt == 8) LAUNCHB(lead, strm, "k_win_scatter_b", (k_win_scatter_b<8, false>), dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
+        else LAUNCHB(lead, strm, "k_win_scatter_b", (k_win_scatter_b<4, false>), dim3(bg->gx_scat, gy), WSC_T, bg->win_scat_lds, wm);
         const int T = bg->win_threads;
         if (T <= 256) LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<256>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);
         else if (T <= 512) LAUNCHB(lead, strm, "k_win_slice_b", k_win_slice_b<512>, dim3(bg->gx_slice, gy), T, bg->win_lds, wm);

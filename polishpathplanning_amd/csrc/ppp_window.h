@@ -81,12 +81,21 @@ __host__ __device__ inline size_t win_slice_lds_bytes(int capw, int cap_el, int 
 #ifndef WSC_T
 #define WSC_T 1024
 #endif
-template <int PPT>
+/* STAGED (large clouds): the workgroup's kept points leave through LDS in window order, so that a wave stores runs of
+   consecutive 16-byte pieces instead of 64 pieces in 64 different lines.  With thousands of workgroups' partial lines in
+   flight the L2 no longer merges the pieces of a line before it evicts it: 10 M points wrote 229 MB for 107 MB of points
+   (2 M points: 42 for 21), against 1.09 x at 1 M points, where the plain form stays. */
+__host__ __device__ inline size_t win_scatter_lds_bytes(int S, int ppt, int threads, bool staged)
+{
+    return staged ? (size_t)12 * S + 16 + (size_t)18 * ppt * threads : (size_t)8 * S;
+}
+template <int PPT, bool STAGED>
 __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    float *s_px = (float *)s_dyn;       /* S plane positions */
+    float *s_px = (float *)s_dyn;       /* S plane positions; STAGED: later the windows' places in the stage */
     int *s_cnt = s_dyn + A.S;           /* S counts, then bases */
+    __shared__ int s_scr[17];
     __shared__ float s_mn[3][WSC_T / 64], s_mx[3][WSC_T / 64];
     __shared__ int s_n[WSC_T / 64];
     const int S = A.S, n = A.n;
@@ -129,16 +138,52 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
         }
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const int c = s_cnt[s];
-        if (c) s_cnt[s] = atomicAdd(&A.win_cnt[(size_t)s * WIN_CNT_STRIDE], c); /* this workgroup's run inside the window */
-    }
-    __syncthreads();
+    if (!STAGED) {
+        for (int s = threadIdx.x; s < S; s += blockDim.x) {
+            const int c = s_cnt[s];
+            if (c) s_cnt[s] = atomicAdd(&A.win_cnt[(size_t)s * WIN_CNT_STRIDE], c); /* this workgroup's run inside the window */
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        if (pw[k] >= 0) {
-            const int pos = s_cnt[pw[k]] + pr[k];
-            if (pos < A.capw) A.win_pts[(size_t)pw[k] * A.capw + pos] = p[k]; /* beyond: the slice sees count > capw and hands the run back */
+        for (int k = 0; k < PPT; ++k) {
+            if (pw[k] >= 0) {
+                const int pos = s_cnt[pw[k]] + pr[k];
+                if (pos < A.capw) A.win_pts[(size_t)pw[k] * A.capw + pos] = p[k]; /* beyond: the slice sees count > capw and hands the run back */
+            }
+        }
+    } else {
+        int *s_loc = (int *)s_px;                 /* the planes are used up: the windows' first places in the stage */
+        int *s_gb = s_dyn + 2 * S;                /* ... and in their global windows */
+        float4 *stage = (float4 *)(s_dyn + ((3 * S + 3) & ~3));
+        u16 *widx = (u16 *)(stage + PPT * (int)blockDim.x);
+        int K;
+        {
+            const int per = (S + (int)blockDim.x - 1) / (int)blockDim.x;
+            const int b0 = threadIdx.x * per;
+            int sum = 0;
+            for (int q = 0; q < per; ++q) if (b0 + q < S) sum += s_cnt[b0 + q];
+            int pre = block_exscan_w(sum, s_scr, &K);
+            for (int q = 0; q < per; ++q) {
+                if (b0 + q < S) {
+                    const int c = s_cnt[b0 + q];
+                    s_loc[b0 + q] = pre; pre += c;
+                    s_gb[b0 + q] = c ? atomicAdd(&A.win_cnt[(size_t)(b0 + q) * WIN_CNT_STRIDE], c) : 0;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (pw[k] >= 0) {
+                const int q = s_loc[pw[k]] + pr[k];
+                stage[q] = p[k]; widx[q] = (u16)pw[k];
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < K; q += blockDim.x) {
+            const int w = widx[q];
+            const int pos = s_gb[w] + (q - s_loc[w]);
+            if (pos < A.capw) A.win_pts[(size_t)w * A.capw + pos] = stage[q];
         }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -943,9 +988,18 @@ __global__ void __launch_bounds__(256) k_win_gather_stage(WinArgs A, float4 *wp_
 /* side, so that the LDS capacities of the slice workgroups are the cloud's own maxima instead of a density guess (a jittered */
 /* grid puts 5 or 6 columns of points into an 8 mm window: +-12 % around the mean).                                            */
 /* ------------------------------------------------------------------ */
+template <bool IN_LDS>
 __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X, int n, const float *__restrict__ px, int S, float px0,
                                                     float inv_step, float pad, int *cnt_win, int *cnt_el, int *cnt_er)
 {
+    /* IN_LDS: the 3 S counters privatised per workgroup (a million points on a few hundred global counters serialise:
+       360 us at 1 M points / 256 windows; 12 us this way) */
+    extern __shared__ __attribute__((aligned(16))) int s_c[];
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < 3 * S; i += blockDim.x) s_c[i] = 0;
+        __syncthreads();
+    }
+    int *cw = IN_LDS ? s_c : cnt_win, *ce = IN_LDS ? s_c + S : cnt_el, *cr = IN_LDS ? s_c + 2 * S : cnt_er;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float x = X[i];
         if (!(x == x)) continue;
@@ -955,25 +1009,33 @@ __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X,
         int w = -1;
         if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
         if (w < 0) continue;
-        atomicAdd(&cnt_win[w], 1);
+        atomicAdd(&cw[w], 1);
         const float Px = px[w];
         const int position = (int)Px;
         if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
             const float d = (x - Px) * 1.f;
-            if (d > 0) atomicAdd(&cnt_el[w], 1); else if (d < 0) atomicAdd(&cnt_er[w], 1);
+            if (d > 0) atomicAdd(&ce[w], 1); else if (d < 0) atomicAdd(&cr[w], 1);
+        }
+    }
+    if (IN_LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < S; i += blockDim.x) {
+            if (s_c[i]) atomicAdd(&cnt_win[i], s_c[i]);
+            if (s_c[S + i]) atomicAdd(&cnt_el[i], s_c[S + i]);
+            if (s_c[2 * S + i]) atomicAdd(&cnt_er[i], s_c[2 * S + i]);
         }
     }
 }
 
 /* ---- launch forms: single (arguments by value) and batched (blockIdx.y = member of the batch) ---- */
-template <int PPT>
-__global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A) { win_scatter_body<PPT>(A, blockIdx.x); }
-template <int PPT>
+template <int PPT, bool STAGED>
+__global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A) { win_scatter_body<PPT, STAGED>(A, blockIdx.x); }
+template <int PPT, bool STAGED>
 __global__ void __launch_bounds__(WSC_T) k_win_scatter_b(const WinArgs *__restrict__ mem)
 {
     const WinArgs &A = mem[blockIdx.y];
     if ((int)blockIdx.x >= A.g_scatter) return;
-    win_scatter_body<PPT>(A, blockIdx.x);
+    win_scatter_body<PPT, STAGED>(A, blockIdx.x);
 }
 template <int TMAX>
 __global__ void __launch_bounds__(TMAX) k_win_slice(WinArgs A)

@@ -685,13 +685,14 @@ def test_area2cloud_with_equal_distances(engine_mod, oracle_mod):
     assert (~nan).sum() > 100
 
 
-@pytest.mark.parametrize("walk", [1, 2, 3])
-def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
+@pytest.mark.parametrize("name,walk", [("small_40k", 1), ("small_40k", 2), ("small_40k", 3), ("cfg2_1m_s256", 1)])
+def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, name, walk):
     """GenPath with Dynamic_adjustment = true (config.txt:13) for connect (walk 1), connect1 (walk 2) and
     Contact_Path_Generation of ./main (walk 3: brute pairing, 10 neighbours, inner samples only):
-    every adjusted knot is a cloud point, so the knot lists must be identical."""
-    pts, cfg = synth.make_config("small_40k")
-    kw = dict(tool_radius=6.0, walk=walk, dynamic_adjustment=1)
+    every adjusted knot is a cloud point, so the knot lists must be identical.  The last case is BASELINE configs[1] at full
+    size (1 M points, 256 slices: two chains of 128 steps) -- the reference's default mode on the headline workload."""
+    pts, cfg = synth.make_config(name)
+    kw = dict(tool_radius=cfg["tool_radius"], walk=walk, dynamic_adjustment=1)
     if walk == 3:
         kw.update(pairing=1, curvature_k=10, depth=0.005)
     o = oracle_mod.Oracle(pts, **kw)
@@ -710,7 +711,7 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, walk):
     wp, owp = e.waypoints(), o.waypoints()
     assert np.linalg.norm(wp[:, :3] - owp[:, :3], axis=1).max() <= TOL_M
     # and it differs from the equal-spacing path
-    e2 = engine_mod.Engine(0, tool_radius=6.0, walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
+    e2 = engine_mod.Engine(0, tool_radius=cfg["tool_radius"], walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
     a, b = e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0], e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]
     assert a.shape != b.shape or np.abs(a - b).max() > 0.05   # v1 drops the end samples, so its paths get shorter
 
