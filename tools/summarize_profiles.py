@@ -19,7 +19,7 @@ def kernel_key(name):
     base = name.split("(")[0].replace("void ", "").strip()
     if "<" in base:
         base, targ = base.split("<", 1)
-        if targ.startswith("true") and base != "k_minmax":   # k_minmax<true> is the bounds + histogram pass of the hot path
+        if targ.startswith("true") and base in ("k_slab_sort", "k_slice_kd"):   # the LDS-overflow passes of the slab path
             base += "_arena"
     return base
 
