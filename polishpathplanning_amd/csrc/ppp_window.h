@@ -37,9 +37,6 @@ __device__ inline void win_flag(DevMeta *m, int why) { atomicOr(&m->win_flag, wh
 #define WIN_CNT_STRIDE 1 /* ints between two windows' counters (a 128-byte line each, stride 32, changed nothing: 10 M points / 1024
                             windows 98 .. 107 us packed, 116 padded -- the scatter's bill is its 16-byte stores, not the atomics) */
 #endif
-#ifndef WIN_POSE_LANES
-#define WIN_POSE_LANES 4
-#endif
 #define WIN_EMAX 8 /* staged points per thread at most (capw <= WIN_EMAX * blockDim) */
 
 struct WinArgs {
@@ -277,13 +274,13 @@ __device__ inline int win_nn_class(const WinView &V, int c, const float4 q)
 }
 
 /* Units of a waypoint's two searches: (class, direction) -- the two band sides (up, down), the two outer classes (up, down),
-   the points on the plane.  A waypoint has G = 4 or 8 lanes: with 4 the band sides go first and the outer classes second
-   (the nearest-neighbour search has closed them by their x gap by then, almost always), with 8 -- when the workgroup has the
-   threads to spare -- both at once.  Partial sums are combined by one fixed tree, ((Er_up + Er_down) + (El_up + El_down)) +
-   ((L_up + L_down) + (R_up + R_down)), then + (plane_up + plane_down): the same bits for either G. */
+   the points on the plane.  A waypoint has G = 4 lanes (a launch whose workgroups have a CU to themselves: the band sides first,
+   the outer classes second -- the nearest-neighbour search has closed those by their x gap by then, almost always) or G = 2 (one
+   class per round: where it saves a whole pass over the slice's waypoints).  Partial sums are combined by one fixed tree, ((Er_up + Er_down) + (El_up + El_down)) + ((L_up + L_down) + (R_up + R_down)),
+   then + (plane_up + plane_down): the same bits for either G. */
 __device__ __forceinline__ int win_unit_class(int G, int round, int g)
 {
-    if (G == 8) return round == 0 ? (g < 4 ? (g < 2 ? 1 : 3) : (g < 6 ? 0 : 4)) : 2;
+    if (G == 2) return round == 0 ? 1 : (round == 1 ? 3 : (round == 2 ? 0 : (round == 3 ? 4 : 2)));
     return round == 0 ? (g < 2 ? 1 : 3) : (round == 1 ? (g < 2 ? 0 : 4) : 2);
 }
 
@@ -544,9 +541,11 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     handeye_rotation(P.handeye, HE);
     /* (8 lanes per waypoint -- both pairs of classes at once -- give the same bits but were slower where tried: 1 M points /
        256 slices 39.6 us against 35.0 with 4; twice the waves run the double-precision spline and the pose arithmetic) */
-    const int G = WIN_POSE_LANES, gshift = G == 8 ? 3 : 2;
+    /* 4 lanes per waypoint, or 2 where that saves a pass over the slice's waypoints (10 M points / 1024 slices: 258 waypoints x 4 lanes are
+       eight more than a 1024-thread workgroup has -- two passes; with 2 lanes one: 228 -> 195 us).  Same bits either way (the tree above). */
+    const int G = ((4 * cnt + T - 1) / T > (2 * cnt + T - 1) / T) ? 2 : 4, gshift = G == 4 ? 2 : 1;
     const int g = tid & (G - 1), per = T >> gshift;
-    const int plane_round = G == 8 ? 1 : 2; /* the unit round of the on-plane class */
+    const int plane_round = G == 4 ? 2 : 4; /* the unit round of the on-plane class */
     const int rounds = (cnt + per - 1) / per;
     const int per_round = (cnt + rounds - 1) / rounds; /* the waypoints spread evenly over the rounds */
     const bool has_plane_class = s_cs[3] > s_cs[2];
@@ -623,8 +622,8 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             if (!ok) win_flag(m, WIN_FLAG_REACH);
         }
         /* -- pcl::NormalEstimation at that point (path_slicing_alg.cpp:141-150): radius search, covariance about the point -- */
-        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int count = 0;
+        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, pairsum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int count = 0, paircnt = 0;
         const float4 c0 = bp;
         for (int round = 0; round <= plane_round; ++round) {
             if (round == plane_round && !has_plane_class) break;
@@ -650,10 +649,21 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
                     });
                 }
             }
-            for (int o = 1; o < G; o <<= 1) { /* (up + down) of a class, then the two classes of a side pair, then (8 lanes) the two pairs: a fixed tree */
+            for (int o = 1; o < G; o <<= 1) { /* (up + down) of a class, then (4 lanes) the two classes of a pair: a fixed tree */
 #pragma unroll
                 for (int i = 0; i < 9; ++i) a[i] += __shfl_xor(a[i], o, 64);
                 cn += __shfl_xor(cn, o, 64);
+            }
+            if (G == 2 && round < 4) { /* a pair of classes is two rounds here: (first + second), then into the total -- the tree above */
+                if ((round & 1) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) pairsum[i] = a[i];
+                    paircnt = cn;
+                    continue;
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) a[i] = pairsum[i] + a[i];
+                cn = paircnt + cn;
             }
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc[i] += a[i];
