@@ -2007,10 +2007,10 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
         HIPCHK(lead, hipEventRecord(bg->join[0], side));
         HIPCHK(lead, hipStreamWaitEvent(lead->stream, bg->join[0], 0));
     }
-    if (count == 1) { /* nothing to collect: the one meta block goes straight to the host */
-        HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->hs[0]->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, lead->stream));
+    if (count == 1) /* nothing to collect, and nothing to publish per step either: the one meta block is fetched when somebody asks
+                       (ppp_sync_batch, a getter) -- in a stream of steps on one workpiece a 200-byte copy behind every pass is a
+                       fourth launch (a blit kernel, 4.4 us of a 68 us step) whose result only the last pass's reader looks at */
         return PPP_OK;
-    }
     if (bg->win) LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta_win, dim3((unsigned)count), 64, 0, bg->wmembers.p, (int)count, bg->metas.p);
     else LAUNCHB(lead, lead->stream, "k_collect_meta", k_collect_meta, dim3((unsigned)count), 64, 0, bg->members.p, (int)count, bg->metas.p);
     HIPCHK(lead, hipMemcpyAsync(bg->hmetas->pinned, bg->metas.p, sizeof(DevMeta) * count, hipMemcpyDeviceToHost, lead->stream));
@@ -2166,9 +2166,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         h->stage_compact = !((bg->batched && bg->win) || (!bg->batched && h->win_path));
         h->gen_done = true; h->path_done = true;
         h->list_final = !h->ranged;
-        h->meta_in_flight = true;
-        h->meta_from_batch = bg->batched;
-        if (bg->batched) { h->bmetas = bg->hmetas; h->bslot = i; }
+        h->meta_in_flight = !(bg->batched && count == 1); /* a batch of one does not publish its meta block: fetched on demand */
+        h->meta_from_batch = bg->batched && count > 1;
+        if (bg->batched && count > 1) { h->bmetas = bg->hmetas; h->bslot = i; }
         h->pending_stream = (i == 0) ? nullptr : lead->stream;
         remember_dst(i);
     }
