@@ -187,17 +187,19 @@ __device__ inline void dyn_stage_ellipse(const float *__restrict__ ell_cs, float
     for (int a = threadIdx.x; a < DYN_ELL; a += blockDim.x) s_ell[a] = ((const float2 *)ell_cs)[a];
 }
 
-/* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative. */
-__device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
+/* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative.  Returns the number of neighbours
+   its search found (0: none, or the point is not a number); L.sel[0] / L.sel_id[0] then still hold the nearest of them, which is
+   what the 1-NN snap of the same point asks for. */
+__device__ inline int wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
                                        const float2 *ell, const DynParams &D, const double point[3], int key,
                                        float bound[3], StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
     const float sp[3] = {(float)point[0], (float)point[1], (float)point[2]};
     bound[0] = bound[1] = bound[2] = NAN;
-    if (!(sp[0] == sp[0] && sp[1] == sp[1] && sp[2] == sp[2])) return;
+    if (!(sp[0] == sp[0] && sp[1] == sp[1] && sp[2] == sp[2])) return 0;
     const int kk = wave_knn(V, L, sp[0], sp[1], sp[2], D.k, D.r0, sc);
-    if (kk <= 0) return;
+    if (kk <= 0) return 0;
     /* computePointPrincipalCurvatures: lane r holds the neighbour of rank r */
     float nn[3] = {0.f, 0.f, 0.f};
     if (lane < kk) {
@@ -397,6 +399,7 @@ __device__ inline void wave_area2cloud(const SlabView &V, DynWaveLds &L, const f
 #endif
     if (st == 1) { bound[0] = res[0]; bound[1] = res[1]; bound[2] = res[2]; }
     sc.mark(5);
+    return kk;
 }
 
 /* API: Area2Cloud for k query points (one wave each) */
@@ -587,6 +590,22 @@ __device__ inline int wave_gsl_bsearch_f(const float *ny, int mm, double dy)
     return seg + (63 - __clzll(m2));
 }
 
+/* the same over double knots, for any dy (a NaN takes gsl_interp_bsearch's own way through the comparisons) */
+__device__ inline int wave_gsl_bsearch_d(const double *ny, int mm, double dy)
+{
+    const int lane = threadIdx.x & 63;
+    const int top = mm - 1;
+    const int stride = (top + 63) >> 6;
+    if (stride > 64 || !(dy == dy)) { auto Yd = [&](int i) { return ny[i]; }; return gsl_bsearch(mm, dy, Yd); }
+    const int i1 = lane * stride;
+    const u64 m1 = __ballot(i1 < top && ny[i1] <= dy);
+    if (m1 == 0) return 0;
+    const int seg = (63 - __clzll(m1)) * stride;
+    const int i2 = seg + lane;
+    const u64 m2 = __ballot(lane < stride && i2 < top && ny[i2] <= dy);
+    return seg + (63 - __clzll(m2));
+}
+
 /* Spline::point on float knots (y, x, z): same operations as GSL's steffen.c.  Called by all lanes of a wave together. */
 __device__ inline void spline_point_f(const float *ny, const float *nx, const float *nz, int mm, double dy, double out[3])
 {
@@ -637,10 +656,11 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, D
     spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float ab[3];
-    wave_area2cloud(V, s_w[wv], normals4, s_ell, D, node, key == 0 ? 1 : 0, ab, sc);
+    const int kk = wave_area2cloud(V, s_w[wv], normals4, s_ell, D, node, key == 0 ? 1 : 0, ab, sc);
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
-    const int got = finite ? wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc) : 0;
+    /* the snap asks for the nearest point of the very query Area2Cloud has just ranked 50 neighbours of: rank 0, no second search */
+    const int got = finite ? (kk > 0 ? 1 : wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc)) : 0;
     if (lane == 0) {
         Bf.first_ab[at] = make_float4(ab[0], ab[1], ab[2], 1.f);
         Bf.first_node[3 * at] = node[0]; Bf.first_node[3 * at + 1] = node[1]; Bf.first_node[3 * at + 2] = node[2];
@@ -821,15 +841,17 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     /* bisection (:237-265), at most 6 Area2Cloud evaluations, the first of them taken ahead of the chain */
     float ab[3] = {first.x, first.y, first.z};
     bool moved = false;
+    int kk_here = 0; /* neighbours Area2Cloud found at the node as it stands (0: not evaluated there, or none) */
     for (int itr = 0; itr <= 5; ++itr) {
-        if (itr > 0) wave_area2cloud(V, L, normals4, s_ell, D, node, c.key == 0 ? 1 : 0, ab, sc);
+        if (itr > 0) kk_here = wave_area2cloud(V, L, normals4, s_ell, D, node, c.key == 0 ? 1 : 0, ab, sc);
         if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break; /* a NaN bound passes, as in the reference: the node turns NaN below */
-        const int iv = gsl_bsearch(nb, (double)ab[1], BY);
+        const int iv = wave_gsl_bsearch_d(ky, nb, (double)ab[1]);
         const double bpx = steffen_eval_at(iv, nb, (double)ab[1], BY, BX);
         const double norm0 = (double)ab[0] - bpx;
         if (fabs(norm0) < D.adjust_threshold) break;
         node[0] = node[0] - norm0;
         moved = true;
+        kk_here = 0;
         if (!(node[0] == node[0])) break;
         sc.mark(6);
     }
@@ -847,7 +869,8 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     }
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
-    const int got = finite ? wave_knn(V, L, qx, qy, qz, 1, D.r1, sc) : 0;
+    /* (a bisection that ended on an evaluation at the node's final place has its nearest point already: rank 0 of that search) */
+    const int got = finite ? (kk_here > 0 ? 1 : wave_knn(V, L, qx, qy, qz, 1, D.r1, sc)) : 0;
     if (lane == 0) {
         if (!finite) *dst = make_float4(0, 0, 0, 0);
         else if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }
