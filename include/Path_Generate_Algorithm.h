@@ -67,7 +67,8 @@ public:
     void show()
     {
         const unsigned char node_rgb[3] = {255, PPP_NODE_GB, PPP_NODE_GB}, path_rgb[3] = {(unsigned char)(blue_paths ? 0 : 255), 0, (unsigned char)(blue_paths ? 255 : 0)};
-        planner.show_dump(node_rgb, path_rgb);
+        /* the derived planner also paints each boundary curve green before it adjusts a slice against it (path_dynamic_alg.cpp:320-322) */
+        planner.show_dump(node_rgb, path_rgb, blue_paths && planner.config().params.dynamic_adjustment != 0);
     }
     /* path_slicing_alg.cpp:141-150: the whole-cloud normal field (the reference's GenPath and getPath call it themselves;
        here they evaluate normals only where getPath needs them, so this runs when the CALLER asks for the field) */

@@ -219,6 +219,13 @@ int ppp_get_slice_positions(ppp_handle h, float *px, size_t cap, size_t *S);
 int ppp_get_slice_indices(ppp_handle h, int s, int *out, size_t cap, size_t *n);
 /* Spline knots of slice s (ascending y): what OnePath / path_track feed to Spline() */
 int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t cap, size_t *m);
+/* Dynamic adjustment only: the boundary spline slice s was adjusted against -- compute_boundary(pre_path, boundary, key) of
+   thread_worker (path_dynamic_alg.cpp:183-235, 320-322; v1: Path_Generation.cpp:585-592), the curve drawpath(*boundary, 0,255,0)
+   paints: knots in ascending y with the two end knots 20 mm out.  *m = 0 where compute_boundary returned 0 at that step (fewer than
+   3 boundary points: nothing is painted, the slice is adjusted against the chain's previous boundary) and for the slice a chain starts
+   from.  *step = the slice's step in its chain (0 = next to the start slice; -1 = the start slice itself, or no dynamic adjustment):
+   the order thread_worker adjusts -- and paints -- in.  Evaluate with ppp_spline_create / ppp_spline_eval below. */
+int ppp_get_boundary(ppp_handle h, int s, double *y, double *x, double *z, size_t cap, size_t *m, int *step);
 /* Spline::point(y) of slice s (include/Spline.h:22-25): xyz[3*i..] */
 int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz);
 

@@ -13,11 +13,13 @@
 #ifndef PPP_PLANNER_HPP
 #define PPP_PLANNER_HPP
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ppp_hip.h"
@@ -212,9 +214,12 @@ public:
        spline knots insert_point added (coloured node_rgb: red, white in contour_alg.cpp:228-230) followed by the cloud itself,
        white, with the cloud point nearest to every millimetre of every path recoloured path_rgb (drawpath,
        path_slicing_alg.cpp:269-288).  No viewer here: with PPP_SHOW_PCD=<file> in the environment that very cloud is written
-       as a PointXYZRGB PCD (binary) for any viewer; without it a notice is printed.  The boundary curves drawpath also paints
-       while the dynamic adjustment runs (0,255,0) are not kept by the engine and are not in the dump. */
-    void show_dump(const unsigned char node_rgb[3], const unsigned char path_rgb[3])
+       as a PointXYZRGB PCD (binary) for any viewer; without it a notice is printed.  with_boundaries: the planner with the
+       dynamic adjustment also paints, before it adjusts a slice, the boundary curve it adjusts it against
+       (drawpath(*boundary, 0,255,0), path_dynamic_alg.cpp:320-322); slices are painted in the order thread_worker takes them
+       (the start slice, then step by step outwards; the reference's two threads interleave as they please -- here left before
+       right), so a later curve recolours an earlier one where they share a cloud point, as there. */
+    void show_dump(const unsigned char node_rgb[3], const unsigned char path_rgb[3], bool with_boundaries = false)
     {
         const char *out = std::getenv("PPP_SHOW_PCD");
         if (!out || !out[0] || !ok()) {
@@ -229,23 +234,58 @@ public:
         std::vector<float> nodes;
         int S = 0;
         if (ppp_num_slices(h_, &S) != PPP_OK) S = 0; /* show() before GenPath: the bare cloud */
+        /* drawpath: dy = miny; while (dy < maxy) { nearest cloud point of path.point(dy) takes the colour; dy += 1; } */
+        auto samples = [](double miny, double maxy) {
+            std::vector<double> q;
+            for (double dy = miny; dy < maxy; dy += 1) q.push_back(dy);
+            return q;
+        };
+        auto paint = [&](const std::vector<double> &xyz, const unsigned char rgb[3]) {
+            std::vector<float> qf(xyz.begin(), xyz.end());
+            std::vector<int> nn(qf.size() / 3, -1);
+            if (nn.empty() || ppp_nearest(h_, qf.data(), nn.size(), nn.data()) != PPP_OK) return;
+            for (int id : nn) if (id >= 0 && (size_t)id < n) for (int c = 0; c < 3; ++c) crgb[3 * (size_t)id + c] = rgb[c];
+        };
+        /* painting order: by the slice's step in its chain when the boundaries are painted too, else as the slices stand */
+        std::vector<std::pair<int, int>> order;
         for (int s = 0; s < S; ++s) {
+            int step = s;
+            if (with_boundaries && ppp_get_boundary(h_, s, nullptr, nullptr, nullptr, 0, nullptr, &step) != PPP_OK) step = s;
+            order.push_back(std::make_pair(step, s));
+        }
+        if (with_boundaries) std::sort(order.begin(), order.end());
+        std::vector<std::vector<float>> slice_nodes(S > 0 ? S : 0);
+        const unsigned char green[3] = {0, 255, 0};
+        size_t painted_boundaries = 0;
+        for (const auto &os : order) {
+            const int s = os.second;
+            if (with_boundaries) {
+                size_t mb = 0;
+                if (ppp_get_boundary(h_, s, nullptr, nullptr, nullptr, 0, &mb, nullptr) == PPP_OK && mb >= 3) {
+                    std::vector<double> by(mb), bx(mb), bz(mb);
+                    ppp_spline sp = nullptr;
+                    if (ppp_get_boundary(h_, s, by.data(), bx.data(), bz.data(), mb, &mb, nullptr) == PPP_OK &&
+                        ppp_spline_create(device_from_env(), mb, by.data(), bx.data(), bz.data(), &sp) == PPP_OK) {
+                        const std::vector<double> q = samples(by.front(), by.back());
+                        std::vector<double> xyz(3 * q.size());
+                        if (!q.empty() && ppp_spline_eval(sp, q.data(), q.size(), xyz.data()) == PPP_OK) { paint(xyz, green); ++painted_boundaries; }
+                        ppp_spline_destroy(sp);
+                    }
+                }
+            }
             size_t m = 0;
             if (ppp_get_nodes(h_, s, nullptr, nullptr, nullptr, 0, &m) != PPP_OK || m < 3) continue;
             std::vector<double> y(m), x(m), z(m);
             ppp_get_nodes(h_, s, y.data(), x.data(), z.data(), m, &m);
-            for (size_t i = 0; i < m; ++i) { nodes.push_back((float)x[i]); nodes.push_back((float)y[i]); nodes.push_back((float)z[i]); }
-            /* drawpath: dy = miny; while (dy < maxy) { nearest cloud point of path.point(dy) takes the path colour; dy += 1; } */
-            std::vector<double> q;
-            for (double dy = y.front(); dy < y.back(); dy += 1) q.push_back(dy);
+            for (size_t i = 0; i < m; ++i) { slice_nodes[s].push_back((float)x[i]); slice_nodes[s].push_back((float)y[i]); slice_nodes[s].push_back((float)z[i]); }
+            const std::vector<double> q = samples(y.front(), y.back());
             if (q.empty()) continue;
             std::vector<double> xyz(3 * q.size());
             if (ppp_eval_spline(h_, s, q.data(), q.size(), xyz.data()) != PPP_OK) continue;
-            std::vector<float> qf(xyz.begin(), xyz.end());
-            std::vector<int> nn(q.size(), -1);
-            if (ppp_nearest(h_, qf.data(), q.size(), nn.data()) != PPP_OK) continue;
-            for (int id : nn) if (id >= 0 && (size_t)id < n) for (int c = 0; c < 3; ++c) crgb[3 * (size_t)id + c] = path_rgb[c];
+            paint(xyz, path_rgb);
         }
+        for (int s = 0; s < S; ++s) nodes.insert(nodes.end(), slice_nodes[s].begin(), slice_nodes[s].end()); /* other_cloud: in slice order */
+        if (with_boundaries) std::printf("show(): %zu boundary curves painted\n", painted_boundaries);
         const size_t nn_ = nodes.size() / 3;
         std::vector<float> all(nodes);
         all.insert(all.end(), cloud.begin(), cloud.begin() + 3 * n);

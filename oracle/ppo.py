@@ -91,6 +91,7 @@ def lib():
         L.ppo_gen_path.argtypes = [vp]
         L.ppo_num_slices.argtypes = [vp]
         L.ppo_get_nodes.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+        L.ppo_get_boundary.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
         L.ppo_get_slice_indices.argtypes = [vp, C.c_int, ip, C.c_int]
         L.ppo_eval_spline.argtypes = [vp, C.c_int, dp, C.c_int, dp]
         L.ppo_get_path.argtypes = [vp]
@@ -214,6 +215,14 @@ class Oracle:
         m = self.L.ppo_get_nodes(self.h, s, None, None, None, 0)
         y = np.empty(m); x = np.empty(m); z = np.empty(m)
         self.L.ppo_get_nodes(self.h, s, _d(y), _d(x), _d(z), m)
+        return y, x, z
+
+    def boundary(self, s):
+        """knots (y, x, z) of the boundary spline slice s was adjusted against; empty arrays when there is none"""
+        m = self.L.ppo_get_boundary(self.h, s, None, None, None, 0)
+        y = np.empty(m); x = np.empty(m); z = np.empty(m)
+        if m:
+            self.L.ppo_get_boundary(self.h, s, _d(y), _d(x), _d(z), m)
         return y, x, z
 
     def slice_indices(self, s):

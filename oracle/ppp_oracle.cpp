@@ -901,6 +901,7 @@ struct ppo_handle {
     std::vector<float> px;
     std::vector<std::vector<int>> slice_idx;
     std::vector<Spline> path_set;
+    std::vector<Spline> boundary_set; /* [s]: the boundary slice s was adjusted against (dynamic adjustment; empty = none) */
     std::vector<std::array<float, 6>> wp, wp_pre, wp_smooth;
     std::vector<std::array<float, 3>> wp_xyz;
     std::vector<std::array<float, 4>> wp_normal;
@@ -1332,12 +1333,13 @@ struct ppo_handle {
     int adjust_all()
     {
         int S = (int)path_set.size();
+        boundary_set.assign(S, Spline());
         auto chain = [&](int from, int to, int dir, int key) -> int {
             Spline boundary;
             bool have_boundary = false;
             for (int s = from; s != to; s += dir) {
                 const Spline &pre = path_set[s - dir];
-                if (compute_boundary(pre, boundary, key)) have_boundary = true;
+                if (compute_boundary(pre, boundary, key)) { have_boundary = true; boundary_set[s] = boundary; } /* drawpath(*boundary, 0,255,0), :321-322 */
                 if (!have_boundary) return -(1 + s); /* the reference would use an unconstructed Spline */
                 if (dynamic_adjust_path(path_set[s], boundary, key) < 0) return -(1 + s);
             }
@@ -1364,6 +1366,7 @@ struct ppo_handle {
             for (int s = 1; s < S; ++s) {
                 Spline boundary;
                 if (!compute_boundary(path_set[s - 1], boundary, 1)) continue;
+                boundary_set[s] = boundary;
                 if (dynamic_adjust_path(path_set[s], boundary, 1, true) < 0) return -(1 + s);
             }
             return 0;
@@ -1845,6 +1848,15 @@ int ppo_num_slices(const ppo_handle *h) { return (int)h->path_set.size(); }
 int ppo_get_nodes(const ppo_handle *h, int s, double *y, double *x, double *z, int cap)
 {
     const Spline &sp = h->path_set[s];
+    int m = (int)sp.y.size();
+    for (int i = 0; i < m && i < cap; ++i) { y[i] = sp.y[i]; x[i] = sp.x[i]; z[i] = sp.z[i]; }
+    return m;
+}
+/* the boundary spline slice s was adjusted against (the curve thread_worker paints green before it adjusts the slice); 0 knots: none */
+int ppo_get_boundary(const ppo_handle *h, int s, double *y, double *x, double *z, int cap)
+{
+    if (s < 0 || s >= (int)h->boundary_set.size()) return 0;
+    const Spline &sp = h->boundary_set[s];
     int m = (int)sp.y.size();
     for (int i = 0; i < m && i < cap; ++i) { y[i] = sp.y[i]; x[i] = sp.x[i]; z[i] = sp.z[i]; }
     return m;

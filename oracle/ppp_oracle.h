@@ -85,6 +85,8 @@ int ppo_insert_point(ppo_handle *h, const int *indices, int n, float plane_x,
 int ppo_gen_path(ppo_handle *h);
 int ppo_num_slices(const ppo_handle *h);
 int ppo_get_nodes(const ppo_handle *h, int s, double *y, double *x, double *z, int cap);
+/* the boundary spline (compute_boundary, path_dynamic_alg.cpp:183-235) slice s was adjusted against; returns its knot count, 0 = none */
+int ppo_get_boundary(const ppo_handle *h, int s, double *y, double *x, double *z, int cap);
 int ppo_get_slice_indices(const ppo_handle *h, int s, int *out, int cap);
 /* Spline::point for slice s; returns 0, or -1 if any y is outside [miny, bigy] (GSL_EDOM) */
 int ppo_eval_spline(const ppo_handle *h, int s, const double *y, int k, double *xyz);

@@ -446,8 +446,12 @@ __device__ inline DynChain dyn_chain(int walk, int chain, int t, int centre, int
 
 struct DynBuffers {
     float4 *bnd_pts;  /* [chain][maxNB]  bx by bz in_loop                      */
-    double *bnd_knots; /* [chain][3][maxNB + 2]  y, x, z of the boundary spline */
+    double *bnd_knots; /* [slot][3][maxNB + 2]  y, x, z of a boundary spline; slot = the slice adjusted against it (every boundary of the
+                          pass is kept: drawpath(*boundary, ...) of the viewer, ppp_get_boundary) or, keep_all == 0, the chain */
     int *bnd_n;        /* [chain] knots of the current boundary (0 = none yet)  */
+    int *bnd_slot;     /* [chain] the slot that boundary is in                  */
+    int *bnd_all_n;    /* [slice] knots of the boundary in the slice's slot (0 = compute_boundary gave none at that step) */
+    int keep_all;
     float4 *adj_pts;   /* [chain][maxNA]  y x z valid                           */
     int maxNB, maxNA;
     /* what k_dyn_first_eval leaves for every node i of every slice s, at [s][i] (it does not depend on the chain) */
@@ -789,7 +793,8 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
     double *ly = (double *)(s_raw + dyn_scratch_bytes(Bf.maxNB)), *lx = ly + capB + 2;
-    double *gy = Bf.bnd_knots + (size_t)chain * 3 * (Bf.maxNB + 2), *gx = gy + (Bf.maxNB + 2), *gz = gx + (Bf.maxNB + 2);
+    const size_t slot_doubles = 3 * ((size_t)Bf.maxNB + 2);
+    double *gy = Bf.bnd_knots + (size_t)(Bf.keep_all ? c.s : chain) * slot_doubles, *gx = gy + (Bf.maxNB + 2), *gz = gx + (Bf.maxNB + 2);
     const double *ky = gy, *kx = gx;
     int nb;
     {
@@ -799,7 +804,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
         sc.mark(14);
         if (node_number <= 2) { /* compute_boundary returns 0: the previous boundary stays; v1 has none then (Path_Generation.cpp:589-592) */
             if (walk == 3) { nb = 0; if (blockIdx.x == 0 && threadIdx.x == 0) Bf.bnd_n[chain] = 0; }
-            else nb = Bf.bnd_n[chain];
+            else { nb = Bf.bnd_n[chain]; ky = Bf.bnd_knots + (size_t)Bf.bnd_slot[chain] * slot_doubles; kx = ky + (Bf.maxNB + 2); }
             __syncthreads(); /* the scratch becomes the waves' search areas */
         } else {
             const bool keep_copy = blockIdx.x == 0;
@@ -817,6 +822,8 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
                     gx[0] = lx[0]; gy[0] = ly[0]; gz[0] = gz[1];
                     gx[idx + 1] = lx[idx + 1]; gy[idx + 1] = ly[idx + 1]; gz[idx + 1] = gz[idx];
                     Bf.bnd_n[chain] = node_number + 2;
+                    Bf.bnd_slot[chain] = Bf.keep_all ? c.s : chain;
+                    if (Bf.keep_all) Bf.bnd_all_n[c.s] = node_number + 2;
                 }
             }
             __syncthreads();

@@ -131,6 +131,7 @@ struct ppp_handle_s {
     DevBuf<double> dyn_bnd_knots;
     DevBuf<int> dyn_bnd_n;
     int dyn_maxNB = 1, dyn_maxNA = 1;
+    bool dyn_keep_all = false;
     bool normals_valid = false;
     DevBuf<int> node_start, node_cnt, band_cnt;
     DevBuf<int> wp_cnt, wp_off, tail, slice_wpcnt;
@@ -369,7 +370,11 @@ int ensure_dynamic_buffers(ppp_handle h)
 {
     HIPCHK(h, h->normals4.ensure(std::max<size_t>(h->n, 1)));
     HIPCHK(h, h->dyn_bnd_pts.ensure(2 * (size_t)h->dyn_maxNB)); HIPCHK(h, h->dyn_adj_pts.ensure(2 * (size_t)h->dyn_maxNA));
-    HIPCHK(h, h->dyn_bnd_knots.ensure(2 * 3 * ((size_t)h->dyn_maxNB + 2))); HIPCHK(h, h->dyn_bnd_n.ensure(2));
+    /* every boundary of a pass is kept (a slot per slice) for ppp_get_boundary -- the curves the reference's viewer paints green --
+       unless that is more than 1 GiB: then the chains' two current ones only */
+    const size_t slot_doubles = 3 * ((size_t)h->dyn_maxNB + 2), nslots = (size_t)std::max(h->S_cap, 2);
+    h->dyn_keep_all = nslots * slot_doubles * sizeof(double) <= ((size_t)1 << 30);
+    HIPCHK(h, h->dyn_bnd_knots.ensure((h->dyn_keep_all ? nslots : 2) * slot_doubles)); HIPCHK(h, h->dyn_bnd_n.ensure(4 + nslots));
     const size_t nfirst = (size_t)std::max(h->S_cap, 1) * h->dyn_maxNA;
     if (nfirst > ((size_t)1 << 27)) /* 56 bytes a node: 7.5 GB */
         return fail(h, PPP_ERR_CAPACITY, "dynamic adjustment: slices x nodes per slice beyond 2^27");
@@ -873,9 +878,9 @@ int enqueue_dynamic(ppp_handle h)
     int rc = enqueue_normals(h);
     if (rc) return rc;
     const DynParams D = dyn_params(h);
-    DynBuffers Bf{h->dyn_bnd_pts.p, h->dyn_bnd_knots.p, h->dyn_bnd_n.p, h->dyn_adj_pts.p, h->dyn_maxNB, h->dyn_maxNA,
-                  h->dyn_first_ab.p, h->dyn_first_node.p, h->dyn_first_snap.p};
-    HIPCHK(h, hipMemsetAsync(h->dyn_bnd_n.p, 0, 2 * sizeof(int), h->stream));
+    DynBuffers Bf{h->dyn_bnd_pts.p, h->dyn_bnd_knots.p, h->dyn_bnd_n.p, h->dyn_bnd_n.p + 2, h->dyn_bnd_n.p + 4, h->dyn_keep_all ? 1 : 0,
+                  h->dyn_adj_pts.p, h->dyn_maxNB, h->dyn_maxNA, h->dyn_first_ab.p, h->dyn_first_node.p, h->dyn_first_snap.p};
+    HIPCHK(h, hipMemsetAsync(h->dyn_bnd_n.p, 0, (4 + (size_t)std::max(h->S_cap, 2)) * sizeof(int), h->stream));
     const int S = h->S_cap, walk = h->P.walk;
     const int centre = walk == PPP_WALK_CENTER_INT ? host_centre_index(h) : 0;
     const int nchains = walk == PPP_WALK_CENTER_INT ? 2 : 1;
@@ -2505,6 +2510,36 @@ int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t c
             if (z) z[i] = (double)fz[i];
         }
     }
+    return PPP_OK;
+}
+
+int ppp_get_boundary(ppp_handle h, int s, double *y, double *x, double *z, size_t cap, size_t *m, int *step)
+{
+    int rc = ensure_ready(h, true, false);
+    if (rc) return rc;
+    if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
+    if (m) *m = 0;
+    if (step) *step = -1;
+    if (!h->P.dynamic_adjustment) return PPP_OK;
+    /* the step of its chain slice s is adjusted in (the chains of enqueue_dynamic) */
+    const int walk = h->P.walk;
+    int t = -1;
+    if (walk == PPP_WALK_CENTER_INT) {
+        const int centre = host_centre_index(h);
+        t = s < centre ? centre - 1 - s : (s > centre ? s - centre - 1 : -1);
+    } else t = s - 1;
+    if (step) *step = t;
+    if (t < 0) return PPP_OK;
+    if (!h->dyn_keep_all || !h->dyn_bnd_n.p) return fail(h, PPP_ERR_CAPACITY, "the boundaries of this pass were not kept (more than 1 GiB of them)");
+    int cnt = 0;
+    HIPCHK(h, copy_sync(h, &cnt, h->dyn_bnd_n.p + 4 + s, 4, hipMemcpyDeviceToHost));
+    if (cnt < 0 || cnt > h->dyn_maxNB + 2) return fail(h, PPP_ERR_HIP, "boundary table corrupt");
+    if (m) *m = (size_t)cnt;
+    const size_t k = std::min(cap, (size_t)cnt), row = (size_t)h->dyn_maxNB + 2;
+    const double *base = h->dyn_bnd_knots.p + (size_t)s * 3 * row;
+    if (k && y) HIPCHK(h, copy_sync(h, y, base, k * 8, hipMemcpyDeviceToHost));
+    if (k && x) HIPCHK(h, copy_sync(h, x, base + row, k * 8, hipMemcpyDeviceToHost));
+    if (k && z) HIPCHK(h, copy_sync(h, z, base + 2 * row, k * 8, hipMemcpyDeviceToHost));
     return PPP_OK;
 }
 

@@ -74,7 +74,7 @@ EXPORTS = [
     "ppp_set_cloud", "ppp_set_cloud_device", "ppp_num_points", "ppp_gen_path_async", "ppp_get_path_async", "ppp_run_async",
     "ppp_sync", "ppp_failed_slice", "ppp_num_slices", "ppp_num_waypoints", "ppp_get_waypoints",
     "ppp_get_waypoints_device", "ppp_copy_waypoints_to_device", "ppp_get_tail_index", "ppp_minmax", "ppp_get_slice_positions",
-    "ppp_get_slice_indices", "ppp_get_nodes", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
+    "ppp_get_slice_indices", "ppp_get_nodes", "ppp_get_boundary", "ppp_eval_spline", "ppp_ranged_x_index", "ppp_insert_point",
     "ppp_normals_at", "ppp_estimate_normals", "ppp_area2cloud", "ppp_nearest", "ppp_get_stage", "ppp_smooth_sweeps", "ppp_enable_timing",
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
@@ -146,6 +146,7 @@ def lib():
         L.ppp_get_slice_positions.argtypes = [vp, fp, sz, szp]
         L.ppp_get_slice_indices.argtypes = [vp, C.c_int, ip, sz, szp]
         L.ppp_get_nodes.argtypes = [vp, C.c_int, dp, dp, dp, sz, szp]
+        L.ppp_get_boundary.argtypes = [vp, C.c_int, dp, dp, dp, sz, szp, C.POINTER(C.c_int)]
         L.ppp_eval_spline.argtypes = [vp, C.c_int, dp, sz, dp]
         L.ppp_ranged_x_index.argtypes = [vp, C.c_int, ip, sz, szp]
         L.ppp_insert_point.argtypes = [vp, ip, sz, C.c_float, dp, dp, dp, sz, szp]
@@ -560,6 +561,15 @@ class Engine:
         y = np.empty(k); x = np.empty(k); z = np.empty(k)
         self._chk(self.L.ppp_get_nodes(self.h, int(s), _d(y), _d(x), _d(z), m.value, C.byref(m)))
         return y[:m.value], x[:m.value], z[:m.value]
+
+    def boundary(self, s):
+        """(y, x, z, step): knots of the boundary spline slice s was adjusted against (empty: none) and the slice's step in its chain"""
+        m = C.c_size_t(); step = C.c_int()
+        self._chk(self.L.ppp_get_boundary(self.h, int(s), None, None, None, 0, C.byref(m), C.byref(step)))
+        k = max(m.value, 1)
+        y = np.empty(k); x = np.empty(k); z = np.empty(k)
+        self._chk(self.L.ppp_get_boundary(self.h, int(s), _d(y), _d(x), _d(z), m.value, C.byref(m), C.byref(step)))
+        return y[:m.value], x[:m.value], z[:m.value], step.value
 
     def eval_spline(self, s, y):
         y = np.ascontiguousarray(y, np.float64)

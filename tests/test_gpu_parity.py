@@ -438,6 +438,54 @@ def test_show_dump_and_timing_csv_of_the_connect_planner(engine_mod, oracle_mod,
     assert set(painted.tolist()) == want
 
 
+def test_show_dump_paints_the_boundary_curves_of_the_dynamic_adjustment(engine_mod, oracle_mod, tmp_path):
+    """thread_worker paints every boundary curve green before it adjusts a slice against it (drawpath(*boundary, 0,255,0),
+    path_dynamic_alg.cpp:320-322), then the adjusted path blue (:330): the dump of examples/connect with
+    Dynamic_adjustment = true holds both, painted in the chains' order (a later curve recolours an earlier one where they
+    share a cloud point).  The boundaries themselves (ppp_get_boundary) are the oracle's, knot for knot."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("small_40k")
+    pcd = str(tmp_path / "w.pcd")
+    engine_mod.save_pcd(pcd, pts)
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\nSmooth = false\n"
+                    "Alignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = true\n" % str(tmp_path / "wp.txt"))
+    dump = str(tmp_path / "show.pcd")
+    r = subprocess.run([os.path.join(root, "examples", "connect"), pcd], env=dict(os.environ, PPP_CONFIG=str(conf), PPP_SHOW_PCD=dump),
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    xyz, rgb = _read_rgb_pcd(dump)
+    kw = dict(tool_radius=6.0, walk=1, dynamic_adjustment=1)
+    e = engine_mod.Engine(0, **kw); e.set_cloud(pts); S = e.gen_path()
+    o = oracle_mod.Oracle(pts, **kw); assert o.gen_path() == S
+    nk = sum(len(e.nodes(s)[0]) for s in range(S))
+    assert len(xyz) == nk + len(pts)
+    crgb = rgb[nk:]
+    want = np.full(len(pts), 0xFFFFFF, np.uint32)
+    steps, nb = [], 0
+    for s in range(S):
+        by, bx, bz, step = e.boundary(s)
+        oy, ox, oz = o.boundary(s)
+        assert np.array_equal(by, oy) and np.array_equal(bx, ox) and np.array_equal(bz, oz), s
+        steps.append((step, s))
+    assert sorted(st for st, _ in steps)[:2] == [-1, 0]                  # one start slice, the chains go out from it
+    for step, s in sorted(steps):
+        by, bx, bz, _ = e.boundary(s)
+        if len(by) >= 3:
+            nb += 1
+            rc, p = engine_mod.Spline(by, bx, bz).point(np.arange(by[0], by[-1], 1.0))
+            assert rc == 0
+            want[e.nearest(p.astype(np.float32))] = 0x00FF00
+        ky = e.nodes(s)[0]
+        rc, p = e.eval_spline(s, np.arange(ky[0], ky[-1], 1.0))
+        want[e.nearest(p.astype(np.float32))] = 0x0000FF
+    assert nb == S - 1 and "%d boundary curves painted" % nb in r.stdout
+    assert np.array_equal(crgb, want)
+    assert (want == 0x00FF00).sum() > 100 and (want == 0x0000FF).sum() > 100
+
+
 def test_robot_path_class_end_to_end(engine_mod, oracle_mod, tmp_path):
     """include/robot_path.h (class RobotPath, robot_path.h:58-98; behaviour of the July snapshot path_connect_ex0720.cpp): the
     three-argument constructor, single-direction float walk from min.x + Radius, +-5 trim, no first/last drop, no
@@ -706,6 +754,12 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, name, walk):
         if len(gy) != len(oy) or not (np.array_equal(gy, oy) and np.array_equal(gx, ox) and np.array_equal(gz, oz)):
             bad += 1
     assert bad == 0
+    nb = 0
+    for s in range(S):                                                   # the boundary every slice was adjusted against
+        by, bx, bz, step = e.boundary(s); oy, ox, oz = o.boundary(s)
+        assert np.array_equal(by, oy) and np.array_equal(bx, ox) and np.array_equal(bz, oz), s
+        nb += len(by) >= 3
+    assert nb >= S - 2
     Wo = o.get_path(); W = e.get_path()
     assert W == Wo
     wp, owp = e.waypoints(), o.waypoints()
