@@ -535,7 +535,7 @@ int plan_window(ppp_handle h, int S, double per)
     }
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
     HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
-    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * WIN_CNT_STRIDE, h->stream)); /* the passes' counters (a line each): every pass leaves them cleared again */
+    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * WIN_CNT_STRIDE, h->stream)); /* the windows' counters: every pass leaves them cleared again */
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->win_path = true;
     if (getenv("PPP_WIN_DEBUG"))
