@@ -165,6 +165,25 @@ struct ppp_handle_s {
 
     DevMeta hmeta;
     DevMeta *hmeta_pinned = nullptr; /* the hot calls end with an async copy of the device meta into it */
+    /* a new cloud's plan without the host in the middle: k_ingest_minmax's last workgroup reduces the bounds and walks the slices,
+       k_win_census_auto counts the windows, both write their results to pinned memory (PlanAuto + plane table + census) */
+    DevBuf<int> plan_ticket;         /* [2], zero between launches */
+    DevBuf<PlanAuto> plan_auto;
+    bool auto_valid = false;         /* the pinned census belongs to the cloud just set, with auto_S slices and auto_pad */
+    int auto_S = 0;
+    float auto_pad = 0.f;
+    bool slab_cnt_used = true;       /* a slab-path pass has been enqueued since the slab histogram was last cleared by the plan */
+    char *pin = nullptr;             /* pinned staging for the small copies of the plan (bounds partials, plane table, census) */
+    size_t pin_bytes = 0;
+    hipError_t ensure_pin(size_t bytes)
+    {
+        if (bytes <= pin_bytes) return hipSuccess;
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_bytes = 0; }
+        const size_t want = std::max<size_t>(bytes, 128 * 1024);
+        hipError_t e = hipHostMalloc((void **)&pin, want, hipHostMallocDefault);
+        if (e == hipSuccess) pin_bytes = want;
+        return e;
+    }
     bool meta_in_flight = false;
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
     float *out2 = nullptr;          /* batched form: the emitting launch also writes the list here (at most out2_cap rows) */
@@ -200,7 +219,7 @@ struct ppp_handle_s {
         X.release(); Y.release(); Z.release(); Xp.release(); Yp.release(); Zp.release(); part_idx.release(); unsorted4.release(); sorted4.release();
         slab_cnt.release(); slab_start.release(); slab_cursor.release(); coarse_cursor.release(); slab_ytab.release(); slab_xmin.release(); slab_xmax.release();
         meta.release(); px.release(); lo.release(); hi.release(); node_x.release(); node_y.release(); node_z.release();
-        normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); dyn_first_ab.release(); dyn_first_snap.release(); dyn_first_node.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release();
+        normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); dyn_first_ab.release(); dyn_first_snap.release(); dyn_first_node.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release(); plan_ticket.release(); plan_auto.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
@@ -208,6 +227,7 @@ struct ppp_handle_s {
         drop_graph();
         drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
+        if (pin) (void)hipHostFree(pin);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
         if (back) { delete back; back = nullptr; }
@@ -407,6 +427,10 @@ int enqueue_normals(ppp_handle h)
     return PPP_OK;
 }
 
+/* pinned layout of the plan results of a new cloud */
+constexpr size_t PIN_REC0 = 0, PIN_REC1 = 64, PIN_PX = 128, PIN_CENSUS = PIN_PX + sizeof(float) * WIN_AUTO_SCAP,
+                 PIN_AUTO_BYTES = PIN_CENSUS + sizeof(int) * 3 * WIN_AUTO_SCAP;
+
 /* Threads of a slice workgroup for a launch of `wgs` of them.  The kernel holds 116 VGPRs, i.e. 16 waves per CU.  While a
    launch has fewer workgroups than the device has room for, a workgroup is as wide as its work can use (a left point per
    thread in the pairing, 4 .. 8 lanes per waypoint in the pose stage): the launch ends with its slowest workgroup.  A launch
@@ -468,9 +492,21 @@ int plan_window(ppp_handle h, int S, double per)
     /* exact populations of the windows of this handle's slices and of their band sides: one pass over the x coordinates at plan time */
     const int n_src = h->use_part ? h->n_part : (int)h->n;
     HIPCHK(h, h->win_px.ensure((size_t)S)); HIPCHK(h, h->win_cnt.ensure(std::max<size_t>(3, WIN_CNT_STRIDE) * (size_t)S));
-    HIPCHK(h, hipMemcpyAsync(h->win_px.p, px.data(), sizeof(float) * (size_t)S, hipMemcpyHostToDevice, h->stream));
+    /* a cloud that has just been set brought its census along (refresh_bounds_and_plan): taken when the device's walk, slice count
+       and pad are this plan's, bit for bit */
+    const bool from_auto = h->auto_valid && !h->use_part && h->auto_S == S && S <= WIN_AUTO_SCAP && h->pin &&
+                           memcmp(&h->auto_pad, &pad, sizeof(float)) == 0 && memcmp(h->pin + PIN_PX, px.data(), sizeof(float) * (size_t)S) == 0;
+    h->auto_valid = false;
+    int *census = nullptr;
+    if (from_auto) census = (int *)(h->pin + PIN_CENSUS);
+    else {
+    HIPCHK(h, h->ensure_pin(sizeof(float) * 4 * (size_t)S));
+    float *px_pin = (float *)h->pin;
+    census = (int *)(px_pin + S);
+    memcpy(px_pin, px.data(), sizeof(float) * (size_t)S);
+    memset(census, 0, sizeof(int) * 3 * (size_t)S);
+    HIPCHK(h, hipMemcpyAsync(h->win_px.p, px_pin, sizeof(float) * (size_t)S, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * 3 * (size_t)S, h->stream));
-    std::vector<int> census(3 * (size_t)S, 0);
     if (n_src > 0) {
         const float *cx = h->use_part ? h->Xp.p : h->X.p;
         if (S <= 4096) /* the counters fit a workgroup's LDS: a few hundred workgroups, each flushing its non-zero counters once */
@@ -479,9 +515,10 @@ int plan_window(ppp_handle h, int S, double per)
         else
             LAUNCH(h, "k_win_census", k_win_census<false>, std::max(1, std::min((n_src + 255) / 256, 4096)), 256, 0, cx, n_src,
                    h->win_px.p, S, px[0], 1.0f / (float)step, pad, h->win_cnt.p, h->win_cnt.p + S, h->win_cnt.p + 2 * (size_t)S);
-        HIPCHK(h, hipMemcpyAsync(census.data(), h->win_cnt.p, sizeof(int) * 3 * (size_t)S, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(census, h->win_cnt.p, sizeof(int) * 3 * (size_t)S, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     int max_w = 0, max_el = 0;
     for (int s2 = h->sb; s2 < h->se; ++s2) { max_w = std::max(max_w, census[s2]); max_el = std::max(max_el, census[(size_t)S + s2]); }
     const double expect = std::max(1, max_w);
@@ -535,8 +572,8 @@ int plan_window(ppp_handle h, int S, double per)
     }
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
     HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
-    HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * WIN_CNT_STRIDE, h->stream)); /* the windows' counters: every pass leaves them cleared again */
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!from_auto) /* the windows' counters: every pass leaves them cleared again (in stream order ahead of the first pass: no wait); the census that came with the cloud has cleared its own */
+        HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * std::max<size_t>(3, WIN_CNT_STRIDE), h->stream));
     h->win_path = true;
     if (getenv("PPP_WIN_DEBUG"))
         fprintf(stderr, "[ppp] window plan: S %d [%d,%d) pad %.2f capw %d cap_el %d NBc %d (throughput %d) threads %d ppt %d lds %zu B max window %d max left side %d\n",
@@ -746,12 +783,16 @@ int make_plan(ppp_handle h)
     h->node_cap = std::max(16, (int)std::min(2.0e9, overlap * (double)n + 16));
 
     HIPCHK(h, h->unsorted4.ensure(n)); HIPCHK(h, h->sorted4.ensure(n));
+    const int *slab_cnt_before = h->slab_cnt.p;
     HIPCHK(h, h->slab_cnt.ensure(B)); HIPCHK(h, h->slab_start.ensure(B + 1)); HIPCHK(h, h->slab_cursor.ensure(B));
     HIPCHK(h, h->coarse_cursor.ensure((B >> SCAT_COARSE_SHIFT) + 2));
     HIPCHK(h, h->slab_ytab.ensure((size_t)B * (YTB + 1)));
     /* one scatter pass leaves runs of chunk / B points: below ~4 points per run the second pass pays for itself */
     h->two_pass_scatter = B >= 4096 && h->n_range >= 3000000;
-    HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream)); /* every run leaves it cleared again */
+    if (h->slab_cnt_used || h->slab_cnt.p != slab_cnt_before) { /* every run leaves it cleared again: cleared here after a slab-path pass (one that broke off may not have) and when new */
+        HIPCHK(h, hipMemsetAsync(h->slab_cnt.p, 0, sizeof(int) * (size_t)B, h->stream));
+        h->slab_cnt_used = false;
+    }
     HIPCHK(h, h->slab_xmin.ensure(B)); HIPCHK(h, h->slab_xmax.ensure(B));
     HIPCHK(h, h->px.ensure(h->S_cap)); HIPCHK(h, h->lo.ensure(h->S_cap)); HIPCHK(h, h->hi.ensure(h->S_cap));
     if (h->P.dynamic_adjustment) {
@@ -796,6 +837,7 @@ int enqueue_index(ppp_handle h)
     const float *sX = h->use_part ? h->Xp.p : h->X.p, *sY = h->use_part ? h->Yp.p : h->Y.p, *sZ = h->use_part ? h->Zp.p : h->Z.p;
     const int *idmap = h->use_part ? h->part_idx.p : ((h->part_given && h->part_has_idx) ? h->part_idx.p : nullptr);
     DevParams D = dev_params(h);
+    h->slab_cnt_used = true;
     D.keep_run_state = (h->win_path && h->gen_done) ? 1 : 0; /* an API mirror asks for the slab index behind a finished window pass */
     size_t hist_lds = sizeof(int) * (size_t)h->B;
     /* slab grid from the bounds cached when the cloud was set (identical to what k_minmax finds) */
@@ -1021,33 +1063,84 @@ int slice_lds_ok(ppp_handle h, int capb)
     return std::max(slice_lds_bytes(capb), slice_kd_bytes(capb)) + 1024 <= (size_t)h->max_lds;
 }
 
-/* cache the bounds of the resident cloud for the plan (sizing only; the hot path recomputes them on device), then plan */
-int refresh_bounds_and_plan(ppp_handle h)
+/* workgroups of the bounds pass over n points (k_minmax<false> / k_ingest_minmax) */
+int bounds_grid(size_t n) { return std::max(1, std::min(((int)n / 4 + 255) / 256, 2048)); }
+
+/* may the window path apply to the next plan, as far as the parameters say (plan_window decides with the bounds in hand)? */
+bool window_params_ok(const ppp_handle h)
+{
+    return h->win_allowed && !h->win_disabled && !getenv("PPP_NO_WINDOW_PATH") && h->P.pairing == PPP_PAIR_KD && !h->P.dynamic_adjustment &&
+           !h->aligned && !h->big_path && (int)(h->P.tool_radius * 2) >= 1;
+}
+
+/* cache the bounds of the resident cloud for the plan (sizing only; the hot path recomputes them on device), then plan.
+   raw != nullptr: the cloud has just arrived and is converted in the same pass (k_ingest_minmax); the bounds come back reduced, in
+   pinned memory, and where the window path may apply its census follows in the same stream: two launches, one wait, no copy or
+   fill command (each of those costs the host 10-20 us here; this path was 150 us for 30 us of kernels) */
+int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stride_bytes = 0)
 {
     const size_t n = h->n;
+    h->auto_valid = false;
+    h->win_disabled = false;
+    h->big_path = false; /* (the plan turns the arena passes on again where this cloud needs them) */
     {
-        int g = std::max(1, std::min(((int)n / 4 + 255) / 256, 2048));
+        const int g = bounds_grid(n);
         HIPCHK(h, h->mm_part.ensure(g));
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
-                           (int *)nullptr, 0.f, 0.f, (int *)nullptr);
-        HIPCHK(h, hipGetLastError());
-        std::vector<MinMaxPart> parts(g);
-        HIPCHK(h, hipMemcpyAsync(parts.data(), h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        h->h_nvalid = 0;
-        for (int d = 0; d < 3; ++d) { h->h_mn[d] = INFINITY; h->h_mx[d] = -INFINITY; }
-        for (auto &r : parts) {
-            h->h_nvalid += r.cnt;
-            for (int d = 0; d < 3; ++d) { h->h_mn[d] = std::min(h->h_mn[d], r.mn[d]); h->h_mx[d] = std::max(h->h_mx[d], r.mx[d]); }
+        if (raw) {
+            HIPCHK(h, h->ensure_pin(PIN_AUTO_BYTES));
+            if (!h->plan_ticket.p) {
+                HIPCHK(h, h->plan_ticket.ensure(2)); HIPCHK(h, h->plan_auto.ensure(1));
+                HIPCHK(h, hipMemsetAsync(h->plan_ticket.p, 0, 2 * sizeof(int), h->stream));
+            }
+            const bool census = window_params_ok(h) && !h->part_given && (h->P.walk >= 0 && h->P.walk <= 4);
+            if (census && (h->win_px.cap < WIN_AUTO_SCAP || h->win_cnt.cap < 3 * (size_t)WIN_AUTO_SCAP)) {
+                HIPCHK(h, h->win_px.ensure(WIN_AUTO_SCAP)); HIPCHK(h, h->win_cnt.ensure(3 * (size_t)WIN_AUTO_SCAP));
+                HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * 3 * (size_t)WIN_AUTO_SCAP, h->stream)); /* every census and every pass leaves them cleared */
+            }
+            PlanAutoArgs PA;
+            PA.ticket = h->plan_ticket.p; PA.dev = h->plan_auto.p; PA.host = (PlanAuto *)(h->pin + PIN_REC0);
+            PA.walk = census ? h->P.walk : -1; PA.tool_radius = h->P.tool_radius; PA.normal_radius = h->P.normal_radius;
+            PA.px = h->win_px.p; PA.px_cap = census ? WIN_AUTO_SCAP : 0;
+            PlanAuto *rec0 = (PlanAuto *)(h->pin + PIN_REC0), *rec1 = (PlanAuto *)(h->pin + PIN_REC1);
+            rec0->S = -2; rec1->census = 0; rec1->S = -2;
+            hipLaunchKernelGGL(k_ingest_minmax, dim3(g), dim3(MM_T), 0, h->stream, raw, stride_bytes, (int)n, h->P.change_range, h->X.p, h->Y.p,
+                               h->Z.p, h->mm_part.p, PA);
+            HIPCHK(h, hipGetLastError());
+            if (census) {
+                const int gc = std::max(1, std::min(((int)n + 4095) / 4096, 512));
+                hipLaunchKernelGGL(k_win_census_auto, dim3(gc), dim3(256), sizeof(int) * 3 * (size_t)WIN_AUTO_SCAP, h->stream, h->X.p, (int)n,
+                                   h->win_px.p, h->plan_auto.p, 1.0f / (float)(int)(h->P.tool_radius * 2), h->win_cnt.p, h->plan_ticket.p + 1, rec1,
+                                   (float *)(h->pin + PIN_PX), (int *)(h->pin + PIN_CENSUS));
+                HIPCHK(h, hipGetLastError());
+            }
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (rec0->S == -2) return fail(h, PPP_ERR_HIP, "the bounds of the new cloud did not arrive");
+            h->h_nvalid = rec0->fin.cnt;
+            for (int d = 0; d < 3; ++d) { h->h_mn[d] = rec0->fin.mn[d]; h->h_mx[d] = rec0->fin.mx[d]; }
+            if (census && rec1->census == 1) { h->auto_valid = true; h->auto_S = rec1->S; h->auto_pad = rec1->pad; }
+        } else {
+            hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
+                               (int *)nullptr, 0.f, 0.f, (int *)nullptr);
+            HIPCHK(h, hipGetLastError());
+            /* (through pinned memory: a copy into pageable memory is staged by the runtime, ~10 us more on this critical path) */
+            HIPCHK(h, h->ensure_pin(sizeof(MinMaxPart) * (size_t)g));
+            MinMaxPart *parts = (MinMaxPart *)h->pin;
+            HIPCHK(h, hipMemcpyAsync(parts, h->mm_part.p, sizeof(MinMaxPart) * g, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->h_nvalid = 0;
+            for (int d = 0; d < 3; ++d) { h->h_mn[d] = INFINITY; h->h_mx[d] = -INFINITY; }
+            for (int q = 0; q < g; ++q) {
+                const MinMaxPart &r = parts[q];
+                h->h_nvalid += r.cnt;
+                for (int d = 0; d < 3; ++d) { h->h_mn[d] = std::min(h->h_mn[d], r.mn[d]); h->h_mx[d] = std::max(h->h_mx[d], r.mx[d]); }
+            }
         }
         if (!h->h_nvalid) for (int d = 0; d < 3; ++d) { h->h_mn[d] = 3.402823466e+38f; h->h_mx[d] = -3.402823466e+38f; }
     }
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
     h->normals_valid = false;
-    h->win_disabled = false;
-    h->big_path = false; /* (the plan turns the arena passes on again where this cloud needs them) */
     return make_plan(h);
 }
 
@@ -1060,13 +1153,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     if (h->back) { delete h->back; h->back = nullptr; }
     if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
     HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
-    if (n) {
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, raw_dev, stride_bytes, (int)n,
-                           h->P.change_range, h->X.p, h->Y.p, h->Z.p);
-        HIPCHK(h, hipGetLastError());
-    }
-    return refresh_bounds_and_plan(h);
+    return n ? refresh_bounds_and_plan(h, raw_dev, stride_bytes) : refresh_bounds_and_plan(h);
 }
 
 
@@ -1880,6 +1967,7 @@ int upload_members(ppp_handle lead, BatchGraph *bg, float *dst_dev, const size_t
         M.g_minmax = std::max(1, std::min(std::min(h->mm_grid, PPP_MM_GRID_MAX), mm_share));
         M.g_scatter = std::max(1, ((int)h->n + chunk - 1) / chunk);
         M.g_sort = h->B; M.g_slice = h->S_cap; M.g_pose = std::max(1, h->S_cap); M.g_smooth = h->sm_tiles;
+        h->slab_cnt_used = true;
         M.slab_cnt = h->slab_cnt.p; M.slab_start = h->slab_start.p; M.slab_cursor = h->slab_cursor.p; M.coarse_cursor = h->coarse_cursor.p;
         M.px = h->px.p; M.lo = h->lo.p; M.hi = h->hi.p;
         M.unsorted4 = h->unsorted4.p; M.sorted4 = h->sorted4.p; M.slab_xmin = h->slab_xmin.p; M.slab_xmax = h->slab_xmax.p;

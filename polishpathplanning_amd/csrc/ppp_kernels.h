@@ -285,6 +285,139 @@ __device__ inline int slice_walk_device(int walk, float min_x, float max_x, doub
     return 0;
 }
 
+/* k_ingest and k_minmax<false> as one pass over a new cloud: the converted coordinates are written and reduced in the same
+   registers (ppp_set_cloud*: a planner fed with a new cloud every time pays this launch on its critical path) */
+/* What the last workgroup of k_ingest_minmax leaves for the plan of a new cloud (device copy + pinned host copy): the reduced
+   bounds and, when the window path may apply, the slice walk from them (written to the plan's plane table) with the window pad --
+   so that the census of the windows can follow in the same stream without the host in between */
+struct PlanAuto {
+    MinMaxPart fin;
+    int S;       /* slices of the walk (-1: no walk asked for) */
+    float pad;   /* plan_window's pad from these bounds          */
+    int census;  /* k_win_census_auto: 1 = the counters behind this record are the census of (S, pad), 0 = it did not run */
+    int reserved;
+};
+struct PlanAutoArgs {
+    int *ticket;          /* zero between launches */
+    PlanAuto *dev, *host; /* host: pinned            */
+    int walk;             /* -1: bounds only         */
+    double tool_radius;
+    float normal_radius;
+    float *px;            /* the plan's plane table (device) */
+    int px_cap;
+};
+__global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__ raw, size_t stride, int n, int scale, float *__restrict__ X,
+                                                       float *__restrict__ Y, float *__restrict__ Z, MinMaxPart *part, PlanAutoArgs PA)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    const int step = (int)(gridDim.x * blockDim.x);
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { /* four points' reads in flight */
+            const int i = i0 + u * step;
+            if (i < n) { const float *p = (const float *)(raw + (size_t)i * stride); v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * step;
+            if (i >= n) break;
+            float x = v[u][0], y = v[u][1], z = v[u][2];
+            if (scale) { x *= 1000; y *= 1000; z *= 1000; }
+            if (!(isfinite(x) && isfinite(y) && isfinite(z))) { x = y = z = __int_as_float(0x7fc00000); }
+            X[i] = x; Y[i] = y; Z[i] = z;
+            if (x == x) {
+                mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+                mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+                mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+                cnt++;
+            }
+        }
+    }
+    __shared__ float s_mn[3][MM_T / 64], s_mx[3][MM_T / 64];
+    __shared__ int s_cnt[MM_T / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPart r;
+        r.cnt = 0; r.pad = 0;
+        for (int w = 0; w < MM_T / 64; ++w) r.cnt += s_cnt[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < MM_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            r.mn[d] = a; r.mx[d] = b;
+        }
+        part[blockIdx.x] = r;
+    }
+    if (!PA.ticket) return;
+    /* the last workgroup to get here reduces the partials (the host's own sequential min / max / sum give the same values) */
+    __shared__ int s_last, s_nfront, s_cc, s_S;
+    __shared__ float s_mid;
+    __shared__ float s_front[1024];
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(PA.ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int d = 0; d < 3; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; }
+    cnt = 0;
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += blockDim.x) {
+        const MinMaxPart r = part[q];
+        cnt += r.cnt;
+        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], r.mn[d]); mx[d] = fmaxf(mx[d], r.mx[d]); }
+    }
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    __syncthreads();
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_cnt[wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PlanAuto r;
+        r.fin.cnt = 0; r.fin.pad = 0;
+        for (int w = 0; w < MM_T / 64; ++w) r.fin.cnt += s_cnt[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < MM_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            r.fin.mn[d] = a; r.fin.mx[d] = b;
+        }
+        if (!r.fin.cnt) for (int d = 0; d < 3; ++d) { r.fin.mn[d] = 3.402823466e+38f; r.fin.mx[d] = -3.402823466e+38f; }
+        r.S = -1; r.pad = 0.f; r.census = 0; r.reserved = 0;
+        s_nfront = -1;
+        const int istep = (int)(PA.tool_radius * 2);
+        if (PA.walk >= 0 && r.fin.cnt > 0) {
+            if (PA.walk == 1 && istep > 0 && r.fin.mn[0] <= r.fin.mx[0]) { /* closed form per index: every thread fills its entries below (as setup_body) */
+                const int imin = (int)r.fin.mn[0], imax = (int)r.fin.mx[0];
+                const int cc = (imax + imin) / 2;
+                int nfront = 0, nback = 0;
+                if (imax > cc - istep && cc - istep > imin) nfront = (cc - imin - 1) / istep;
+                if (imax > cc + istep && cc + istep > imin) nback = (imax - cc - 1) / istep;
+                r.S = nfront + 1 + nback;
+                s_nfront = nfront; s_cc = cc; s_S = r.S; s_mid = (r.fin.mn[0] + r.fin.mx[0]) / 2;
+            } else r.S = slice_walk_device(PA.walk, r.fin.mn[0], r.fin.mx[0], PA.tool_radius, PA.px, PA.px_cap, s_front, 1024);
+            /* plan_window's pad, in its arithmetic */
+            const double rx = (double)r.fin.mx[0] - r.fin.mn[0], ry = (double)r.fin.mx[1] - r.fin.mn[1];
+            const double area = rx * ry;
+            const double spacing = area > 0 ? sqrt(area / r.fin.cnt) : 1.0;
+            r.pad = (float)fmax(3.0, (double)PA.normal_radius + fmax(1.5, spacing));
+        }
+        *PA.dev = r;
+        *PA.host = r;
+        *PA.ticket = 0;
+    }
+    __syncthreads();
+    if (s_nfront >= 0) {
+        const int istep = (int)(PA.tool_radius * 2);
+        for (int i = threadIdx.x; i < s_S && i < PA.px_cap; i += blockDim.x)
+            PA.px[i] = i < s_nfront ? (float)(s_cc - (s_nfront - i) * istep) : (i == s_nfront ? s_mid : (float)(s_cc + (i - s_nfront) * istep));
+    }
+}
+
 /* Resets the per-run state, finishes a2, runs a3 (slice walk + the PassThrough limits of
    rangedX_index(int), path_slicing_alg.cpp:152-158,247) and clears the slab histogram. */
 #ifndef SETUP_T

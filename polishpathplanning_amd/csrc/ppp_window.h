@@ -1037,6 +1037,65 @@ __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X,
     }
 }
 
+/* The census of a cloud that has just arrived, straight behind k_ingest_minmax in the stream: walk, slice count and pad come
+   from the record that kernel's last workgroup left (PlanAuto), so the host is not needed in between; the last workgroup here
+   hands the counters, the plane table and the record to pinned host memory and clears the counters again -- no copy or fill
+   command on the way (each costs the host 10-20 us on this runtime; a new cloud's plan was 150 us of which 30 us were kernels). */
+#define WIN_AUTO_SCAP 4096 /* slices the LDS counters of this form have room for */
+__global__ void __launch_bounds__(256) k_win_census_auto(const float *__restrict__ X, int n, const float *px, const PlanAuto *plan, float inv_step,
+                                                         int *cnt, int *ticket, PlanAuto *plan_host, float *px_host, int *census_host)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_c[];
+    __shared__ int s_last;
+    const int S = plan->S;
+    const float pad = plan->pad;
+    const bool valid = S >= 1 && S <= WIN_AUTO_SCAP;
+    if (valid) {
+        for (int i = threadIdx.x; i < 3 * S; i += blockDim.x) s_c[i] = 0;
+        __syncthreads();
+        const float px0 = px[0];
+        int *cw = s_c, *ce = s_c + S, *cr = s_c + 2 * S;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            const float x = X[i];
+            if (!(x == x)) continue;
+            const float fj = fminf(fmaxf(floorf((x - px0) * inv_step + 0.5f), 0.f), (float)(S - 1));
+            const int j = (int)fj;
+            const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
+            int w = -1;
+            if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
+            if (w < 0) continue;
+            atomicAdd(&cw[w], 1);
+            const float Px = px[w];
+            const int position = (int)Px;
+            if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
+                const float d = (x - Px) * 1.f;
+                if (d > 0) atomicAdd(&ce[w], 1); else if (d < 0) atomicAdd(&cr[w], 1);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * S; i += blockDim.x)
+            if (s_c[i]) atomicAdd(&cnt[i], s_c[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (valid) {
+        for (int i = threadIdx.x; i < 3 * S; i += blockDim.x) { census_host[i] = __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cnt[i] = 0; }
+        for (int i = threadIdx.x; i < S; i += blockDim.x) px_host[i] = px[i];
+    }
+    if (threadIdx.x == 0) {
+        PlanAuto r = *plan;
+        r.census = valid ? 1 : 0;
+        *plan_host = r;
+        *ticket = 0;
+    }
+}
+
 /* ---- launch forms: single (arguments by value) and batched (blockIdx.y = member of the batch) ---- */
 template <int PPT, bool STAGED>
 __global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A) { win_scatter_body<PPT, STAGED>(A, blockIdx.x); }
