@@ -576,8 +576,9 @@ int plan_window(ppp_handle h, int S, double per)
         HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * std::max<size_t>(3, WIN_CNT_STRIDE), h->stream));
     h->win_path = true;
     if (getenv("PPP_WIN_DEBUG"))
-        fprintf(stderr, "[ppp] window plan: S %d [%d,%d) pad %.2f capw %d cap_el %d NBc %d (throughput %d) threads %d ppt %d lds %zu B max window %d max left side %d\n",
-                S, h->sb, h->se, pad, capw, cap_el, NBc, h->win_NBc_thr, T, h->win_ppt, win_slice_lds_for(h, NBc), max_w, max_el);
+        fprintf(stderr, "[ppp] window plan: S %d [%d,%d) pad %.2f capw %d cap_el %d NBc %d (throughput %d) threads %d ppt %d lds %zu B max window %d max left side %d census %s\n",
+                S, h->sb, h->se, pad, capw, cap_el, NBc, h->win_NBc_thr, T, h->win_ppt, win_slice_lds_for(h, NBc), max_w, max_el,
+                from_auto ? "came with the cloud" : "at plan time");
     return PPP_OK;
 }
 

@@ -1612,6 +1612,41 @@ def test_window_path_hands_a_pass_back_when_a_search_leaves_its_window(engine_mo
     assert a.fast_path()                                   # ... a new cloud gets the window path again
 
 
+def test_census_that_comes_with_a_new_cloud_equals_the_one_taken_at_plan_time(tmp_path):
+    """A cloud that has just been set brings bounds, slice walk and window census along in the same stream
+    (k_ingest_minmax's last workgroup + k_win_census_auto, results in pinned memory); a plan made later for the same cloud
+    (new parameters) takes its census the earlier way.  Both must size the same plan and give the same list -- for all five
+    walks, a cloud with dropped (NaN) points, and when a second cloud follows on the same handle."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from polishpathplanning_amd import engine, synth
+        pts, cfg = synth.make_config("small_40k")
+        pts2, _ = synth.make_config("small_40k", seed=77)
+        pts2 = pts2.copy(); pts2[::97] = np.nan
+        for walk in range(5):
+            e = engine.Engine(0, tool_radius=6.0, walk=walk)
+            for cloud in (pts, pts2):
+                e.set_cloud(cloud); e.gen_path(); e.get_path()          # census came with the cloud
+                a = e.waypoints().copy(); assert e.fast_path()
+                e.set_params(tool_radius=7.0); e.gen_path(); e.get_path()
+                e.set_params(tool_radius=6.0); e.gen_path(); e.get_path()  # census at plan time
+                b = e.waypoints().copy(); assert e.fast_path()
+                assert a.shape == b.shape and np.array_equal(a, b), walk
+        print("same lists")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PPP_WIN_DEBUG="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "same lists" in r.stdout, r.stdout + r.stderr
+    plans = [ln for ln in r.stderr.splitlines() if ln.startswith("[ppp] window plan")]
+    assert len(plans) == 5 * 2 * 3
+    for k in range(0, len(plans), 3):
+        with_cloud, _, later = plans[k:k + 3]
+        assert with_cloud.endswith("census came with the cloud") and later.endswith("census at plan time")
+        assert with_cloud.rsplit(" census ", 1)[0] == later.rsplit(" census ", 1)[0]   # capacities, buckets, threads: the same plan
+
+
 def test_window_path_applies_only_where_the_windows_do_not_overlap(engine_mod, oracle_mod):
     """Tool steps below about 2 x pad + 2 mm (here radius 4 -> step 8) make the slices' windows overlap: the plan stays on the
     slab index, with the same parity; so do brute pairing and the dynamic adjustment."""
