@@ -55,6 +55,20 @@ def load_traffic(kernel, launches_per_pass, config):
     return best if best else (None, None)
 
 
+_RECORD_FD = None
+
+
+def emit_record(out):
+    """the one line of the run, on the process's real stdout"""
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    if _RECORD_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        while line:
+            line = line[os.write(_RECORD_FD, line):]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +113,13 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    # stdout carries ONE line, the JSON record: whatever native libraries print while they come up (RCCL's version banner goes to
+    # stdout) is sent to stderr; the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    global _RECORD_FD
+    _RECORD_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -353,7 +374,7 @@ def main():
             "exchange": ("torch.distributed gather to rank 0 over RCCL (direct send/recv of padded blocks), asynchronous behind each "
                          "step in the planner's stream order" if gatherers[0].dist else None),
         }
-        print(json.dumps(out), flush=True)
+        emit_record(out)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -553,7 +574,7 @@ def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth)
             "cpu_baseline": None,
             "assembled_path": {"sharded_list_equals_unsharded_handle": sharded_equals_whole, "rows": W},
         }
-        print(json.dumps(out), flush=True)
+        emit_record(out)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0 and not out["assembled_path"]["sharded_list_equals_unsharded_handle"]:

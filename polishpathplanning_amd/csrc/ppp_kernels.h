@@ -351,7 +351,13 @@ __global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__
             for (int w = 0; w < MM_T / 64; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
             r.mn[d] = a; r.mx[d] = b;
         }
-        part[blockIdx.x] = r;
+        /* published word by word with agent-scope stores (write-through), the ticket drawn once they are acknowledged: a release
+           fence here would write back the whole L2 -- the 12 bytes a point this pass has just converted -- once per workgroup
+           (measured: 31 us for 1 M points against 16 us for the two separate kernels) */
+        int *dst = (int *)&part[blockIdx.x];
+        const int *src = (const int *)&r;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(MinMaxPart) / 4); ++k) __hip_atomic_store(dst + k, src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!PA.ticket) return;
     /* the last workgroup to get here reduces the partials (the host's own sequential min / max / sum give the same values) */
@@ -359,16 +365,21 @@ __global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__
     __shared__ float s_mid;
     __shared__ float s_front[1024];
     if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(PA.ticket, 1) == (int)gridDim.x - 1;
+        __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0): the stores above have been acknowledged */
+        s_last = __hip_atomic_fetch_add(PA.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     for (int d = 0; d < 3; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; }
     cnt = 0;
     for (int q = threadIdx.x; q < (int)gridDim.x; q += blockDim.x) {
-        const MinMaxPart r = part[q];
+        MinMaxPart r;
+        {
+            const int *src = (const int *)&part[q];
+            int *dst = (int *)&r;
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(MinMaxPart) / 4); ++k) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         cnt += r.cnt;
         for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], r.mn[d]); mx[d] = fmaxf(mx[d], r.mx[d]); }
     }
