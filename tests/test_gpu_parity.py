@@ -768,6 +768,10 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, name, walk):
     e2 = engine_mod.Engine(0, tool_radius=cfg["tool_radius"], walk=walk); e2.set_cloud(pts); e2.gen_path(); e2.get_path()
     a, b = e2.stage(engine_mod.STAGE_WP_XYZ)[:, 0], e.stage(engine_mod.STAGE_WP_XYZ)[:, 0]
     assert a.shape != b.shape or np.abs(a - b).max() > 0.05   # v1 drops the end samples, so its paths get shorter
+    by, bx, bz, step = e2.boundary(1)                         # no adjustment, no boundaries
+    assert len(by) == 0 and step == -1
+    with pytest.raises(engine_mod.PPPError):
+        e.boundary(S)
 
 
 def test_dynamic_fit_paths_agree():
