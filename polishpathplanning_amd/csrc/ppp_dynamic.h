@@ -33,20 +33,50 @@ struct __attribute__((aligned(16))) DynWaveLds {
     int cnt[64];           /* candidates per rank: more than one = equal distances, ranked again on the whole key */
     int sel[64];
     int sel_id[64]; /* cloud index of neighbour r (the low half of its key) */
+    int sel_slot[64]; /* the candidate slot neighbour r was kept in */
     int off[65];  /* exclusive prefix of the y-window sizes of 64 neighbouring slabs */
     int w0[64];   /* first position of each window                                  */
 };
 
+/* The slab grid and the y-bucket scale of the pass: read ONCE when a kernel starts, together with its other first reads, so
+   that no search begins with a trip to the meta block (slab_of / ytab_bucket on the values, same expressions). */
+struct DynGrid { int B, total; float x0, invw, y0, ysc; };
+__device__ inline DynGrid dyn_grid(const DevMeta *m)
+{
+    DynGrid G;
+    G.B = m->B; G.total = m->n_sorted; G.x0 = m->slab_x0; G.invw = m->slab_invw; G.y0 = m->mn[1]; G.ysc = m->ytab_scale;
+    return G;
+}
+__device__ inline int dyn_slab_of(const DynGrid &G, float x)
+{
+    int b = (int)((x - G.x0) * G.invw);
+    b = b < 0 ? 0 : b;
+    return b >= G.B ? G.B - 1 : b;
+}
+__device__ inline int dyn_ybucket(const DynGrid &G, float y)
+{
+    int q = (int)((y - G.y0) * G.ysc);
+    q = q < 0 ? 0 : q;
+    return q >= YTB ? YTB - 1 : q;
+}
 /* exact k nearest neighbours of q (ascending (distance, cloud index)): returns kk <= k, positions
    in L.sel[0..kk).  All 64 lanes of the wave call this together.
-   Every slab the search ball touches is binary-searched for its y-window by its own lane (the
-   searches are chains of dependent loads: side by side they cost one chain, not one per slab); the
-   windows are then walked as one flat list, 64 candidates per step. */
-__device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float qy, float qz, int k, float r0, StampCtx &sc)
+   Every slab the search ball touches gives its y-window from its y-bucket row (own lane each); the windows are then walked
+   as one flat list, 64 candidates per step.  With `normals4` the normals of the candidates inside the ball are requested as
+   soon as the ball is settled and travel while the ranking runs; lane r returns neighbour r's in nn[] (zeros beyond kk).
+   (Measured and dropped in round 3: loading the windows one after the other, lane = place inside the window, eight windows in
+   flight -- no flat index to search, but two and a half times the instructions: 3.65 -> 3.88 ms at cfg 2; an LDS copy of the
+   index rows of the step's slabs, requested with the kernel's first reads so that a search goes straight to its candidates:
+   3.54 -> 3.69 ms, the rows come from the L2 faster than nine more loads per thread cost; ranking in registers -- candidate j's
+   distance broadcast from its lane, its rank the population count of two compare masks, scalar arithmetic only --: the ranking
+   1.9 -> 5.4 us; the rank-order sums with all their LDS reads issued ahead of the chain of additions: no faster, and 30 more
+   registers cost k_dyn_first_eval a wave per SIMD, 159 -> 200 us.) */
+__device__ inline int wave_knn(const SlabView &V, const DynGrid &G, DynWaveLds &L, float qx, float qy, float qz, int k,
+                               float r0, const float4 *__restrict__ normals4, float nn[3], StampCtx &sc)
 {
     const int lane = threadIdx.x & 63;
-    const int B = V.m->B;
-    const int total = V.m->n_sorted;
+    const int B = G.B;
+    const int total = G.total;
     float r = r0;
     int count = 0;
     for (int attempt = 0; attempt < 48; ++attempt) {
@@ -55,20 +85,31 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
         bool overflow = false;
         const float pady = 1e-5f * (fabsf(qy) + r) + 1e-6f, padx = 1e-5f * (fabsf(qx) + r) + 1e-6f;
         const float ylo = qy - r - pady, yhi = qy + r + pady;
-        int blo = slab_of(V.m, qx - r - padx) - 1, bhi = slab_of(V.m, qx + r + padx) + 1;
+        int blo = dyn_slab_of(G, qx - r - padx) - 1, bhi = dyn_slab_of(G, qx + r + padx) + 1;
         blo = blo < 0 ? 0 : blo;
         bhi = bhi >= B ? B - 1 : bhi;
+        const int q0 = dyn_ybucket(G, ylo), q1 = dyn_ybucket(G, yhi) + 1;
+        auto keep = [&](bool in, float d, int id, int pos) { /* candidates inside the ball take the next slots, in lane order */
+            const u64 mask = __ballot(in);
+            if (in) {
+                const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.dk[slot] = __float_as_uint(d); L.pos[slot] = pos; }
+            }
+            count += __popcll(mask);
+            if (count > DYN_KNN_CAP) overflow = true;
+        };
         for (int cb = blo; cb <= bhi && !overflow; cb += 64) {
             const int bb = cb + lane;
             int a = 0, e = 0;
             if (bb <= bhi) {
-                const int s0 = V.slab_start[bb];
                 if (V.ytab) {
                     /* the slab's y-bucket row bounds the window from outside (bucket() is monotone in y): no search at all,
                        a few candidates more -- each is tested against r2 below anyway */
+                    const int s0 = V.slab_start[bb];
                     const int *T = V.ytab + (size_t)bb * (YTB + 1);
-                    a = s0 + T[ytab_bucket(V.m, ylo)]; e = s0 + T[ytab_bucket(V.m, yhi) + 1];
+                    a = s0 + T[q0]; e = s0 + T[q1];
                 } else {
+                    const int s0 = V.slab_start[bb];
                     const int s1 = V.slab_start[bb + 1];
                     int l0 = s0, l1 = s1, u0 = s0, u1 = s1; /* first y >= ylo, first y > yhi */
                     while (l0 < l1 || u0 < u1) {
@@ -105,7 +146,7 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (base + 64 * u >= T) break;
+                    if (base + 64 * u >= T || overflow) break;
                     bool in = false;
                     float d = 0.f;
                     int id = 0;
@@ -114,13 +155,7 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
                         id = idx_of(c4[u]);
                         in = d <= r2;
                     }
-                    const u64 mask = __ballot(in);
-                    if (in) {
-                        const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (slot < DYN_KNN_CAP) { L.key[slot] = ((u64)__float_as_uint(d) << 32) | (u32)id; L.dk[slot] = __float_as_uint(d); L.pos[slot] = i4[u]; }
-                    }
-                    count += __popcll(mask);
-                    if (count > DYN_KNN_CAP) { overflow = true; break; }
+                    keep(in, d, id, i4[u]);
                 }
             }
         }
@@ -132,6 +167,14 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
     __threadfence_block();
     sc.mark(2);
     const int kk = count < k ? count : k;
+    /* the normals of the candidates inside the ball (two per lane: slots lane and lane + 64) are requested now and travel
+       while the ranking runs; a fuller ball gathers the k it needs afterwards, as before */
+    const bool pre = normals4 != nullptr && count <= 128;
+    float4 nq0 = make_float4(0.f, 0.f, 0.f, 0.f), nq1 = nq0;
+    if (pre) {
+        if (lane < count) nq0 = normals4[(u32)L.key[lane]];
+        if (lane + 64 < count) nq1 = normals4[(u32)L.key[lane + 64]];
+    }
     /* rank by counting: (distance, cloud index) is a total order.  Distances are almost always all different, so a candidate's
        rank is the number of smaller DISTANCES -- 32-bit compares on values read four per LDS access (every lane the same
        address: a broadcast), two candidates per lane in one sweep; candidates that land on the same rank (equal distances)
@@ -172,11 +215,25 @@ __device__ inline int wave_knn(const SlabView &V, DynWaveLds &L, float qx, float
                 rank = 0;
                 for (int j = 0; j < count; ++j) rank += L.key[j] < kc;
             }
-            if (rank < kk) { L.sel[rank] = L.pos[c]; L.sel_id[rank] = (int)(u32)kc; }
+            if (rank < kk) { L.sel[rank] = L.pos[c]; L.sel_id[rank] = (int)(u32)kc; L.sel_slot[rank] = c; }
         }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     sc.mark(3);
+    if (normals4 != nullptr) { /* lane r: the normal of neighbour r */
+        nn[0] = nn[1] = nn[2] = 0.f;
+        if (pre) {
+            const int sl = lane < kk ? L.sel_slot[lane] : 0;
+            const int from = sl & 63;
+            const float x0 = __shfl(nq0.x, from, 64), y0 = __shfl(nq0.y, from, 64), z0 = __shfl(nq0.z, from, 64);
+            const float x1 = __shfl(nq1.x, from, 64), y1 = __shfl(nq1.y, from, 64), z1 = __shfl(nq1.z, from, 64);
+            if (lane < kk) { nn[0] = sl >= 64 ? x1 : x0; nn[1] = sl >= 64 ? y1 : y0; nn[2] = sl >= 64 ? z1 : z0; }
+        } else if (lane < kk) {
+            const float4 nv = normals4[L.sel_id[lane]];
+            nn[0] = nv.x; nn[1] = nv.y; nn[2] = nv.z;
+        }
+    }
+    sc.mark(9);
     return kk;
 }
 
@@ -190,7 +247,7 @@ __device__ inline void dyn_stage_ellipse(const float *__restrict__ ell_cs, float
 /* Area2Cloud(point, flag, key): key 0 = left (min x), 1 = right (max x).  Wave-cooperative.  Returns the number of neighbours
    its search found (0: none, or the point is not a number); L.sel[0] / L.sel_id[0] then still hold the nearest of them, which is
    what the 1-NN snap of the same point asks for. */
-__device__ inline int wave_area2cloud(const SlabView &V, DynWaveLds &L, const float4 *__restrict__ normals4,
+__device__ inline int wave_area2cloud(const SlabView &V, const DynGrid &G, DynWaveLds &L, const float4 *__restrict__ normals4,
                                        const float2 *ell, const DynParams &D, const double point[3], int key,
                                        float bound[3], StampCtx &sc)
 {
@@ -198,14 +255,10 @@ __device__ inline int wave_area2cloud(const SlabView &V, DynWaveLds &L, const fl
     const float sp[3] = {(float)point[0], (float)point[1], (float)point[2]};
     bound[0] = bound[1] = bound[2] = NAN;
     if (!(sp[0] == sp[0] && sp[1] == sp[1] && sp[2] == sp[2])) return 0;
-    const int kk = wave_knn(V, L, sp[0], sp[1], sp[2], D.k, D.r0, sc);
-    if (kk <= 0) return 0;
     /* computePointPrincipalCurvatures: lane r holds the neighbour of rank r */
     float nn[3] = {0.f, 0.f, 0.f};
-    if (lane < kk) {
-        const float4 nv = normals4[L.sel_id[lane]];
-        nn[0] = nv.x; nn[1] = nv.y; nn[2] = nv.z;
-    }
+    const int kk = wave_knn(V, G, L, sp[0], sp[1], sp[2], D.k, D.r0, normals4, nn, sc);
+    if (kk <= 0) return 0;
     float n0[3];
     for (int i = 0; i < 3; ++i) n0[i] = __shfl(nn[i], 0, 64);
     float proj[3] = {0.f, 0.f, 0.f};
@@ -215,7 +268,6 @@ __device__ inline int wave_area2cloud(const SlabView &V, DynWaveLds &L, const fl
                         m2 = (i == 2 ? 1.f : 0.f) - n0[i] * n0[2];
             proj[i] = m0 * nn[0] + m1 * nn[1] + m2 * nn[2];
         }
-    sc.mark(9);
     /* centroid and covariance of the projected normals: summed neighbour by neighbour in rank order, as the reference's
        loops do (a tree reduction gives other last bits, and the ellipse extremum below is a discontinuous function of
        them).  The nine sums are independent of each other, so each gets a lane of its own: the values go through LDS
@@ -419,10 +471,11 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_area2cloud_api(DevMeta *m, D
     const int q = blockIdx.x * DYN_WAVES + wv;
     if (q >= k) return;
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
+    const DynGrid G = dyn_grid(m);
     double p[3] = {pts[3 * q], pts[3 * q + 1], pts[3 * q + 2]};
     float b[3];
     StampCtx sc; sc.begin(15, false);
-    wave_area2cloud(V, s_w[wv], normals4, s_ell, D, p, key, b, sc);
+    wave_area2cloud(V, G, s_w[wv], normals4, s_ell, D, p, key, b, sc);
     if ((threadIdx.x & 63) == 0) { out[3 * q] = b[0]; out[3 * q + 1] = b[1]; out[3 * q + 2] = b[2]; }
 }
 
@@ -614,12 +667,19 @@ __device__ inline int wave_gsl_bsearch_d(const double *ny, int mm, double dy)
 __device__ inline void spline_point_f(const float *ny, const float *nx, const float *nz, int mm, double dy, double out[3])
 {
     auto Yf = [&](int i) { return (double)ny[i]; };
-    auto Xf = [&](int i) { return (double)nx[i]; };
-    auto Zf = [&](int i) { return (double)nz[i]; };
     const int iv = wave_gsl_bsearch_f(ny, mm, dy);
-    out[0] = steffen_eval_at(iv, mm, dy, Yf, Xf);
+    /* the two splines side by side instead of one after the other: even lanes evaluate y -> x, odd lanes y -> z (twenty
+       double-precision divisions between them), lanes 0 and 1 hand the results to the wave */
+    const float *nv = (threadIdx.x & 1) ? nz : nx;
+    auto Vf = [&](int i) { return (double)nv[i]; };
+    const double v = steffen_eval_at(iv, mm, dy, Yf, Vf);
+    auto lane_double = [](double d, int l) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(d), l), hi = __builtin_amdgcn_readlane(__double2hiint(d), l);
+        return __hiloint2double(hi, lo);
+    };
+    out[0] = lane_double(v, 0);
     out[1] = dy;
-    out[2] = steffen_eval_at(iv, mm, dy, Yf, Zf);
+    out[2] = lane_double(v, 1);
 }
 
 /* The first Area2Cloud of dynamic_adjust_path's bisection (path_dynamic_alg.cpp:237-243) is taken at the node as sampled
@@ -636,6 +696,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, D
     __shared__ float2 s_ell[DYN_ELL];
     StampCtx sc; sc.begin(6, blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0);
     dyn_stage_ellipse(ell_cs, s_ell);
+    const DynGrid G = dyn_grid(m);
     __syncthreads();
     if (m->err) return;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -660,11 +721,12 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_first_eval(DevMeta *m, D
     spline_point_f(node_y + st, node_x + st, node_z + st, mm, dy, node);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float ab[3];
-    const int kk = wave_area2cloud(V, s_w[wv], normals4, s_ell, D, node, key == 0 ? 1 : 0, ab, sc);
+    const int kk = wave_area2cloud(V, G, s_w[wv], normals4, s_ell, D, node, key == 0 ? 1 : 0, ab, sc);
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
     /* the snap asks for the nearest point of the very query Area2Cloud has just ranked 50 neighbours of: rank 0, no second search */
-    const int got = finite ? (kk > 0 ? 1 : wave_knn(V, s_w[wv], qx, qy, qz, 1, D.r1, sc)) : 0;
+    float no_nn[3];
+    const int got = finite ? (kk > 0 ? 1 : wave_knn(V, G, s_w[wv], qx, qy, qz, 1, D.r1, nullptr, no_nn, sc)) : 0;
     if (lane == 0) {
         Bf.first_ab[at] = make_float4(ab[0], ab[1], ab[2], 1.f);
         Bf.first_node[3 * at] = node[0]; Bf.first_node[3 * at + 1] = node[1]; Bf.first_node[3 * at + 2] = node[2];
@@ -695,10 +757,11 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     float *ly = (float *)(s_raw + dyn_scratch_bytes(Bf.maxNA)), *lx = ly + capA, *lz = lx + capA;
     const DynFitLds F = dyn_fit_lds(s_raw, capA);
     const float4 *pts = Bf.adj_pts + (size_t)chain * Bf.maxNA; /* (y, x, z, valid) */
-    /* first reads, all at once: the samples of the step before, the ellipse table, the state of the pass */
+    /* first reads, all at once: the samples of the step before, the ellipse table, the slab grid, the state of the pass */
     const int nv = t > 0 ? dyn_stage_samples(pts, Bf.maxNA, F, [](const float4 &p) { return p.w != 0.f; }, [](const float4 &p) { return p.x; }) : 0;
     const int bn = (t > 0 && walk == 3) ? Bf.bnd_n[chain] : 3;
     dyn_stage_ellipse(ell_cs, s_ell);
+    const DynGrid G = dyn_grid(m);
     const int err = m->err;
     __syncthreads();
     if (err) return;
@@ -755,7 +818,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_boundary_pts(DevMeta *m,
     sc.mark(1);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0, ytab};
     float b[3];
-    wave_area2cloud(V, ((DynWaveLds *)s_raw)[wv], normals4, s_ell, D, point, c.key, b, sc);
+    wave_area2cloud(V, G, ((DynWaveLds *)s_raw)[wv], normals4, s_ell, D, point, c.key, b, sc);
     if (lane == 0) *dst = make_float4(b[0], b[1], b[2], 1.f);
     sc.mark(6);
 }
@@ -789,6 +852,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     const float4 first = Bf.first_ab[at];
     double node[3] = {Bf.first_node[3 * at], Bf.first_node[3 * at + 1], Bf.first_node[3 * at + 2]};
     dyn_stage_ellipse(ell_cs, s_ell); /* (the barriers of the fit come before any use) */
+    const DynGrid G = dyn_grid(m);
     if (m->err) return;
     const DynChain c = dyn_chain(walk, chain, t, centre, m->S);
     if (!c.active) return;
@@ -850,7 +914,7 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     bool moved = false;
     int kk_here = 0; /* neighbours Area2Cloud found at the node as it stands (0: not evaluated there, or none) */
     for (int itr = 0; itr <= 5; ++itr) {
-        if (itr > 0) kk_here = wave_area2cloud(V, L, normals4, s_ell, D, node, c.key == 0 ? 1 : 0, ab, sc);
+        if (itr > 0) kk_here = wave_area2cloud(V, G, L, normals4, s_ell, D, node, c.key == 0 ? 1 : 0, ab, sc);
         if ((double)ab[1] < bminy || (double)ab[1] > bbigy) break; /* a NaN bound passes, as in the reference: the node turns NaN below */
         const int iv = wave_gsl_bsearch_d(ky, nb, (double)ab[1]);
         const double bpx = steffen_eval_at(iv, nb, (double)ab[1], BY, BX);
@@ -877,7 +941,8 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_dyn_adjust_pts(DevMeta *m, D
     const float qx = (float)node[0], qy = (float)node[1], qz = (float)node[2];
     const bool finite = fabsf(qx) <= 3.402823466e+38f && fabsf(qy) <= 3.402823466e+38f && fabsf(qz) <= 3.402823466e+38f;
     /* (a bisection that ended on an evaluation at the node's final place has its nearest point already: rank 0 of that search) */
-    const int got = finite ? (kk_here > 0 ? 1 : wave_knn(V, L, qx, qy, qz, 1, D.r1, sc)) : 0;
+    float no_nn[3];
+    const int got = finite ? (kk_here > 0 ? 1 : wave_knn(V, G, L, qx, qy, qz, 1, D.r1, nullptr, no_nn, sc)) : 0;
     if (lane == 0) {
         if (!finite) *dst = make_float4(0, 0, 0, 0);
         else if (got < 1) { set_err(m, DERR_QUERY, c.s); *dst = make_float4(0, 0, 0, 0); }

@@ -25,7 +25,9 @@ __global__ void __launch_bounds__(64 * DYN_WAVES) k_sor_dist(DevMeta *m, const f
     StampCtx sc; sc.begin(15, false);
     SlabView V{sorted4, slab_start, slab_xmin, slab_xmax, m, nullptr, 0, 0};
     const float4 q = sorted4[p];
-    const int kk = wave_knn(V, s_w[wv], q.x, q.y, q.z, mean_k + 1, r0, sc);
+    const DynGrid G = dyn_grid(m);
+    float no_nn[3];
+    const int kk = wave_knn(V, G, s_w[wv], q.x, q.y, q.z, mean_k + 1, r0, nullptr, no_nn, sc);
     if (kk < mean_k + 1) { if (lane == 0) set_err(m, DERR_QUERY, -1); return; } /* PCL would read past its neighbour vectors */
     float sd = 0.f;
     if (lane < kk) {

@@ -4,8 +4,13 @@ stamps serialise what the product build overlaps."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polishpathplanning_amd import engine, synth
-engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), "libppp_hip_stamps.so")
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+argv = sys.argv[1:]
+stamps_lib = "libppp_hip_stamps.so"
+if "--lib" in argv:
+    stamps_lib = argv[argv.index("--lib") + 1]
+    del argv[argv.index("--lib"):argv.index("--lib") + 2]
+engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), stamps_lib)
+args = [a for a in argv if not a.startswith("--")]
 name = args[0] if args else "cfg2_1m_s256"
 dynamic = 1 if "--dynamic" in sys.argv else 0
 pts, cfg = synth.make_config(name)
