@@ -285,7 +285,7 @@ def main():
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
         workload_key = args.config + ("_b%d" % args.batch if args.batch > 1 else "") + ("_dyn" if args.dynamic else "")
         traffic, traffic_src = load_traffic(dom, launches.get(dom, 1), workload_key)
-        roofline = {"bound": "hbm", "kernel": dom, "launch_path": "window (3 launches)" if eng.fast_path() else "slab index (6 launches)",
+        roofline = {"bound": "hbm", "kernel": dom, "launch_path": ("window (%d launches)" if eng.fast_path() else "slab index (%d launches)") % sum(launches.values()),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,

@@ -78,7 +78,9 @@ __device__ inline int idx_of(const float4 &p) { return __float_as_int(p.w); }
    entry YTB is the slab's population.  bucket() is monotone in y, so the lower bound of any y lies inside its own bucket:
    a search is one table look-up plus a binary search over that bucket's few points instead of over the whole slab
    (ten dependent reads become three).  Exactness never depends on the table: it only narrows the first interval. */
-#define YTB 128
+#ifndef YTB
+#define YTB 512
+#endif
 __device__ inline int ytab_bucket(const DevMeta *m, float y)
 {
     int q = (int)((y - m->mn[1]) * m->ytab_scale);
