@@ -85,7 +85,9 @@ __device__ inline int wave_knn(const SlabView &V, const DynGrid &G, DynWaveLds &
         bool overflow = false;
         const float pady = 1e-5f * (fabsf(qy) + r) + 1e-6f, padx = 1e-5f * (fabsf(qx) + r) + 1e-6f;
         const float ylo = qy - r - pady, yhi = qy + r + pady;
-        int blo = dyn_slab_of(G, qx - r - padx) - 1, bhi = dyn_slab_of(G, qx + r + padx) + 1;
+        /* slab_of is monotone and is what binned the points: every point with |x - qx| <= r lies in [blo, bhi] (the band gathers
+           of the hot path rest on the same argument); a slab of margin either side was a third more candidates for nothing */
+        int blo = dyn_slab_of(G, qx - r - padx), bhi = dyn_slab_of(G, qx + r + padx);
         blo = blo < 0 ? 0 : blo;
         bhi = bhi >= B ? B - 1 : bhi;
         const int q0 = dyn_ybucket(G, ylo), q1 = dyn_ybucket(G, yhi) + 1;

@@ -382,6 +382,7 @@ DynParams dyn_params(const ppp_handle h)
     double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
     double rho = (area > 0 && h->h_nvalid > 0) ? (double)h->h_nvalid / area : 1.0;
     D.r0 = (float)std::max(0.5, 1.25 * std::sqrt((double)D.k / (3.14159265358979 * rho)));
+    if (const char *ev = getenv("PPP_DYN_R0F")) D.r0 = (float)std::max(0.5, atof(ev) * std::sqrt((double)D.k / (3.14159265358979 * rho))); /* tuning runs only */
     D.r1 = (float)std::max(0.25, 2.0 * std::sqrt(1.0 / (3.14159265358979 * rho)));
     return D;
 }
