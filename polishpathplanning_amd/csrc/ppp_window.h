@@ -97,6 +97,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
     __shared__ int s_n[WSC_T / 64];
     const int S = A.S, n = A.n;
     const int i0 = bx * (PPT * (int)blockDim.x);
+    STAMP_BEGIN();
     float4 p[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -111,6 +112,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
         m->node_cursor = 0; m->smooth_done = -1; m->emit_ticket = 0; m->big_slabs = 0; m->big_slices = 0; m->arena_cursor = 0; m->win_flag = 0;
     }
     __syncthreads();
+    STAMP(7, 0); /* loads issued, plane table staged */
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
     int pw[PPT], pr[PPT]; /* window (or -1) and rank inside this workgroup's run */
@@ -135,12 +137,14 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
         }
     }
     __syncthreads();
+    STAMP(7, 1); /* points arrived, windows found, ranks from the LDS counters */
     if (!STAGED) {
         for (int s = threadIdx.x; s < S; s += blockDim.x) {
             const int c = s_cnt[s];
             if (c) s_cnt[s] = atomicAdd(&A.win_cnt[(size_t)s * WIN_CNT_STRIDE], c); /* this workgroup's run inside the window */
         }
         __syncthreads();
+        STAMP(7, 2); /* runs reserved (global atomics) */
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (pw[k] >= 0) {
@@ -183,6 +187,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
             if (pos < A.capw) A.win_pts[(size_t)w * A.capw + pos] = stage[q];
         }
     }
+    STAMP(7, 3); /* stores issued */
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
     cnt = wave_sum(cnt);
@@ -200,6 +205,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
         }
         A.win_part[bx] = r;
     }
+    STAMP(7, 4); /* bounds partial */
 }
 
 /* ------------------------------------------------------------------ */

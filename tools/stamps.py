@@ -25,6 +25,7 @@ labels = {0: ("k_slice_kd", ["gather", "band sort", "NN+lerp", "cand sort", "fla
           1: ("k_pose", ["staging", "dy+spline", "nearest", "normal", "pose+handeye"]),
           2: ("k_slab_scatter", ["zero", "count", "reserve", "scatter"]),
           5: ("k_setup", ["partials", "slab scan", "bounds+walk", "band limits"]),
+          7: ("k_win_scatter", ["loads issued + table", "points in, windows, LDS ranks", "global atomics", "stores issued", "bounds partial"]),
           6: ("k_win_slice", ["load+clear", "hist+scan+place", "bucket finish", "pairing NN", "cand sort", "flatten", "knots+spline", "nearest", "normal", "pose+store"]),
           }
 if dynamic:
