@@ -1,4 +1,5 @@
-"""developer scratch: how much slower does the dynamic adjustment's chain run while another stream keeps the device full?"""
+"""Developer tool: the dynamic-adjustment pass (cfg 2) alone and while a second handle keeps the device full with plain passes
+(what concurrent launches cost the chain).  usage: python tools/chain_beside_load.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polishpathplanning_amd import engine, synth
