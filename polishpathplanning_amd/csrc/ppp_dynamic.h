@@ -70,7 +70,8 @@ __device__ inline int dyn_ybucket(const DynGrid &G, float y)
    3.54 -> 3.69 ms, the rows come from the L2 faster than nine more loads per thread cost; ranking in registers -- candidate j's
    distance broadcast from its lane, its rank the population count of two compare masks, scalar arithmetic only --: the ranking
    1.9 -> 5.4 us; the rank-order sums with all their LDS reads issued ahead of the chain of additions: no faster, and 30 more
-   registers cost k_dyn_first_eval a wave per SIMD, 159 -> 200 us.) */
+   registers cost k_dyn_first_eval a wave per SIMD, 159 -> 200 us; the index rows requested from the x of the knot in front of a
+   sample while its spline is still being evaluated: 3.42 -> 3.45 ms.) */
 __device__ inline int wave_knn(const SlabView &V, const DynGrid &G, DynWaveLds &L, float qx, float qy, float qz, int k,
                                float r0, const float4 *__restrict__ normals4, float nn[3], StampCtx &sc)
 {
