@@ -55,6 +55,18 @@ def load_traffic(kernel, launches_per_pass, config):
     return best if best else (None, None)
 
 
+def load_traffic_total(launches, config):
+    """HBM bytes of one whole pass: the sum of load_traffic over every kernel of the pass (None when a kernel has no committed summary)."""
+    total, srcs = 0.0, set()
+    for k, n in launches.items():
+        t, src = load_traffic(k, n, config)
+        if t is None:
+            return None, None
+        total += t
+        srcs.add(src.split(" (")[0])
+    return (total, ", ".join(sorted(srcs))) if launches else (None, None)
+
+
 _RECORD_FD = None
 
 
@@ -87,6 +99,8 @@ def main():
                     help="also report the step time over K distinct resident clouds planned round-robin (K x working set beyond "
                          "the 256 MiB Infinity Cache) and the cold time of a never-seen cloud; 0 = off, the default run uses 8")
     ap.add_argument("--no-dynamic", action="store_true", help="skip the Dynamic_adjustment = true measurement that the default one-GPU run reports beside the headline")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the cfg3 x 64 batch and the cfg5 measurement that the default one-GPU run reports beside the headline")
     ap.add_argument("--dynamic", action="store_true",
                     help="plan with Dynamic_adjustment = true (the reference's config.txt default; SURVEY.md 8f rank 1): the same "
                          "workload through the slice-to-slice chains -- a measurement beside the headline, not the headline")
@@ -249,7 +263,38 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
         tg = torch.tensor([(time.perf_counter() - tg0) / reps * 1e3], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        engine_gather = None
+        if force_dist and args.batch == 1:
+            # the engine's own exchange (ppp_gather_waypoints: ncclSend / ncclRecv group on the PLANNER's stream) rehearsed against the real
+            # librccl with a one-rank communicator -- the block sent to itself and received (PPP_GATHER_REHEARSE) -- beside the framework's
+            # gather above: step time with and without it, same handle, same stream, host wait once per loop
+            try:
+                from polishpathplanning_amd.robot_path import RcclComm
+                comm = RcclComm(0, 1)
+                rbuf = torch.empty((max(w_all[0], 1), 6), dtype=torch.float32, device=dev)
+                os.environ["PPP_GATHER_REHEARSE"] = "1"
+
+                def loop(with_gather, count):
+                    t = time.perf_counter()
+                    for _ in range(count):
+                        eng.run_async()
+                        if with_gather:
+                            eng.gather_waypoints(comm.ptr, 0, 1, 0, [w_all[0]], rbuf.data_ptr())
+                    eng.sync()
+                    return (time.perf_counter() - t) / count * 1e3
+                cnt = max(10, args.steps)
+                loop(True, 3); loop(False, 3)
+                t_with = min(loop(True, cnt) for _ in range(3)); t_without = min(loop(False, cnt) for _ in range(3))
+                same = bool(np.array_equal(rbuf[: w_all[0]].cpu().numpy(), eng.waypoints()))
+                engine_gather = {"step_ms_with_group_send_recv": t_with, "step_ms_without_exchange": t_without, "added_us": (t_with - t_without) * 1e3,
+                                 "received_block_equals_the_list": same,
+                                 "note": "one rank, real librccl: ncclSend to self + ncclRecv from self in one group on the planner's stream"}
+                del os.environ["PPP_GATHER_REHEARSE"]
+                comm.close()
+            except Exception as ex:
+                engine_gather = {"error": "%s: %s" % (type(ex).__name__, ex)}
         multi = {"n_ranks_seen": {"torch_distributed_world_size": int(dist.get_world_size()), "rccl_allreduce_of_ones": int(round(float(ones.item())))},
+                 "engine_gather_rehearsal": engine_gather,
                  "waypoints_per_rank": [int(round(float(x))) for x in wl.cpu().tolist()],
                  "gather_ms_per_step_alone": float(tg.item()),
                  "note": "gather_ms_per_step_alone: the collective back to back with a host wait around the loop; inside the timed loop it "
@@ -289,10 +334,12 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_MEASURED_COPY_GBS,
                     "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_total": load_traffic_total(launches, workload_key)[0],
                     "launches_per_pass": launches.get(dom, 1),
                     "avg_launch_ms": kern_ms[dom] / max(1, launches.get(dom, 1)),
                     "note": "one pass = one launch of every stage over the %d workpiece(s) of a step; kernel_ms are per pass (summed "
-                            "over a kernel's launches); algorithmic_bytes = 12 B x points + 24 B x waypoints of the step" % args.batch,
+                            "over a kernel's launches); algorithmic_bytes = 12 B x points + 24 B x waypoints of the step; traffic = HBM bytes "
+                            "of the dominant kernel's launches, traffic_total = of every launch of the pass (committed PMC summaries)" % args.batch,
                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
                     "algorithmic_bytes": alg_bytes,
                     "pipeline_gbs": alg_bytes / (elapsed / args.steps) / 1e9}
@@ -354,6 +401,17 @@ def main():
         if world == 1 and args.batch == 1 and not args.dynamic and not args.no_dynamic:
             dynamic = measure_dynamic(args, engine, cfg, pts, local_rank, None if args.no_cpu_baseline else "oracle")
 
+        # ---- the bandwidth-sized BASELINE configurations (configs[2]: 64 x 250 k points in batched launches; configs[4]: 10 M points /
+        # 1024 slices) in the same process, after the headline: lines of the record, never the headline ----
+        other = None
+        if world == 1 and args.batch == 1 and not args.dynamic and not args.no_other_configs and args.config == "cfg2_1m_s256":
+            other = {}
+            for key, name, nb, checked in (("cfg3b64", "cfg3_250k_s128", 64, 16), ("cfg5", "cfg5_10m_s1024", 1, 1)):
+                try:
+                    other[key] = measure_other_config(args, engine, synth, local_rank, name, nb, 0 if args.no_cpu_baseline else checked)
+                except Exception as ex:   # the headline line must not depend on these
+                    other[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
         out = {
             "metric": "polishing waypoints/sec for 1M-pt cloud, 256 slices; path L2 err vs ref",
             "value": value, "unit": "waypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,6 +428,7 @@ def main():
             "assembled_path": assembled,
             "latency": latency,
             "dynamic": dynamic,
+            "other_configs": other,
             "multi_gpu": multi,
             "exchange": ("torch.distributed gather to rank 0 over RCCL (direct send/recv of padded blocks), asynchronous behind each "
                          "step in the planner's stream order" if gatherers[0].dist else None),
@@ -378,6 +437,86 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def measure_other_config(args, engine, synth, local_rank, name, nb, n_checked):
+    """One of the bandwidth-sized BASELINE configurations through the same entry point as the headline's timed loop
+    (ppp_run_batch_async: one launch per stage over the step's workpieces), clouds resident, `steps` steps enqueued back to back
+    with one host wait at the end; then the stages' HIP-event durations, and the path error of `n_checked` members against the
+    oracle's fast mode (its kd index instead of per-slice scans: a check, not a timed baseline)."""
+    from polishpathplanning_amd.hipbuf import DeviceBuffer
+    base_seed = sorted(synth.CONFIGS).index(name) + 1
+    amp_rng = np.random.default_rng(base_seed)
+    engines, clouds, w_all = [], [], []
+    for bi in range(nb):
+        over = {}
+        if nb > 1:
+            over["amp"] = float(synth.CONFIGS[name]["amp"] * amp_rng.uniform(0.5, 1.5))
+        pts, cfg = synth.make_config(name, seed=base_seed + 17 * bi, **over)
+        e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+        e.set_cloud(pts)
+        S = e.gen_path()
+        w_all.append(e.get_path())
+        if cfg.get("slices") and S != cfg["slices"]:
+            raise RuntimeError("config %s produced %d slices, expected %d" % (name, S, cfg["slices"]))
+        engines.append(e); clouds.append(pts)
+    offs = np.concatenate([[0], np.cumsum(w_all)[:-1]]).astype(np.int64)
+    buf = DeviceBuffer(int(sum(w_all)) * 24)
+    steps = max(5, min(args.steps, 20))
+    for _ in range(3):
+        engine.run_batch_async(engines, buf.ptr, offs, w_all)
+    engine.sync_batch(engines)
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        for _ in range(steps):
+            engine.run_batch_async(engines, buf.ptr, offs, w_all)
+        engine.sync_batch(engines)
+        dt = (time.perf_counter() - t) / steps
+        best = dt if best is None else min(best, dt)
+    eng = engines[0]
+    eng.enable_timing(True)
+    acc, launches = {}, {}
+    for _ in range(5):
+        engine.run_batch_async(engines, buf.ptr, offs, w_all)
+        engine.sync_batch(engines)
+        kt, launches = eng.kernel_times(with_launches=True)
+        for k, v in kt.items():
+            acc.setdefault(k, []).append(v)
+    eng.enable_timing(False)
+    kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    dom = max(kern_ms, key=kern_ms.get)
+    n_points = int(sum(int(c.shape[0]) for c in clouds))
+    alg_bytes = 12.0 * n_points + 24.0 * float(sum(w_all))
+    workload_key = name + ("_b%d" % nb if nb > 1 else "")
+    out = {"workload": name, "workpieces": nb, "points": n_points, "slices_per_workpiece": int(engines[0].num_slices()), "waypoints": int(sum(w_all)),
+           "steps": steps, "ms_per_step": best * 1e3, "waypoints_per_s": float(sum(w_all)) / best, "algorithmic_bytes": alg_bytes,
+           "pipeline_gbs": alg_bytes / best / 1e9, "pipeline_frac_of_peak": alg_bytes / best / 1e9 / HBM_PEAK_GBS,
+           "launch_path": ("window (%d launches)" if eng.fast_path() else "slab index (%d launches)") % sum(launches.values()),
+           "dominant_kernel": dom, "dominant_kernel_ms": kern_ms[dom], "dominant_kernel_gbs": alg_bytes / (kern_ms[dom] * 1e-3) / 1e9,
+           "dominant_kernel_frac": alg_bytes / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
+           "traffic_total": load_traffic_total(launches, workload_key)[0],
+           "note": "best of 3 runs of `steps` steps enqueued back to back, one host wait per run; kernel_ms from HIP events around every "
+                   "launch of a pass enqueued directly (full-width launches; the timed loop's graph may run a batch as two halves)"}
+    if n_checked:
+        from oracle import ppo
+        members = sorted(set(int(round(q)) for q in np.linspace(0, nb - 1, min(n_checked, nb))))
+        worst, rms2, rows, equal = 0.0, 0.0, 0, True
+        for bi in members:
+            o = ppo.Oracle(clouds[bi], tool_radius=synth.CONFIGS[name]["tool_radius"])
+            o.gen_path(); o.get_path()
+            gw, ow = engines[bi].waypoints(), o.waypoints()
+            if gw.shape != ow.shape or not len(gw):
+                equal = False
+                continue
+            d = np.linalg.norm(gw[:, :3] - ow[:, :3], axis=1)
+            worst = max(worst, float(d.max())); rms2 += float((d ** 2).sum()); rows += len(d)
+        out["path_l2_err"] = {"max_m": worst, "rms_m": float(np.sqrt(rms2 / max(rows, 1))), "waypoints_equal": equal, "members_checked": members,
+                              "against": "the oracle's fast mode"}
+    for e in engines:
+        e.close()
     return out
 
 

@@ -15,6 +15,18 @@
 #include <string>
 #include <vector>
 #include "Spline.h"
+/* The reference's drivers write `cout << ... << endl` unqualified (src/main.cpp:10,16, src/connect.cpp:13,19,
+   src/connect1.cpp:13,19, src/contour.cpp:13,19).  Upstream those names reach them through THIS header ->
+   pcl/visualization/cloud_viewer.h -> VTK's vtkIOStream.h (`using std::cout; using std::endl; using std::cerr;` at global
+   scope).  The drop-in header takes PCL and VTK away, so it supplies the same three names itself -- here, in the header
+   the drivers include, not in ppp_planner.hpp / Spline.h, whose other includers get nothing at global scope
+   (tests/test_host_logic.py::test_reference_drivers_compile_unchanged).  -DPPP_NO_GLOBAL_IOSTREAM_NAMES leaves them out. */
+#ifndef PPP_NO_GLOBAL_IOSTREAM_NAMES
+#include <iostream>
+using std::cerr;
+using std::cout;
+using std::endl;
+#endif
 
 class path_generater {
 public:

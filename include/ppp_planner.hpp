@@ -45,16 +45,6 @@ typedef PppVec3<double> Vector3d;
 
 typedef std::map<double, std::vector<double>> MAP; /* Path_Generate_Algorithm.h:53 */
 
-/* The reference's drivers write `cout << ... << endl` unqualified (src/main.cpp:10,16, src/connect.cpp:13,19,
-   src/connect1.cpp:13,19, src/contour.cpp:13,19).  Upstream those names reach them through
-   include/Path_Generate.h:12 / Path_Generate_Algorithm.h:17 -> pcl/visualization/cloud_viewer.h -> VTK's
-   vtkIOStream.h, which has `using std::cout; using std::endl; using std::cerr; ...` at global scope.  The drop-in
-   headers take PCL and VTK away, so they supply the same names themselves: the drivers compile unchanged
-   (tests/test_host_logic.py::test_reference_drivers_compile_unchanged). */
-using std::cerr;
-using std::cout;
-using std::endl;
-
 namespace ppp {
 
 /* One engine handle + the state every planner class of the reference keeps. */

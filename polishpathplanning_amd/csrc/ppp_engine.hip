@@ -373,6 +373,18 @@ int validate_params(ppp_handle h, const ppp_params *p)
     return PPP_OK;
 }
 
+/* Launch-geometry / search-radius overrides of the tuning scripts (tools/_run_*.sh): read only by builds made with -DPPP_TUNING
+   (make variant NAME=tune DEFS=-DPPP_TUNING); the product library ignores them, so a stray variable cannot change a plan. */
+static inline const char *tuning_env(const char *name)
+{
+#ifdef PPP_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 DynParams dyn_params(const ppp_handle h)
 {
     DynParams D;
@@ -382,7 +394,7 @@ DynParams dyn_params(const ppp_handle h)
     double area = ((double)h->h_mx[0] - h->h_mn[0]) * ((double)h->h_mx[1] - h->h_mn[1]);
     double rho = (area > 0 && h->h_nvalid > 0) ? (double)h->h_nvalid / area : 1.0;
     D.r0 = (float)std::max(0.5, 1.25 * std::sqrt((double)D.k / (3.14159265358979 * rho)));
-    if (const char *ev = getenv("PPP_DYN_R0F")) D.r0 = (float)std::max(0.5, atof(ev) * std::sqrt((double)D.k / (3.14159265358979 * rho))); /* tuning runs only */
+    if (const char *ev = tuning_env("PPP_DYN_R0F")) D.r0 = (float)std::max(0.5, atof(ev) * std::sqrt((double)D.k / (3.14159265358979 * rho))); /* tuning runs only */
     D.r1 = (float)std::max(0.25, 2.0 * std::sqrt(1.0 / (3.14159265358979 * rho)));
     return D;
 }
@@ -460,7 +472,7 @@ int win_pick_threads(const ppp_handle h, long long wgs)
         T = std::min(wide, 64 * std::max(1, 16 / conc));
     }
     T = std::max(T, tmin);
-    if (const char *ev = getenv("PPP_WIN_T")) { /* tuning runs only */
+    if (const char *ev = tuning_env("PPP_WIN_T")) { /* tuning runs only */
         const int tv = atoi(ev);
         if (tv >= tmin && tv <= 1024 && tv % 64 == 0) T = tv;
     }
@@ -548,15 +560,15 @@ int plan_window(ppp_handle h, int S, double per)
        as many points per thread as the stage has room for */
     {
         int from = PPP_PPT16_FROM;
-        if (const char *ev = getenv("PPP_WIN_STAGE_FROM")) from = atoi(ev); /* tuning runs only */
-        h->win_staged = n_src > from && !getenv("PPP_WIN_NO_STAGE");
+        if (const char *ev = tuning_env("PPP_WIN_STAGE_FROM")) from = atoi(ev); /* tuning runs only */
+        h->win_staged = n_src > from && !tuning_env("PPP_WIN_NO_STAGE");
     }
     if (h->win_staged) {
         h->win_ppt = 8;
         if (win_scatter_lds_bytes(S, 8, WSC_T, true) + 2048 > (size_t)h->max_lds) h->win_ppt = 4;
         if (win_scatter_lds_bytes(S, h->win_ppt, WSC_T, true) + 2048 > (size_t)h->max_lds) { h->win_staged = false; h->win_ppt = 8; }
     }
-    if (const char *ev = getenv("PPP_WIN_PPT")) { const int pv = atoi(ev); if ((pv == 4 || pv == 8) && !h->win_staged) h->win_ppt = pv; } /* tuning runs only */
+    if (const char *ev = tuning_env("PPP_WIN_PPT")) { const int pv = atoi(ev); if ((pv == 4 || pv == 8) && !h->win_staged) h->win_ppt = pv; } /* tuning runs only */
     h->win_gs = std::max(1, (n_src + h->win_ppt * WSC_T - 1) / (h->win_ppt * WSC_T));
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
@@ -1193,6 +1205,9 @@ int ppp_create(int device_id, ppp_handle *out)
     ppp_default_params(&h->P);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     if (h->meta.ensure(1) != hipSuccess) { delete h; return PPP_ERR_HIP; }
+    /* a handle that finishes a gathered list before it ever ran a pass (ppp_finish_path_async) reads win_flag, S and the bounds
+       from this block: hipMalloc does not clear it */
+    if (hipMemset(h->meta.p, 0, sizeof(DevMeta)) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     if (hipHostMalloc((void **)&h->hmeta_pinned, sizeof(DevMeta), hipHostMallocDefault) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) h->max_lds = lds;
@@ -2313,7 +2328,9 @@ int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, in
     if (!h->path_done || !h->list_final) return fail(h, PPP_ERR_ARG, "no finished list on this handle (call ppp_get_path_async / ppp_run_async first)");
     if (counts_rows[rank] > (size_t)h->W_cap) return fail(h, PPP_ERR_CAPACITY, "counts_rows[rank] exceeds this handle's list capacity");
     if (rank == root && !recv_dev) return fail(h, PPP_ERR_ARG, "the root needs a receive buffer");
-    if (nranks == 1) { /* nothing to exchange: the list goes to the receive buffer */
+    /* rehearsal (one rank, a real one-rank communicator): the block travels through librccl's send / recv group instead of the copy */
+    const bool rehearse = nranks == 1 && nccl_comm != nullptr && getenv("PPP_GATHER_REHEARSE") != nullptr;
+    if (nranks == 1 && !rehearse) { /* nothing to exchange: the list goes to the receive buffer */
         if (counts_rows[0]) HIPCHK(h, hipMemcpyAsync(recv_dev, h->wp_out.p, counts_rows[0] * 24, hipMemcpyDeviceToDevice, h->stream));
         return PPP_OK;
     }
@@ -2328,7 +2345,9 @@ int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, in
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : 1;
     };
     int nres = 0;
-    switch (ppp_gather_exchange(ops, rank, nranks, root, counts_rows, h->wp_out.p, recv_dev, nccl_comm, (void *)h->stream, &nres)) {
+    const int gres = rehearse ? ppp_gather_self_loop(ops, counts_rows[0], h->wp_out.p, recv_dev, nccl_comm, (void *)h->stream, &nres)
+                              : ppp_gather_exchange(ops, rank, nranks, root, counts_rows, h->wp_out.p, recv_dev, nccl_comm, (void *)h->stream, &nres);
+    switch (gres) {
     case PPP_GATHER_OK: break;
     case PPP_GATHER_COPY_FAILED: return fail(h, PPP_ERR_HIP, "copy of the root's own block failed");
     case PPP_GATHER_GROUP_START_FAILED: return fail(h, PPP_ERR_HIP, "ncclGroupStart failed (ncclResult " + std::to_string(nres) + ")");

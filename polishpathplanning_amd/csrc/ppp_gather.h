@@ -48,3 +48,22 @@ static inline int ppp_gather_exchange(const PppGatherOps &ops, int rank, int nra
     if (e || e2) { if (nccl_result) *nccl_result = e ? e : e2; return PPP_GATHER_XFER_FAILED; }
     return PPP_GATHER_OK;
 }
+
+/* Pre-flight of the group path on ONE rank (no second GPU needed): the rank sends its block to itself and receives it, both
+   inside one ncclGroupStart / ncclGroupEnd -- the same calls, datatype, communicator and stream a multi-rank gather hands to
+   librccl, with real transfers behind them (ppp_gather_waypoints with nranks == 1 and PPP_GATHER_REHEARSE=1;
+   tests/test_gpu_parity.py::test_gather_rehearsal_through_the_real_rccl). */
+static inline int ppp_gather_self_loop(const PppGatherOps &ops, size_t rows, const float *send, float *recv, void *comm, void *stream,
+                                       int *nccl_result)
+{
+    const int kFloat = 7; /* ncclFloat32 */
+    if (nccl_result) *nccl_result = 0;
+    if (!rows) return PPP_GATHER_OK;
+    int e = ops.group_start();
+    if (e) { if (nccl_result) *nccl_result = e; return PPP_GATHER_GROUP_START_FAILED; }
+    e = ops.send(send, rows * 6, kFloat, 0, comm, stream);
+    if (!e) e = ops.recv(recv, rows * 6, kFloat, 0, comm, stream);
+    const int e2 = ops.group_end(); /* always reached */
+    if (e || e2) { if (nccl_result) *nccl_result = e ? e : e2; return PPP_GATHER_XFER_FAILED; }
+    return PPP_GATHER_OK;
+}

@@ -1558,6 +1558,7 @@ __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, i
         m->any_short = s_short;
         m->nkept = nk;
         m->big_slabs = 0; m->big_slices = 0; /* the index of this handle plays no part in what follows */
+        m->win_flag = 0;                     /* ... and neither does a window pass: nothing here may ask for a re-run on the slab path */
         int W = s_run;
         if (W != W_given || W > W_cap) { m->err = DERR_CAPACITY; W = 0; }
         m->W = W;

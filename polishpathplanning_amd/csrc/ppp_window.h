@@ -293,6 +293,15 @@ __device__ __forceinline__ int win_unit_class(int G, int round, int g)
 #ifndef WSL_T
 #define WSL_T 1024
 #endif
+/* diagnostic builds (tools/phase_costs.sh): the slice kernel leaves after phase WIN_STOP_AFTER, so that the difference of two
+   builds' durations and instruction counters is that phase's bill.  `sink` keeps the phase's register results alive.  Never
+   defined in the product. */
+#ifdef WIN_STOP_AFTER
+#define WIN_STOP(slot, sink) do { if (WIN_STOP_AFTER == (slot)) { A.wps_nn[tid] = (int)(sink); \
+        if ((slot) < 5 && tid == 0) { A.node_start[s] = 0; A.node_cnt[s] = 0; if (kept) A.wp_cnt[k] = 0; } return; } } while (0)
+#else
+#define WIN_STOP(slot, sink) do { } while (0)
+#endif
 
 template <int TMAX>
 __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
@@ -346,6 +355,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     for (int b = tid; b <= NB; b += T) tab[b] = 0;
     __syncthreads();
     STAMP(6, 0); /* window load issued, table cleared */
+    WIN_STOP(0, __float_as_int(pr[0].x) ^ __float_as_int(pr[WIN_EMAX - 1].y));
 #pragma unroll
     for (int e = 0; e < WIN_EMAX; ++e) {
         const int i = tid + e * T;
@@ -379,6 +389,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) pts[atomicAdd(&tab[pb[e]], 1)] = pr[e];
     __syncthreads();
     STAMP(6, 1); /* histogram, scan, placement */
+    WIN_STOP(1, pb[0] ^ pb[WIN_EMAX - 1]);
     /* tab[b] is now the END of bucket b.  Inside a bucket (a point or two, a dozen in the densest windows) the points stand in
        arrival order: every point counts the members of its bucket that precede it on (y, cloud index) -- independent reads, no
        chain of dependent moves as in an insertion sort -- and takes that place. */
@@ -406,6 +417,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     if (tid <= WIN_CLASSES) s_cs[tid] = 0;
     __syncthreads();
     STAMP(6, 2); /* buckets finished */
+    WIN_STOP(2, pb[0] ^ __float_as_int(pts[tid % 64].y));
     if (tid < WIN_CLASSES) s_cs[tid + 1] = tab[(tid + 1) * NBc - 1];
     __syncthreads();
     WinView V;
@@ -445,6 +457,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     for (int b = tid; b <= NBcand; b += T) hc[b] = 0;
     __syncthreads();
     STAMP(6, 3); /* pairing: two nearest-neighbour queries per left point + lerp */
+    WIN_STOP(3, (int)kr[0] ^ kb[0] ^ kb[CE - 1] ^ (int)(kr[CE - 1] >> 32));
 #pragma unroll
     for (int e = 0; e < CE; ++e) if (kb[e] >= 0) atomicAdd(&hc[kb[e]], 1);
     __syncthreads();
@@ -480,11 +493,14 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     if (tid == 0) s_m = 0;
     __syncthreads();
     STAMP(6, 4); /* candidate sort */
+    WIN_STOP(4, (int)ckeys[tid % 64]);
     /* one knot per distinct y: Node[y] = ... is overwritten by every later writer and El is walked in ascending cloud index,
        so the z kept is the one of the candidate with the highest cloud index inside the run of equal keys.  The knots take
        the place of the sorted keys: everything a chunk needs of them is read before the scan's barriers, written after. */
     for (int base = 0; base < nEl; base += T) {
         const int j = base + tid;
+        const int o0 = s_m; /* slots below o0 hold knots of earlier chunks by now; a run of equal keys that reaches into this chunk
+                               starts at or above o0 (every finished run left one knot and has at least one member) */
         int keep = 0;
         float ky = 0.f, kz = 0.f;
         if (j < nEl) {
@@ -493,7 +509,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             if (keep) {
                 int best_i = YK_POS(kj);
                 int best_idx = idx_of(pts[el0 + best_i]);
-                for (int q = j - 1; q >= 0 && YK_Y(ckeys[q]) == YK_Y(kj); --q) {
+                for (int q = j - 1; q >= o0 && YK_Y(ckeys[q]) == YK_Y(kj); --q) {
                     const int ci = YK_POS(ckeys[q]);
                     const int id = idx_of(pts[el0 + ci]);
                     if (id > best_idx) { best_idx = id; best_i = ci; }
@@ -503,7 +519,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         }
         int tot;
         const int pre = block_exscan_w(keep, s_scr, &tot);
-        const int o = s_m;
+        const int o = o0;
         __syncthreads();
         if (keep) knot[o + pre] = make_float2(ky, kz);
         if (tid == 0) s_m = o + tot;
@@ -529,6 +545,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     __syncthreads();
     const int nknots = s_nk, cnt = s_cnt;
     STAMP(6, 5); /* map flattening, knot count, waypoint count */
+    WIN_STOP(5, nknots ^ cnt ^ __float_as_int(knot[0].y));
     for (int i = tid; i < nknots; i += T) {
         const float2 kn = knot[i];
         A.node_x[s_base + i] = Px; /* insert_cloud.points[i].x = PlanePoint[0] */
@@ -580,6 +597,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         const bool finite = q.y == q.y && q.z == q.z;
         const bool on = act && finite;
         STAMP(6, 6); /* knots out, dy, interval, Steffen */
+        WIN_STOP(6, __float_as_int(q.z) ^ iv);
         /* -- kdtree.nearestKSearch(q, 1) (:189): inner classes first, the outer ones are closed by their x gap almost always -- */
         float best = P.nn_hint2;
         int bidx = 0x7fffffff;
@@ -617,6 +635,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         }
         const bool found = on && bidx != 0x7fffffff;
         STAMP(6, 7); /* nearest point */
+        WIN_STOP(7, bidx ^ __float_as_int(bp.z));
         /* the window holds every point within `pad` of the plane: the answers are the whole cloud's as long as the ball that
            proves the nearest neighbour and the normal's radius search stay inside it */
         if (on && g == 0) {
@@ -676,6 +695,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             count += cn;
         }
         STAMP(6, 8); /* normal: radius search + covariance */
+        WIN_STOP(8, count ^ __float_as_int(acc[0] + acc[4] + acc[8]));
         if (act && g == 0) {
             float n4[4] = {NAN, NAN, NAN, NAN};
             if (found && count >= 3) {

@@ -294,3 +294,43 @@ def write_path_file(path, wp6):
 def _ostream_float(v):
     # std::ostream << float with default flags == printf("%g")
     return "%g" % float(v)
+
+
+class RcclComm:
+    """An ncclComm_t of this process's own, made through the librccl the engine itself resolves (dlopen("librccl.so"): the same
+    library instance ppp_gather_waypoints calls into) -- for C++-style callers of ppp_gather_waypoints that own their communicator,
+    and for its one-rank pre-flight.  world == 1 needs no rendezvous; world > 1 takes the 128-byte unique id from `broadcast`
+    (a callable bytes -> bytes that hands rank 0's id to every rank, e.g. over torch.distributed)."""
+
+    def __init__(self, rank=0, world=1, broadcast=None, lib_path=None):
+        import ctypes as C
+        import os
+        name = lib_path or os.environ.get("PPP_RCCL_LIB") or "librccl.so"
+        try:
+            self.lib = C.CDLL(name, mode=C.RTLD_GLOBAL)
+        except OSError:
+            self.lib = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc:
+                raise RuntimeError("ncclGetUniqueId failed (ncclResult %d)" % rc)
+        if world > 1:
+            raw = broadcast(bytes(uid.internal) if rank == 0 else b"\0" * 128)
+            C.memmove(C.byref(uid), raw, 128)
+        self.comm = C.c_void_p()
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), int(world), uid, int(rank))
+        if rc:
+            raise RuntimeError("ncclCommInitRank failed (ncclResult %d)" % rc)
+        self.ptr = self.comm.value
+
+    def close(self):
+        if getattr(self, "comm", None) is not None and self.comm.value:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None

@@ -835,6 +835,29 @@ class _DeviceBuffer:
         return self._b.to_host(nfloats).reshape(-1, 6)
 
 
+def test_finish_on_a_fresh_handle_that_never_ran_a_pass(engine_mod):
+    """ppp_finish_path_async on a handle that was created, given the cloud and nothing else (rank 0 of --mode slices may do
+    exactly that): the meta block of such a handle has never been written by a pass, so nothing in it may ask for a re-run
+    (a stale win_flag made ppp_sync repeat the plan on the slab path over the list just finished) and the getters must
+    report the finished list."""
+    pts, cfg = synth.make_config("small_40k")
+    one = engine_mod.Engine(0, tool_radius=6.0); one.set_cloud(pts); one.gen_path(); W = one.get_path()
+    pre = one.stage(engine_mod.STAGE_WP_PRESMOOTH)
+    counts = one.waypoint_counts()
+    src = _DeviceBuffer(W * 24)
+    assert one.copy_stage_to_device(engine_mod.STAGE_WP_PRESMOOTH, src.ptr, W) == W
+    for fast in (True, False):
+        fresh = engine_mod.Engine(0, tool_radius=6.0, fast_path=fast)
+        fresh.set_cloud(pts)
+        fresh.finish_path_async(src.ptr, W, counts)
+        fresh.sync()
+        assert fresh.num_waypoints() == W
+        assert fresh.waypoints().tobytes() == one.waypoints().tobytes()
+        assert np.array_equal(fresh.tail_index(), one.tail_index())
+        assert np.array_equal(fresh.stage(engine_mod.STAGE_WP_PRESMOOTH), pre)
+        fresh.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_slice_range_sharding_is_bit_identical_to_one_handle(engine_mod, world):
     pts, cfg = synth.make_config("small_40k")
@@ -1535,6 +1558,44 @@ def test_gather_waypoints_multi_rank_pattern_through_a_recording_rccl(tmp_path):
     assert d["send_log"][1].startswith("send buf=") and d["send_log"][1].endswith("count=%d " % (6 * W) + tail % (2, stream))
     assert d["fail_raised"] and "ncclResult 5" in d["fail_msg"]
     assert d["fail_log"][0] == "group_start" and d["fail_log"][-1] == "group_end" and len(d["fail_log"]) == 3   # no second recv after the failure
+
+
+def test_gather_rehearsal_through_the_real_rccl():
+    """Pre-flight of ppp_gather_waypoints' send / recv group against the REAL librccl on one GPU: a one-rank
+    communicator, PPP_GATHER_REHEARSE=1, the handle's list sent to itself and received inside one ncclGroupStart / ncclGroupEnd on
+    the handle's stream; the received block equals the list byte for byte.  In a child process with a deadline: a collective
+    that never completes must not take the suite with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from polishpathplanning_amd import engine, synth
+from polishpathplanning_amd.hipbuf import DeviceBuffer
+from polishpathplanning_amd.robot_path import RcclComm
+pts, cfg = synth.make_config("small_40k")
+e = engine.Engine(0, tool_radius=6.0); e.set_cloud(pts); e.gen_path(); W = e.get_path()
+own = e.waypoints()
+comm = RcclComm(0, 1)
+recv = DeviceBuffer(W * 24)
+plain = DeviceBuffer(W * 24)
+e.gather_waypoints(0, 0, 1, 0, [W], plain.ptr); e.sync()          # the lone rank's plain copy
+os.environ["PPP_GATHER_REHEARSE"] = "1"
+for _ in range(3):                                                   # the group path, more than once on the same communicator
+    e.gather_waypoints(comm.ptr, 0, 1, 0, [W], recv.ptr)
+e.sync()
+got = recv.to_host(W * 6).reshape(-1, 6)
+print(json.dumps({"W": int(W), "equal": bool(got.tobytes() == own.tobytes()), "plain_equal": bool(plain.to_host(W * 6).reshape(-1, 6).tobytes() == own.tobytes())}))
+comm.close()
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1])
+    assert d["W"] > 0 and d["equal"] and d["plain_equal"], d
 
 
 def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):

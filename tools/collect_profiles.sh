@@ -4,12 +4,12 @@
 # Usage: tools/collect_profiles.sh <tag> [bench args...]
 set -o pipefail
 TAG=${1:-r01}; shift
-case " $* " in *" --gpus "*) echo "collect_profiles.sh: profile one rank (PPP_BENCH_FORCE_DIST=1 rehearses the exchange): a profiled process must not start the launcher"; exit 2;; esac
+case " $* " in *" --gpus "*|*" --gpus="*) echo "collect_profiles.sh: profile one rank (PPP_BENCH_FORCE_DIST=1 rehearses the exchange): a profiled process must not start the launcher"; exit 2;; esac
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-dynamic --rotate 0 --profile-passes 3 $@"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-dynamic --no-other-configs --rotate 0 --profile-passes 3 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/pmc_fetch.log 2>&1 || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/pmc_write.log 2>&1 || echo "write failed"

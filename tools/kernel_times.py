@@ -13,6 +13,10 @@ args = sys.argv[1:]
 if args and args[0] == "--lib":
     engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), args[1])
     args = args[2:]
+loose = False
+if args and args[0] == "--loose":          # diagnostic builds whose results are wrong on purpose (tools/phase_costs.sh): errors are reported, not raised
+    loose = True
+    args = args[1:]
 rng_kw = {}
 if args and args[0] == "--range":          # one slice-range handle: --range begin:end
     b, e_ = args[1].split(":")
@@ -22,6 +26,16 @@ for name in args or ["cfg2_1m_s256"]:
     pts, cfg = synth.make_config(name)
     e = engine.Engine(0, tool_radius=cfg["tool_radius"], **rng_kw)
     e.set_cloud(pts)
+    if loose:
+        _sync = e.sync
+        def _loose_sync():
+            try:
+                _sync()
+            except engine.PPPError as ex:
+                if not getattr(e, "_told", False):
+                    print("   (loose) sync reports:", ex); e._told = True
+        e.sync = _loose_sync
+        e.waypoints = lambda: __import__("numpy").zeros(0)
     e.run_async(); e.sync()
     W = e.num_waypoints()
     ts = []

@@ -3,10 +3,11 @@
 # and the share of lanes the VALU instructions had active.  usage (GPU box): bash tools/pmc_insts.sh [bench args]
 set -o pipefail
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+case " $* " in *" --gpus "*|*" --gpus="*) echo "$0: profile one rank (PPP_BENCH_FORCE_DIST=1 rehearses the exchange): a profiled process must not start the launcher"; exit 2;; esac
+cd "${GRAFT_REPO_ROOT:-$(pwd)}" || exit 2
 OUT=gpurun_out/pmc_insts
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dynamic --rotate 0 --profile-passes 3 "$@" > $OUT/log.txt 2>&1 || echo failed
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dynamic --no-other-configs --rotate 0 --profile-passes 3 "$@" > $OUT/log.txt 2>&1 || echo failed
 python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()

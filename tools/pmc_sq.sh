@@ -3,10 +3,11 @@
 # usage (GPU box): bash tools/pmc_sq.sh  -> table on stdout, raw csv under gpurun_out/pmc_sq
 set -o pipefail
 export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+case " $* " in *" --gpus "*|*" --gpus="*) echo "$0: profile one rank (PPP_BENCH_FORCE_DIST=1 rehearses the exchange): a profiled process must not start the launcher"; exit 2;; esac
+cd "${GRAFT_REPO_ROOT:-$(pwd)}" || exit 2
 OUT=gpurun_out/pmc_sq
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dynamic --rotate 0 --profile-passes 3 "$@" > $OUT/log.txt 2>&1 || echo failed
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dynamic --no-other-configs --rotate 0 --profile-passes 3 "$@" > $OUT/log.txt 2>&1 || echo failed
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/pmc_sq/**/*counter_collection.csv', recursive=True)
