@@ -159,7 +159,7 @@ struct ppp_handle_s {
     DevBuf<int> win_cnt;
     DevBuf<float4> win_pts;
     DevBuf<MinMaxPart> win_part;
-    DevBuf<float4> wps_xyz, wps_normal;
+    DevBuf<float4> wps_xyz, wps_normal, wps_rec;
     DevBuf<int> wps_nn;
     DevBuf<float> wps_pre;
 
@@ -223,7 +223,7 @@ struct ppp_handle_s {
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
         mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
-        win_px.release(); win_cnt.release(); win_pts.release(); win_part.release(); wps_xyz.release(); wps_normal.release(); wps_nn.release(); wps_pre.release();
+        win_px.release(); win_cnt.release(); win_pts.release(); win_part.release(); wps_xyz.release(); wps_normal.release(); wps_nn.release(); wps_pre.release(); wps_rec.release();
         drop_graph();
         drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
@@ -584,7 +584,7 @@ int plan_window(ppp_handle h, int S, double per)
         HIPCHK(h, h->node_x.ensure(h->node_cap)); HIPCHK(h, h->node_y.ensure(h->node_cap)); HIPCHK(h, h->node_z.ensure(h->node_cap));
     }
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
-    HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots));
+    HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots)); HIPCHK(h, h->wps_rec.ensure(4 * slots));
     if (!from_auto) /* the windows' counters: every pass leaves them cleared again (in stream order ahead of the first pass: no wait); the census that came with the cloud has cleared its own */
         HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * std::max<size_t>(3, WIN_CNT_STRIDE), h->stream));
     h->win_path = true;
@@ -620,7 +620,7 @@ WinArgs win_args(const ppp_handle h)
     A.node_x = h->node_x.p; A.node_y = h->node_y.p; A.node_z = h->node_z.p;
     A.node_start = h->node_start.p; A.node_cnt = h->node_cnt.p; A.band_cnt = h->band_cnt.p;
     A.wp_cnt = h->wp_cnt.p; A.wp_off = h->wp_off.p; A.tail = h->tail.p;
-    A.wps_xyz = h->wps_xyz.p; A.wps_normal = h->wps_normal.p; A.wps_nn = h->wps_nn.p; A.wps_pre = h->wps_pre.p;
+    A.wps_xyz = h->wps_xyz.p; A.wps_normal = h->wps_normal.p; A.wps_nn = h->wps_nn.p; A.wps_pre = h->wps_pre.p; A.wps_rec = h->wps_rec.p;
     A.wp_pre = h->wp_pre.p; A.wp_smooth = h->wp_smooth.p; A.wp_out = h->wp_out.p; A.out2 = h->out2; A.out2_cap = h->out2_cap;
     return A;
 }
