@@ -41,6 +41,7 @@
 
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -160,6 +161,7 @@ struct ppp_handle_s {
     DevBuf<float4> win_pts;
     DevBuf<MinMaxPart> win_part;
     DevBuf<float4> wps_xyz, wps_normal, wps_rec;
+    DevBuf<int> fin_ticket; /* arrivals of the window finish launch's workgroups (the last one publishes the meta block) */
     DevBuf<int> wps_nn;
     DevBuf<float> wps_pre;
 
@@ -622,6 +624,7 @@ WinArgs win_args(const ppp_handle h)
     A.wp_cnt = h->wp_cnt.p; A.wp_off = h->wp_off.p; A.tail = h->tail.p;
     A.wps_xyz = h->wps_xyz.p; A.wps_normal = h->wps_normal.p; A.wps_nn = h->wps_nn.p; A.wps_pre = h->wps_pre.p; A.wps_rec = h->wps_rec.p;
     A.wp_pre = h->wp_pre.p; A.wp_smooth = h->wp_smooth.p; A.wp_out = h->wp_out.p; A.out2 = h->out2; A.out2_cap = h->out2_cap;
+    A.meta_host = h->hmeta_pinned; A.fin_ticket = h->fin_ticket.p; /* (a member of a batch of several publishes into the batch's pinned array: upload_members_win) */
     return A;
 }
 size_t win_slice_lds(const ppp_handle h) { return win_slice_lds_for(h, h->win_NBc); }
@@ -1079,6 +1082,10 @@ int slice_lds_ok(ppp_handle h, int capb)
 
 /* workgroups of the bounds pass over n points (k_minmax<false> / k_ingest_minmax) */
 int bounds_grid(size_t n) { return std::max(1, std::min(((int)n / 4 + 255) / 256, 2048)); }
+/* ... of the conversion pass of a new cloud (k_ingest_minmax): about one workgroup per CU, eight points per thread.  Its workgroups
+   end on ONE ticket counter, and same-address atomics serialise at ~11 ns each: the 977 workgroups bounds_grid gives a million
+   points spent 10 us of a 23 us launch queueing there */
+int ingest_grid(size_t n) { return std::max(1, std::min(((int)n / 8 + MM_T - 1) / MM_T, 256)); }
 
 /* may the window path apply to the next plan, as far as the parameters say (plan_window decides with the bounds in hand)? */
 bool window_params_ok(const ppp_handle h)
@@ -1118,7 +1125,7 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
             PA.px = h->win_px.p; PA.px_cap = census ? WIN_AUTO_SCAP : 0;
             PlanAuto *rec0 = (PlanAuto *)(h->pin + PIN_REC0), *rec1 = (PlanAuto *)(h->pin + PIN_REC1);
             rec0->S = -2; rec1->census = 0; rec1->S = -2;
-            hipLaunchKernelGGL(k_ingest_minmax, dim3(g), dim3(MM_T), 0, h->stream, raw, stride_bytes, (int)n, h->P.change_range, h->X.p, h->Y.p,
+            hipLaunchKernelGGL(k_ingest_minmax, dim3(ingest_grid(n)), dim3(MM_T), 0, h->stream, raw, stride_bytes, (int)n, h->P.change_range, h->X.p, h->Y.p,
                                h->Z.p, h->mm_part.p, PA);
             HIPCHK(h, hipGetLastError());
             if (census) {
@@ -1128,7 +1135,16 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
                                    (float *)(h->pin + PIN_PX), (int *)(h->pin + PIN_CENSUS));
                 HIPCHK(h, hipGetLastError());
             }
+#ifdef PPP_TUNING
+            const auto t_enq = std::chrono::steady_clock::now();
+#endif
             HIPCHK(h, hipStreamSynchronize(h->stream));
+#ifdef PPP_TUNING
+            if (getenv("PPP_COLD_DEBUG")) {
+                const auto t_syn = std::chrono::steady_clock::now();
+                fprintf(stderr, "[ppp cold] wait for ingest%s: %.1f us\n", census ? " + census" : "", std::chrono::duration<double, std::micro>(t_syn - t_enq).count());
+            }
+#endif
             if (rec0->S == -2) return fail(h, PPP_ERR_HIP, "the bounds of the new cloud did not arrive");
             h->h_nvalid = rec0->fin.cnt;
             for (int d = 0; d < 3; ++d) { h->h_mn[d] = rec0->fin.mn[d]; h->h_mx[d] = rec0->fin.mx[d]; }
@@ -1208,6 +1224,7 @@ int ppp_create(int device_id, ppp_handle *out)
     /* a handle that finishes a gathered list before it ever ran a pass (ppp_finish_path_async) reads win_flag, S and the bounds
        from this block: hipMalloc does not clear it */
     if (hipMemset(h->meta.p, 0, sizeof(DevMeta)) != hipSuccess) { delete h; return PPP_ERR_HIP; }
+    if (h->fin_ticket.ensure(1 + WIN_FIN_GROUPS) != hipSuccess || hipMemset(h->fin_ticket.p, 0, sizeof(int) * (1 + WIN_FIN_GROUPS)) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     if (hipHostMalloc((void **)&h->hmeta_pinned, sizeof(DevMeta), hipHostMallocDefault) != hipSuccess) { delete h; return PPP_ERR_HIP; }
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0) h->max_lds = lds;
@@ -1811,7 +1828,8 @@ int ppp_get_path_async(ppp_handle h)
         if (rcw) return rcw;
         h->path_done = true;
         h->list_final = !h->ranged;
-        return enqueue_meta_copy(h);
+        h->meta_in_flight = true; h->meta_from_batch = false; /* the finish launch's last workgroup leaves the meta block in hmeta_pinned */
+        return PPP_OK;
     }
     DevParams D = dev_params(h);
     int nk = std::max(1, h->S_cap);
@@ -2034,6 +2052,9 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
         h->out2_cap = dst_dev ? (int)std::min<size_t>(cap_rows[i], 0x7fffffff) : 0;
         WinArgs &A = mem[i];
         A = win_args(h);
+        /* a member publishes its meta block into the batch's pinned array; a batch of ONE -- a stream of steps on one workpiece -- does
+           not publish at all (the arrival counters are a microsecond at the end of every step): the block is fetched when somebody asks */
+        A.meta_host = count > 1 ? bg->hmetas->pinned + i : nullptr;
         h->out2 = nullptr; h->out2_cap = 0;
         A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (the members' partials are sized for 4 points per thread) */
         slices_total += A.g_slice;
@@ -2118,6 +2139,7 @@ int enqueue_batched(ppp_handle lead, BatchGraph *bg)
         HIPCHK(lead, hipEventRecord(bg->join[0], side));
         HIPCHK(lead, hipStreamWaitEvent(lead->stream, bg->join[0], 0));
     }
+    if (bg->win) return PPP_OK; /* every member's finish launch leaves its meta block in pinned memory itself (win_publish_meta) */
     if (count == 1) /* nothing to collect, and nothing to publish per step either: the one meta block is fetched when somebody asks
                        (ppp_sync_batch, a getter) -- in a stream of steps on one workpiece a 200-byte copy behind every pass is a
                        fourth launch (a blit kernel, 4.4 us of a 68 us step) whose result only the last pass's reader looks at */

@@ -66,6 +66,8 @@ struct WinArgs {
     float *wps_pre;
     float *wp_pre, *wp_smooth, *wp_out, *out2;
     int out2_cap;
+    DevMeta *meta_host; /* pinned host memory: the last workgroup of the finish launch leaves the meta block there (no copy command behind a pass) */
+    int *fin_ticket;    /* arrivals of that launch's workgroups (cleared by the last) */
 };
 
 __host__ __device__ inline size_t win_slice_lds_bytes(int capw, int cap_el, int NB)
@@ -830,6 +832,11 @@ __device__ __forceinline__ void win_verify_body(const WinArgs &A)
 /* ------------------------------------------------------------------ */
 /* launch 3: offsets + compaction + postion_smooth / reduceRPY / flange */
 /* ------------------------------------------------------------------ */
+/* words of the meta block written by the finish launch: agent-scope (write-through) stores, so that the workgroup that publishes
+   the block to the host (win_publish_meta) sees them without any workgroup paying a release fence -- on this device a fence at
+   agent scope writes back the whole L2, once per workgroup that executes it (64 x 250 k points: the finish launch 25 -> 126 us) */
+#define WIN_FIN_GROUPS 32 /* first-level arrival counters of the finish launch (win_publish_meta) */
+#define META_PUT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define WIN_S_MAX 8192 /* slices of a plan on this path (plane table and counters of the scatter, offsets of the finish live in LDS) */
 __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
 {
@@ -868,14 +875,14 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
     const int W = s_run;
     if (tid == 0) s_off[nk] = W;
     __syncthreads();
-    if (W > A.W_cap) { if (bx == 0 && tid == 0) { set_err(m, DERR_CAPACITY, -1); m->W = 0; } return; }
+    if (W > A.W_cap) { if (bx == 0 && tid == 0) { set_err(m, DERR_CAPACITY, -1); META_PUT(&m->W, 0); } return; }
     if (bx == 0) { /* TailIndex.push_back(WayPointsList.size() - 1), the offsets, W: for the host and for the in-order finish */
         for (int k2 = tid; k2 < nk; k2 += blockDim.x) {
             A.wp_off[k2] = s_off[k2]; A.tail[k2] = s_off[k2 + 1] - 1;
             const int s2 = k2 + A.first_kept;
             if (s2 < A.sb || s2 >= A.se) A.wp_cnt[k2] = 0; /* another handle's slice */
         }
-        if (tid == 0) { A.wp_off[nk] = W; m->W = W; m->any_short = s_short; m->sweeps = 0; m->smooth_done = 0; }
+        if (tid == 0) { A.wp_off[nk] = W; META_PUT(&m->W, W); META_PUT(&m->any_short, s_short); META_PUT(&m->sweeps, 0); META_PUT(&m->smooth_done, 0); }
     }
     const int ntiles = smooth_tiles(W);
     const int tile = bx;
@@ -1045,6 +1052,27 @@ __global__ void __launch_bounds__(256) k_win_gather_stage(WinArgs A, float4 *wp_
 /* side, so that the LDS capacities of the slice workgroups are the cloud's own maxima instead of a density guess (a jittered */
 /* grid puts 5 or 6 columns of points into an 8 mm window: +-12 % around the mean).                                            */
 /* ------------------------------------------------------------------ */
+
+/* census of one point (both census kernels): its window and, inside the band, its side */
+__device__ __forceinline__ void win_census_point(float x, const float *__restrict__ px, int S, float px0, float inv_step, float pad,
+                                                 int *cw, int *ce, int *cr)
+{
+    if (!(x == x)) return;
+    const float fj = fminf(fmaxf(floorf((x - px0) * inv_step + 0.5f), 0.f), (float)(S - 1));
+    const int j = (int)fj;
+    const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
+    int w = -1;
+    if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
+    if (w < 0) return;
+    atomicAdd(&cw[w], 1);
+    const float Px = px[w];
+    const int position = (int)Px;
+    if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
+        const float d = (x - Px) * 1.f;
+        if (d > 0) atomicAdd(&ce[w], 1); else if (d < 0) atomicAdd(&cr[w], 1);
+    }
+}
+#define WIN_CENSUS_UNROLL 8 /* x values a thread requests before it looks at the first (one read per dependent loop trip was the census: 22 us for 4 MB) */
 template <bool IN_LDS>
 __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X, int n, const float *__restrict__ px, int S, float px0,
                                                     float inv_step, float pad, int *cnt_win, int *cnt_el, int *cnt_er)
@@ -1057,22 +1085,13 @@ __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X,
         __syncthreads();
     }
     int *cw = IN_LDS ? s_c : cnt_win, *ce = IN_LDS ? s_c + S : cnt_el, *cr = IN_LDS ? s_c + 2 * S : cnt_er;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float x = X[i];
-        if (!(x == x)) continue;
-        const float fj = fminf(fmaxf(floorf((x - px0) * inv_step + 0.5f), 0.f), (float)(S - 1));
-        const int j = (int)fj;
-        const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
-        int w = -1;
-        if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
-        if (w < 0) continue;
-        atomicAdd(&cw[w], 1);
-        const float Px = px[w];
-        const int position = (int)Px;
-        if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
-            const float d = (x - Px) * 1.f;
-            if (d > 0) atomicAdd(&ce[w], 1); else if (d < 0) atomicAdd(&cr[w], 1);
-        }
+    const int step = (int)(gridDim.x * blockDim.x);
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += WIN_CENSUS_UNROLL * step) {
+        float xv[WIN_CENSUS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < WIN_CENSUS_UNROLL; ++u) { const int i = i0 + u * step; xv[u] = i < n ? X[i] : __int_as_float(0x7fc00000); }
+#pragma unroll
+        for (int u = 0; u < WIN_CENSUS_UNROLL; ++u) win_census_point(xv[u], px, S, px0, inv_step, pad, cw, ce, cr);
     }
     if (IN_LDS) {
         __syncthreads();
@@ -1102,22 +1121,13 @@ __global__ void __launch_bounds__(256) k_win_census_auto(const float *__restrict
         __syncthreads();
         const float px0 = px[0];
         int *cw = s_c, *ce = s_c + S, *cr = s_c + 2 * S;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            const float x = X[i];
-            if (!(x == x)) continue;
-            const float fj = fminf(fmaxf(floorf((x - px0) * inv_step + 0.5f), 0.f), (float)(S - 1));
-            const int j = (int)fj;
-            const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
-            int w = -1;
-            if (fabsf(x - px[j]) <= pad) w = j; else if (fabsf(x - px[ja]) <= pad) w = ja; else if (fabsf(x - px[jb]) <= pad) w = jb;
-            if (w < 0) continue;
-            atomicAdd(&cw[w], 1);
-            const float Px = px[w];
-            const int position = (int)Px;
-            if (!(x < (float)(-2 + position) || x > (float)(2 + position))) {
-                const float d = (x - Px) * 1.f;
-                if (d > 0) atomicAdd(&ce[w], 1); else if (d < 0) atomicAdd(&cr[w], 1);
-            }
+        const int step = (int)(gridDim.x * blockDim.x);
+        for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += WIN_CENSUS_UNROLL * step) {
+            float xv[WIN_CENSUS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < WIN_CENSUS_UNROLL; ++u) { const int i = i0 + u * step; xv[u] = i < n ? X[i] : __int_as_float(0x7fc00000); }
+#pragma unroll
+            for (int u = 0; u < WIN_CENSUS_UNROLL; ++u) win_census_point(xv[u], px, S, px0, inv_step, pad, cw, ce, cr);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < 3 * S; i += blockDim.x)
@@ -1167,12 +1177,42 @@ __global__ void __launch_bounds__(TMAX) k_win_slice_b(const WinArgs *__restrict_
     if ((int)blockIdx.x == A.g_slice) { win_verify_body(A); return; }
     win_slice_body<TMAX>(A, blockIdx.x);
 }
-__global__ void __launch_bounds__(SMF_T) k_win_finish(WinArgs A) { win_finish_body(A, blockIdx.x); }
+/* The meta block of a pass for the host, without a copy command behind the pass (each costs the host 10-20 us on this runtime
+   and the device a 4 us blit kernel): the last of the finish launch's workgroups to get here writes it to pinned host memory.
+   Every workgroup of the member arrives, whatever its own part of the finish was. */
+__device__ __forceinline__ void win_publish_meta(const WinArgs &A)
+{
+    if (!A.meta_host) return;
+    __shared__ int s_lastw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0); /* vmcnt(0): what this workgroup put into the meta block (META_PUT, atomics) has been acknowledged */
+        /* two levels of arrival counters: the workgroups of a launch finish together, and a thousand atomics on ONE address queue
+           for ~10 ns each (10 M points: the launch 23 -> 30 us with a single counter) */
+        const int grp = (int)blockIdx.x % WIN_FIN_GROUPS;
+        const int members = (A.g_finish - grp + WIN_FIN_GROUPS - 1) / WIN_FIN_GROUPS;
+        int last = 0;
+        if (__hip_atomic_fetch_add(A.fin_ticket + 1 + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(A.fin_ticket + 1 + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int groups = A.g_finish < WIN_FIN_GROUPS ? A.g_finish : WIN_FIN_GROUPS;
+            last = __hip_atomic_fetch_add(A.fin_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+        }
+        s_lastw = last;
+    }
+    __syncthreads();
+    if (!s_lastw) return;
+    const int *src = (const int *)A.m;
+    int *dst = (int *)A.meta_host;
+    for (int q = threadIdx.x; q < (int)(sizeof(DevMeta) / sizeof(int)); q += blockDim.x) dst[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(A.fin_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(SMF_T) k_win_finish(WinArgs A) { win_finish_body(A, blockIdx.x); win_publish_meta(A); }
 __global__ void __launch_bounds__(SMF_T) k_win_finish_b(const WinArgs *__restrict__ mem)
 {
     const WinArgs &A = mem[blockIdx.y];
     if ((int)blockIdx.x >= A.g_finish) return;
     win_finish_body(A, blockIdx.x);
+    win_publish_meta(A);
 }
 /* the members' meta blocks side by side, so that ONE copy publishes the batch to the host */
 __global__ void __launch_bounds__(64) k_collect_meta_win(const WinArgs *__restrict__ mem, int count, DevMeta *out)
