@@ -490,7 +490,7 @@ int plan_window(ppp_handle h, int S, double per)
     h->win_path = false;
     const int step = (int)(h->P.tool_radius * 2);
     if (!h->win_allowed || h->win_disabled || getenv("PPP_NO_WINDOW_PATH")) return PPP_OK;
-    if (h->P.pairing != PPP_PAIR_KD || h->P.dynamic_adjustment || h->aligned || h->big_path) return PPP_OK;
+    if (h->P.dynamic_adjustment || h->aligned || h->big_path) return PPP_OK; /* (both pairings: kd and v1's brute-force greedy) */
     if (h->h_nvalid <= 0 || S < 1 || S > WIN_S_MAX || step < 1) return PPP_OK;
     const double rx = (double)h->h_mx[0] - h->h_mn[0], ry = (double)h->h_mx[1] - h->h_mn[1];
     const double area = rx * ry;
@@ -535,7 +535,10 @@ int plan_window(ppp_handle h, int S, double per)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     int max_w = 0, max_el = 0;
-    for (int s2 = h->sb; s2 < h->se; ++s2) { max_w = std::max(max_w, census[s2]); max_el = std::max(max_el, census[(size_t)S + s2]); }
+    for (int s2 = h->sb; s2 < h->se; ++s2) {
+        max_w = std::max(max_w, census[s2]); max_el = std::max(max_el, census[(size_t)S + s2]);
+        if (h->P.pairing == PPP_PAIR_BRUTE) max_el = std::max(max_el, census[2 * (size_t)S + s2]); /* its per-side tables hold either side */
+    }
     const double expect = std::max(1, max_w);
     int NBc = 16; /* y-buckets per class: about two per point of a class where the LDS allows (most buckets then hold one point or none) */
     while (NBc < expect / 5.0 && NBc < 4096) NBc <<= 1;
@@ -1090,7 +1093,7 @@ int ingest_grid(size_t n) { return std::max(1, std::min(((int)n / 8 + MM_T - 1) 
 /* may the window path apply to the next plan, as far as the parameters say (plan_window decides with the bounds in hand)? */
 bool window_params_ok(const ppp_handle h)
 {
-    return h->win_allowed && !h->win_disabled && !getenv("PPP_NO_WINDOW_PATH") && h->P.pairing == PPP_PAIR_KD && !h->P.dynamic_adjustment &&
+    return h->win_allowed && !h->win_disabled && !getenv("PPP_NO_WINDOW_PATH") && !h->P.dynamic_adjustment &&
            !h->aligned && !h->big_path && (int)(h->P.tool_radius * 2) >= 1;
 }
 
@@ -1171,6 +1174,14 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
     h->have_cloud = true;
     h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
     h->normals_valid = false;
+#ifdef PPP_TUNING
+    if (getenv("PPP_COLD_DEBUG")) {
+        const auto t_a = std::chrono::steady_clock::now();
+        const int rcp = make_plan(h);
+        fprintf(stderr, "[ppp cold] make_plan: %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_a).count());
+        return rcp;
+    }
+#endif
     return make_plan(h);
 }
 

@@ -282,6 +282,28 @@ __device__ inline int win_nn_class(const WinView &V, int c, const float4 q)
     return bj;
 }
 
+/* insert_point's brute-force argmin (Path_Generation.cpp:141-150 / :163-170) of q inside ONE class: the key is Vector3f::norm()
+   -- sqrt in float, Eigen's x*x + (y*y + z*z) -- and `compare[norm] = j` lets the LAST j of equal keys win: the highest cloud
+   index (the sides are walked in ascending cloud index).  Windowed on the class's y order: norm >= |dy| holds in float arithmetic
+   (every partial sum is >= y*y rounded, sqrt is monotone and sqrtf(fl(y*y)) >= |y|), so a candidate beyond |dy| > best cannot tie. */
+__device__ inline int win_nn_class_brute(const WinView &V, int c, const float4 q)
+{
+    float best = INFINITY;
+    int bidx = -1, bj = V.cs[c];
+    auto visit = [&](const float4 &k, int i) {
+        const float dy = q.y - k.y;
+        if (fabsf(dy) > best) return false;
+        const float d = norm_eigen3(q.x - k.x, dy, q.z - k.z);
+        const int id = idx_of(k);
+        if (d < best || (d == best && id > bidx)) { best = d; bidx = id; bj = i; }
+        return true;
+    };
+    const int p = V.lower_bound(c, q.y);
+    win_walk(V, c, p, true, visit);
+    win_walk(V, c, p, false, visit);
+    return bj;
+}
+
 /* Units of a waypoint's two searches: (class, direction) -- the two band sides (up, down), the two outer classes (up, down),
    the points on the plane.  A waypoint has G = 4 lanes (a launch whose workgroups have a CU to themselves: the band sides first,
    the outer classes second -- the nearest-neighbour search has closed those by their x gap by then, almost always) or G = 2 (one
@@ -429,32 +451,127 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     const int nEr = s_cs[2] - s_cs[1], nEl = s_cs[4] - el0;
     if (tid == 0) A.band_cnt[s] = s_cs[4] - s_cs[1]; /* |rangedX_index| */
     if (nEl == 0 || nEr == 0) { slice_fails(DERR_SLICE); return; }  /* empty map -> < 3 knots; empty FLANN tree */
-    if (nEl > cap_el) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
-    /* ---- insert_point, kd flavour (path_slicing_alg.cpp:184-233): for every left point the nearest right point, for
-       that one the nearest left point, the pair interpolated onto the plane ---- */
+    const bool brute = P.pairing != 0; /* ppp_params.pairing: 0 = PPP_PAIR_KD, 1 = PPP_PAIR_BRUTE (include/ppp_hip.h) */
+    if (nEl > cap_el || (brute && nEr > cap_el)) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
     constexpr int CE = 4; /* candidates per thread at most (cap_el <= CE * blockDim is checked by the plan) */
     u64 kr[CE];
     int kb[CE];
-    int NBcand = next_pow2(max(nEl, 64)); /* about a candidate per bucket, as many as the histogram's cap_el + 1 slots allow */
-    while (NBcand > cap_el) NBcand >>= 1;
-    const float yr_scale = A.yscale * (float)NBcand / (float)NBc; /* NBcand buckets over the same y range */
+    int ncand = nEl;      /* candidates of the std::map: one per left point (kd), one per pair of left_pair (brute) */
+    int NBcand = 64;
+    float yr_scale = 0.f;
+    auto cand_buckets = [&]() { /* about a candidate per bucket, as many as the histogram's cap_el + 1 slots allow; over the windows' y range */
+        NBcand = next_pow2(max(ncand, 64));
+        while (NBcand > cap_el) NBcand >>= 1;
+        yr_scale = A.yscale * (float)NBcand / (float)NBc;
+    };
+    auto make_cand = [&](int e, int ci, const float4 &R, const float4 &Lp) { /* the pair interpolated onto the plane (:220-232 / Path_Generation.cpp:189-201) */
+        const float t = (Px - R.x) / (Lp.x - R.x);
+        float y = R.y + t * (Lp.y - R.y);
+        const float z = R.z + t * (Lp.z - R.z);
+        if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
+        kr[e] = YK_MAKE(y, ci);
+        int q2 = (int)((y - A.y0) * yr_scale);
+        kb[e] = q2 < 0 ? 0 : (q2 >= NBcand ? NBcand - 1 : q2);
+        return z;
+    };
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        const int i = tid + e * T;
-        kb[e] = -1; kr[e] = 0;
-        if (i < nEl) {
-            const float4 q = pts[el0 + i];
-            const float4 R = pts[win_nn_class(V, 1, q)];
-            const float4 Lp = pts[win_nn_class(V, 3, R)];
-            const float t = (Px - R.x) / (Lp.x - R.x);
-            float y = R.y + t * (Lp.y - R.y);
-            const float z = R.z + t * (Lp.z - R.z);
-            if (y == 0.f) y = 0.f; /* -0.0 and +0.0 are one std::map key */
-            cz[i] = z;
-            kr[e] = YK_MAKE(y, i);
-            int q2 = (int)((y - A.y0) * yr_scale);
-            kb[e] = q2 < 0 ? 0 : (q2 >= NBcand ? NBcand - 1 : q2);
+    for (int e = 0; e < CE; ++e) { kb[e] = -1; kr[e] = 0; }
+    if (!brute) {
+        /* ---- insert_point, kd flavour (path_slicing_alg.cpp:184-233): for every left point the nearest right point, for
+           that one the nearest left point, the pair interpolated onto the plane ---- */
+        cand_buckets();
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int i = tid + e * T;
+            if (i < nEl) {
+                const float4 q = pts[el0 + i];
+                const float4 R = pts[win_nn_class(V, 1, q)];
+                const float4 Lp = pts[win_nn_class(V, 3, R)];
+                cz[i] = make_cand(e, i, R, Lp);
+            }
         }
+    } else {
+        /* ---- insert_point, brute flavour (Path_Generation.cpp:129-201).  The two argmins do not depend on the used-flags: every
+           left point's nearest right point and every right point's nearest left point are searched in parallel, on the staged
+           window's y order (Vector3f::norm keys, the last index of equal keys).  The greedy walk over the left points in ascending
+           cloud index with its two flag arrays stays one thread's loop, but over records made beforehand -- (i, j*(i), k*(j*)) in
+           walk order -- so that an iteration is three flag reads, not a chain of look-ups.  Pairs are (right_pair[p], left_pair[p])
+           for p < |left_pair|, the reference's misaligned indexing (App. B.3) included. ---- */
+        const int er0 = s_cs[1];
+        int jr[CE], kq[CE], ord[CE];
+        int mymax = 0;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int i = tid + e * T;
+            jr[e] = kq[e] = ord[e] = 0;
+            if (i < nEl) { const float4 q = pts[el0 + i]; jr[e] = win_nn_class_brute(V, 1, q) - er0; mymax = max(mymax, idx_of(q)); }
+            if (i < nEr) kq[e] = win_nn_class_brute(V, 3, pts[er0 + i]) - el0;
+        }
+        for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, __shfl_xor(mymax, o, 64));
+        if ((tid & 63) == 0) s_scr[tid >> 6] = mymax;
+        __syncthreads();
+        int maxidx = 0;
+        for (int w = 0; w < (T + 63) / 64; ++w) maxidx = max(maxidx, s_scr[w]);
+        __syncthreads();
+        {   /* the left points in ascending cloud index (the order El inherits from `indices`): bucket sort on the index */
+            int NBs = next_pow2(max(nEl, 64));
+            while (NBs > cap_el) NBs >>= 1;
+            const u64 span = (u64)(u32)maxidx + 1ull;
+            auto gen = [&](int i) { return ((u64)(u32)idx_of(pts[el0 + i]) << 32) | (u64)(u32)i; };
+            auto bucket = [&](u64 k) { return (int)(((k >> 32) * (u64)NBs) / span); };
+            auto less = [&](u64 a, u64 b) { return a < b; };
+            block_bucket_sort_cached<CE>(ckeys, nEl, hc, NBs, s_scr, gen, bucket, less);
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { const int t = tid + e * T; if (t < nEl) ord[e] = (int)(u32)(ckeys[t] & 0xffffffffull); }
+        __syncthreads();
+        u16 *jstar = (u16 *)cz, *kstar = jstar + cap_el; /* (cz: 4 bytes per left point) */
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int i = tid + e * T;
+            if (i < nEl) jstar[i] = (u16)jr[e];
+            if (i < nEr) kstar[i] = (u16)kq[e];
+        }
+        __syncthreads();
+        u64 *trip = ckeys; /* walk step t: i | j*(i) << 16 | k*(j*) << 32 */
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int t = tid + e * T;
+            if (t < nEl) { const int i = ord[e], j = jstar[i], k2 = kstar[j]; trip[t] = (u64)(u32)i | ((u64)(u32)j << 16) | ((u64)(u32)k2 << 32); }
+        }
+        __syncthreads();
+        unsigned char *lf = (unsigned char *)cz, *rf = lf + 2 * cap_el; /* El_flag / Er_flag (the look-up tables are used up) */
+        for (int w = tid; w < cap_el; w += T) ((u32 *)cz)[w] = 0u;
+        u16 *rpair = (u16 *)hc, *lpair = rpair + cap_el;
+        __syncthreads();
+        if (tid == 0) {
+            int nl = 0, nr = 0;
+            u64 nx = trip[0];
+            for (int t = 0; t < nEl; ++t) {
+                const u64 tr = nx;
+                if (t + 1 < nEl) nx = trip[t + 1]; /* (the next step's record travels while this one decides) */
+                const int i = (int)(tr & 0xffffu), j = (int)((tr >> 16) & 0xffffu), k2 = (int)((tr >> 32) & 0xffffu);
+                const int fi = lf[i], fj = rf[j], fk = lf[k2];
+                if (fi) continue;                   /* if (El_flag[i] == 0) */
+                if (fj) continue;                   /* Er_flag[compare.begin()->second] != 0: continue */
+                rpair[nr++] = (u16)j; rf[j] = 1;    /* right_pair.push_back */
+                if (!fk) { lpair[nl++] = (u16)k2; lf[k2] = 1; } /* left_pair.push_back only when that left point is unused */
+            }
+            s_m = nl; /* the reference loops i < left_pair.size() (Path_Generation.cpp:189) */
+        }
+        __syncthreads();
+        ncand = s_m;
+        cand_buckets();
+        float zr[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int pq = tid + e * T;
+            zr[e] = 0.f;
+            if (pq < ncand) zr[e] = make_cand(e, pq, pts[er0 + rpair[pq]], pts[el0 + lpair[pq]]);
+        }
+        __syncthreads(); /* the pairs are in registers: their scratch becomes the candidates' */
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { const int pq = tid + e * T; if (pq < ncand) cz[pq] = zr[e]; }
     }
     /* ---- std::map by y: bucket sort of the candidates (keys made once, kept in registers) ---- */
     for (int b = tid; b <= NBcand; b += T) hc[b] = 0;
@@ -497,24 +614,26 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     __syncthreads();
     STAMP(6, 4); /* candidate sort */
     WIN_STOP(4, (int)ckeys[tid % 64]);
-    /* one knot per distinct y: Node[y] = ... is overwritten by every later writer and El is walked in ascending cloud index,
-       so the z kept is the one of the candidate with the highest cloud index inside the run of equal keys.  The knots take
+    /* one knot per distinct y: Node[y] = ... is overwritten by every later writer, so the z kept is the last writer's inside the run
+       of equal keys.  The knots take
        the place of the sorted keys: everything a chunk needs of them is read before the scan's barriers, written after. */
-    for (int base = 0; base < nEl; base += T) {
+    for (int base = 0; base < ncand; base += T) {
         const int j = base + tid;
         const int o0 = s_m; /* slots below o0 hold knots of earlier chunks by now; a run of equal keys that reaches into this chunk
                                starts at or above o0 (every finished run left one knot and has at least one member) */
         int keep = 0;
         float ky = 0.f, kz = 0.f;
-        if (j < nEl) {
+        if (j < ncand) {
             const u64 kj = ckeys[j];
-            keep = (j == nEl - 1) || (YK_Y(ckeys[j + 1]) != YK_Y(kj));
+            keep = (j == ncand - 1) || (YK_Y(ckeys[j + 1]) != YK_Y(kj));
             if (keep) {
+                /* the last writer of a key: the left point with the highest cloud index (kd: candidate = left point, walked in ascending
+                   index), the highest pair number (brute: candidate = pair, written in that order) */
                 int best_i = YK_POS(kj);
-                int best_idx = idx_of(pts[el0 + best_i]);
+                int best_idx = brute ? best_i : idx_of(pts[el0 + best_i]);
                 for (int q = j - 1; q >= o0 && YK_Y(ckeys[q]) == YK_Y(kj); --q) {
                     const int ci = YK_POS(ckeys[q]);
-                    const int id = idx_of(pts[el0 + ci]);
+                    const int id = brute ? ci : idx_of(pts[el0 + ci]);
                     if (id > best_idx) { best_idx = id; best_i = ci; }
                 }
                 ky = ord2f(YK_Y(kj)); kz = cz[best_i];

@@ -1621,10 +1621,13 @@ def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):
 
 @pytest.mark.parametrize("name,walk,kw", [("small_40k", 1, {}), ("small_40k", 0, {}), ("small_40k", 2, {}), ("small_40k", 3, {}), ("small_40k", 4, {}),
                                           ("cfg3_250k_s128", 1, {}), ("small_40k", 1, dict(trim=5.0, drop_ends=0, smooth=0)),
-                                          ("small_40k", 1, dict(path_resolution=3.0, rpy_resolution=0.0)), ("small_40k", 1, dict(change_range=0))])
+                                          ("small_40k", 1, dict(path_resolution=3.0, rpy_resolution=0.0)), ("small_40k", 1, dict(change_range=0)),
+                                          ("small_40k", 3, dict(pairing=1)), ("small_40k", 4, dict(pairing=1)), ("cfg1_50k_s32", 3, dict(pairing=1)),
+                                          ("cfg3_250k_s128", 3, dict(pairing=1))])
 def test_window_path_and_slab_path_agree(engine_mod, name, walk, kw):
     """The two launch sequences (ppp_set_fast_path) plan the same cloud: the same slices, knots, sampled waypoints and nearest
-    cloud points bit for bit, the finished list within the float floor of the normals' summation order."""
+    cloud points bit for bit, the finished list within the float floor of the normals' summation order -- with the kd pairing
+    and with v1's brute-force greedy pairing (pairing=1: Path_Generation.cpp:107-206, walks 3 and 4)."""
     pts, cfg = synth.make_config(name)
     if kw.get("change_range") == 0:
         pts = pts * np.float32(1000.0)
@@ -1714,11 +1717,13 @@ def test_census_that_comes_with_a_new_cloud_equals_the_one_taken_at_plan_time(tm
 
 def test_window_path_applies_only_where_the_windows_do_not_overlap(engine_mod, oracle_mod):
     """Tool steps below about 2 x pad + 2 mm (here radius 4 -> step 8) make the slices' windows overlap: the plan stays on the
-    slab index, with the same parity; so do brute pairing and the dynamic adjustment."""
+    slab index, with the same parity; so does the dynamic adjustment.  (Brute pairing runs on the window path since round 4.)"""
     pts, cfg = synth.make_config("small_40k")
-    for kw in (dict(tool_radius=4.0), dict(tool_radius=6.0, pairing=1, walk=3), dict(tool_radius=6.0, dynamic_adjustment=1)):
+    for kw in (dict(tool_radius=4.0), dict(tool_radius=6.0, dynamic_adjustment=1), dict(tool_radius=6.0, pairing=1, walk=3, dynamic_adjustment=1)):
         e = engine_mod.Engine(0, **kw); e.set_cloud(pts)
         assert not e.fast_path()
+    e = engine_mod.Engine(0, tool_radius=6.0, pairing=1, walk=3); e.set_cloud(pts)
+    assert e.fast_path()
     e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=4.0)
     assert_full_parity(engine_mod, e, o, every_slice=False)
     assert engine_mod.Engine(0, tool_radius=5.0).fast_path() is False     # no cloud yet: nothing planned
