@@ -25,6 +25,10 @@
 #ifndef PPP_PPT8_FROM
 #define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
 #endif
+#ifndef PPP_WIN_PPT8_FROM
+#define PPP_WIN_PPT8_FROM 1200000 /* the window path's binning launch: what it costs is its workgroups' reservations (one global atomic per workgroup and
+                                     non-empty window) -- 1 M points / 256 windows: 122 workgroups of 8 points per thread 20.1 us, 244 of 4 18.8 us, 488 22.7-23.8, 977 33 us */
+#endif
 #ifndef PPP_PPT16_FROM
 #define PPP_PPT16_FROM 1500000 /* ... and 16: a workgroup's run in a slab grows to ~7 points = most of a 128-byte line (2 M points: scatter 36.4 -> 32.4 us) */
 #endif
@@ -559,8 +563,8 @@ int plan_window(ppp_handle h, int S, double per)
     h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc;
     int T = win_pick_threads(h, std::max(1, h->se - h->sb));
     if (!T) return PPP_OK;
-    /* points per thread of the binning launch: 8 from half a million points on (16 was slower at 10 M points: 107 against 100 us) */
-    h->win_ppt = n_src > PPP_PPT8_FROM ? 8 : 4;
+    /* points per thread of the binning launch: 8 from 1.2 million points on (16 was slower at 10 M points: 107 against 100 us) */
+    h->win_ppt = n_src > PPP_WIN_PPT8_FROM ? 8 : 4;
     /* large clouds leave the binning launch through LDS in window order (write amplification 2.1 -> ~1.3 at 10 M points), with
        as many points per thread as the stage has room for */
     {
@@ -573,14 +577,15 @@ int plan_window(ppp_handle h, int S, double per)
         if (win_scatter_lds_bytes(S, 8, WSC_T, true) + 2048 > (size_t)h->max_lds) h->win_ppt = 4;
         if (win_scatter_lds_bytes(S, h->win_ppt, WSC_T, true) + 2048 > (size_t)h->max_lds) { h->win_staged = false; h->win_ppt = 8; }
     }
-    if (const char *ev = tuning_env("PPP_WIN_PPT")) { const int pv = atoi(ev); if ((pv == 4 || pv == 8) && !h->win_staged) h->win_ppt = pv; } /* tuning runs only */
+    if (const char *ev = tuning_env("PPP_WIN_PPT")) { const int pv = atoi(ev); if ((pv == 2 || pv == 4 || pv == 8) && !h->win_staged) h->win_ppt = pv; } /* tuning runs only */
     h->win_gs = std::max(1, (n_src + h->win_ppt * WSC_T - 1) / (h->win_ppt * WSC_T));
+    if (h->win_staged) h->win_gs = std::min(h->win_gs, std::max(1, h->num_cus)); /* the staged form loops over its chunks: a workgroup per CU (its LDS admits no second) */
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
     h->win_first_kept = h->P.drop_ends ? 1 : 0;
     h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
     h->win_px0 = px[0];
-    HIPCHK(h, h->win_part.ensure((size_t)std::max(h->win_gs, (n_src + 4 * WSC_T - 1) / (4 * WSC_T)))); /* (a batch may bin with 4 points per thread) */
+    HIPCHK(h, h->win_part.ensure((size_t)std::max(h->win_gs, (n_src + 2 * WSC_T - 1) / (2 * WSC_T)))); /* (a batch may bin with fewer points per thread) */
     HIPCHK(h, h->win_pts.ensure((size_t)S * (size_t)capw));
     {   /* the knot arrays hold a cap_el segment per slice on this path */
         const double need = (double)S * (double)cap_el;
@@ -649,6 +654,7 @@ int enqueue_window_gen(ppp_handle h)
     if (h->win_staged && h->win_ppt == 8) LAUNCH(h, "k_win_scatter", (k_win_scatter<8, true>), A.g_scatter, WSC_T, scat_lds, A);
     else if (h->win_staged) LAUNCH(h, "k_win_scatter", (k_win_scatter<4, true>), A.g_scatter, WSC_T, scat_lds, A);
     else if (h->win_ppt == 8) LAUNCH(h, "k_win_scatter", (k_win_scatter<8, false>), A.g_scatter, WSC_T, scat_lds, A);
+    else if (h->win_ppt == 2) LAUNCH(h, "k_win_scatter", (k_win_scatter<2, false>), A.g_scatter, WSC_T, scat_lds, A);
     else LAUNCH(h, "k_win_scatter", (k_win_scatter<4, false>), A.g_scatter, WSC_T, scat_lds, A);
     const int T = h->win_threads;
     const size_t lds = win_slice_lds_for(h, A.NBc);
@@ -2068,6 +2074,7 @@ int upload_members_win(ppp_handle lead, BatchGraph *bg, float *dst_dev, const si
         A.meta_host = count > 1 ? bg->hmetas->pinned + i : nullptr;
         h->out2 = nullptr; h->out2_cap = 0;
         A.g_scatter = std::max(1, (A.n + bg->win_ppt * WSC_T - 1) / (bg->win_ppt * WSC_T)); /* (the members' partials are sized for 4 points per thread) */
+        if (bg->win_staged) A.g_scatter = std::min(A.g_scatter, std::max(1, lead->num_cus)); /* (the staged form loops over its chunks) */
         slices_total += A.g_slice;
         /* (NB / NBc / yscale of the launch kind are set below, once the launch's total of slices is known) */
         bg->win_scat_lds = std::max(bg->win_scat_lds, win_scatter_lds_bytes(A.S, bg->win_ppt, WSC_T, bg->win_staged));

@@ -211,6 +211,126 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
     STAMP(7, 4); /* bounds partial */
 }
 
+/* A workgroup barrier for phases that meet through LDS only: waits for this wave's LDS operations, not for its loads from
+   memory (vmcnt counts loads and stores alike on this target, so __syncthreads() would sit out the prefetch below). */
+__device__ __forceinline__ void win_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/* The staged binning of a large cloud as a LOOP: a workgroup takes chunks bx, bx + nwg, ... of PPT x blockDim points.  Its LDS
+   stage admits one workgroup per CU, whose phases -- points from memory, ranks, reservations, stage, stores -- used to follow one
+   another with the memory pipes idle in between; here the next chunk's points are requested as soon as the reservations of the
+   current one have come back and travel while it is staged and stored.  Same runs, same counters: the windows only see another
+   arrival order (the slice kernel orders a window by (y, index) itself). */
+template <int PPT>
+__device__ __forceinline__ void win_scatter_staged_loop(const WinArgs &A, const int bx, const int nwg)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    float *s_px = (float *)s_dyn;
+    int *s_cnt = s_dyn + A.S;
+    __shared__ int s_scr[17];
+    __shared__ float s_mn[3][WSC_T / 64], s_mx[3][WSC_T / 64];
+    __shared__ int s_n[WSC_T / 64];
+    const int S = A.S, n = A.n, T = (int)blockDim.x;
+    const int chunk_pts = PPT * T;
+    const int nchunks = (n + chunk_pts - 1) / chunk_pts;
+    int *s_loc = (int *)s_px;
+    int *s_gb = s_dyn + 2 * S;
+    float4 *stage = (float4 *)(s_dyn + ((3 * S + 3) & ~3));
+    u16 *widx = (u16 *)(stage + PPT * T);
+    if (bx == 0 && threadIdx.x == 0) { /* the run state of this pass: nothing else in this launch touches the meta block */
+        DevMeta *m = A.m;
+        m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
+        m->node_cursor = 0; m->smooth_done = -1; m->emit_ticket = 0; m->big_slabs = 0; m->big_slices = 0; m->arena_cursor = 0; m->win_flag = 0;
+    }
+    float4 p[PPT], pn[PPT];
+    auto request = [&](int chunk, float4 *dst) {
+        const int i0 = chunk * chunk_pts;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = i0 + (int)threadIdx.x + k * T;
+            if (i < n) dst[k] = make_float4(A.X[i], A.Y[i], A.Z[i], __int_as_float(A.idmap ? A.idmap[i] : i));
+            else dst[k] = make_float4(NAN, 0.f, 0.f, 0.f);
+        }
+    };
+    if (bx < nchunks) request(bx, p);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int chunk = bx; chunk < nchunks; chunk += nwg) {
+        for (int s = threadIdx.x; s < S; s += T) { s_px[s] = A.plan_px[s]; s_cnt[s] = 0; }
+        __syncthreads();
+        int pw[PPT], pr[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const float x = p[k].x;
+            pw[k] = -1; pr[k] = 0;
+            if (x == x) {
+                mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+                mn[1] = fminf(mn[1], p[k].y); mx[1] = fmaxf(mx[1], p[k].y);
+                mn[2] = fminf(mn[2], p[k].z); mx[2] = fmaxf(mx[2], p[k].z);
+                cnt++;
+                const float fj = fminf(fmaxf(floorf((x - A.px0) * A.inv_step + 0.5f), 0.f), (float)(S - 1));
+                const int j = (int)fj;
+                const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
+                const float da = fabsf(x - s_px[ja]), dj = fabsf(x - s_px[j]), db = fabsf(x - s_px[jb]);
+                int w = -1;
+                if (dj <= A.pad) w = j; else if (da <= A.pad) w = ja; else if (db <= A.pad) w = jb; /* windows are disjoint (plan) */
+                if (w >= A.sb && w < A.se) { pw[k] = w; pr[k] = atomicAdd(&s_cnt[w], 1); }
+            }
+        }
+        __syncthreads();
+        int K;
+        {
+            const int per = (S + T - 1) / T;
+            const int b0 = threadIdx.x * per;
+            int sum = 0;
+            for (int q = 0; q < per; ++q) if (b0 + q < S) sum += s_cnt[b0 + q];
+            int pre = block_exscan_w(sum, s_scr, &K);
+            for (int q = 0; q < per; ++q) {
+                if (b0 + q < S) {
+                    const int c = s_cnt[b0 + q];
+                    s_loc[b0 + q] = pre; pre += c;
+                    s_gb[b0 + q] = c ? atomicAdd(&A.win_cnt[(size_t)(b0 + q) * WIN_CNT_STRIDE], c) : 0;
+                }
+            }
+        }
+        __syncthreads(); /* (the reservations have come back: nothing below waits on memory) */
+        const int next = chunk + nwg;
+        if (next < nchunks) request(next, pn);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (pw[k] >= 0) {
+                const int q = s_loc[pw[k]] + pr[k];
+                stage[q] = p[k]; widx[q] = (u16)pw[k];
+            }
+        }
+        win_lds_barrier();
+        for (int q = threadIdx.x; q < K; q += T) {
+            const int w = widx[q];
+            const int pos = s_gb[w] + (q - s_loc[w]);
+            if (pos < A.capw) A.win_pts[(size_t)w * A.capw + pos] = stage[q];
+        }
+        win_lds_barrier(); /* the tables and the stage are free for the next chunk */
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) p[k] = pn[k];
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = 0; d < 3; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { for (int d = 0; d < 3; ++d) { s_mn[d][wid] = mn[d]; s_mx[d][wid] = mx[d]; } s_n[wid] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPart r;
+        r.cnt = 0; r.pad = 0;
+        const int nw = (int)(blockDim.x >> 6);
+        for (int w = 0; w < nw; ++w) r.cnt += s_n[w];
+        for (int d = 0; d < 3; ++d) {
+            float a = INFINITY, b = -INFINITY;
+            for (int w = 0; w < nw; ++w) { a = fminf(a, s_mn[d][w]); b = fmaxf(b, s_mx[d][w]); }
+            r.mn[d] = a; r.mx[d] = b;
+        }
+        A.win_part[bx] = r;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* launch 2: the per-slice kernel                                       */
 /* ------------------------------------------------------------------ */
@@ -1274,13 +1394,18 @@ __global__ void __launch_bounds__(256) k_win_census_auto(const float *__restrict
 
 /* ---- launch forms: single (arguments by value) and batched (blockIdx.y = member of the batch) ---- */
 template <int PPT, bool STAGED>
-__global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A) { win_scatter_body<PPT, STAGED>(A, blockIdx.x); }
+__global__ void __launch_bounds__(WSC_T) k_win_scatter(WinArgs A)
+{
+    if (STAGED) win_scatter_staged_loop<PPT>(A, blockIdx.x, A.g_scatter); /* g_scatter workgroups share the chunks of the cloud */
+    else win_scatter_body<PPT, false>(A, blockIdx.x);
+}
 template <int PPT, bool STAGED>
 __global__ void __launch_bounds__(WSC_T) k_win_scatter_b(const WinArgs *__restrict__ mem)
 {
     const WinArgs &A = mem[blockIdx.y];
     if ((int)blockIdx.x >= A.g_scatter) return;
-    win_scatter_body<PPT, STAGED>(A, blockIdx.x);
+    if (STAGED) win_scatter_staged_loop<PPT>(A, blockIdx.x, A.g_scatter);
+    else win_scatter_body<PPT, false>(A, blockIdx.x);
 }
 template <int TMAX>
 __global__ void __launch_bounds__(TMAX) k_win_slice(WinArgs A)
