@@ -307,6 +307,13 @@ int ppp_read_config(const char *path, ppp_config *c);
 int ppp_write_path_file(const char *path, const float *wp6, size_t W);
 
 /* ---- which launch sequence plans a cloud ---- */
+/* Plan reuse (default on).  The first cloud of a handle sizes the window path's LDS capacities from a census of its own windows
+ * (one more launch behind the conversion pass of ppp_set_cloud*).  A later cloud with the same point count and parameters, whose
+ * slice walk has the same length and pad, inherits those capacities (+4 %) and skips that launch -- a planner that is fed one scan
+ * after the other (the constructors of the reference's planner classes: src/Path_Alg/path_slicing_alg.cpp:3-30) saves it on every
+ * workpiece.  The pass checks every window against its capacity on the device; one that does not fit makes the engine plan this
+ * cloud again from its own census and repeat the pass (same results, one wasted pass).  0 turns the reuse off. */
+int ppp_set_plan_reuse(ppp_handle h, int on);
 /* The engine has two launch sequences for the same hot path, with the same results up to the last bits of the normals'
  * float sums (both within the tolerances of tests/): the WINDOW path (three launches: every point binned once into the
  * window of its slice, one fused per-slice kernel, the finish; kd pairing, no dynamic adjustment / alignment, tool steps

@@ -176,6 +176,17 @@ struct ppp_handle_s {
     DevBuf<int> plan_ticket;         /* [2], zero between launches */
     DevBuf<PlanAuto> plan_auto;
     bool auto_valid = false;         /* the pinned census belongs to the cloud just set, with auto_S slices and auto_pad */
+    /* Plan reuse: a planner that is fed one scan after the other plans clouds of one size with one set of parameters.  The first
+       plan takes its window capacities from a census of that cloud; a later cloud with the same point count, parameters, slice
+       count and pad inherits them (+4 %) and skips the census launch -- the pass itself detects a window that does not fit
+       (WIN_FLAG_OVERFLOW), and the plan is then made again from a census of its own */
+    bool plan_reuse = true;          /* ppp_set_plan_reuse */
+    bool inh_valid = false;          /* the members below describe a census-based window plan of this handle */
+    int inh_S = 0, inh_n = 0, inh_max_w = 0, inh_max_el = 0;
+    float inh_pad = 0.f;
+    ppp_params inh_P;
+    bool auto_px_only = false;       /* the cloud just set brought walk + pad along (auto_S, auto_pad, pinned plane table), but no census */
+    bool plan_inherited = false;     /* the current window plan's capacities are inherited */
     int auto_S = 0;
     float auto_pad = 0.f;
     bool slab_cnt_used = true;       /* a slab-path pass has been enqueued since the slab histogram was last cleared by the plan */
@@ -513,12 +524,26 @@ int plan_window(ppp_handle h, int S, double per)
     HIPCHK(h, h->win_px.ensure((size_t)S)); HIPCHK(h, h->win_cnt.ensure(std::max<size_t>(3, WIN_CNT_STRIDE) * (size_t)S));
     /* a cloud that has just been set brought its census along (refresh_bounds_and_plan): taken when the device's walk, slice count
        and pad are this plan's, bit for bit */
-    const bool from_auto = h->auto_valid && !h->use_part && h->auto_S == S && S <= WIN_AUTO_SCAP && h->pin &&
-                           memcmp(&h->auto_pad, &pad, sizeof(float)) == 0 && memcmp(h->pin + PIN_PX, px.data(), sizeof(float) * (size_t)S) == 0;
-    h->auto_valid = false;
+    const bool walk_ok = !h->use_part && h->auto_S == S && S <= WIN_AUTO_SCAP && h->pin &&
+                         memcmp(&h->auto_pad, &pad, sizeof(float)) == 0 && memcmp(h->pin + PIN_PX, px.data(), sizeof(float) * (size_t)S) == 0;
+    const bool from_auto = h->auto_valid && walk_ok;
+    /* ... or it brought the walk only, and the capacities of an earlier cloud's plan apply (refresh_bounds_and_plan) */
+    const bool inherit = !from_auto && h->auto_px_only && walk_ok && h->inh_valid && h->inh_S == S && memcmp(&h->inh_pad, &pad, sizeof(float)) == 0 &&
+                         h->sb == 0 && h->se == S;
+    h->auto_valid = false; h->auto_px_only = false;
+    h->plan_inherited = false;
     int *census = nullptr;
+    std::vector<int> inherited;
     if (from_auto) census = (int *)(h->pin + PIN_CENSUS);
-    else {
+    else if (inherit) { /* every window as full as the fullest of the earlier cloud, + 4 % */
+        inherited.assign(3 * (size_t)S, 0);
+        for (int s2 = 0; s2 < S; ++s2) {
+            inherited[s2] = h->inh_max_w + h->inh_max_w / 25 + 8;
+            inherited[(size_t)S + s2] = inherited[2 * (size_t)S + s2] = h->inh_max_el + h->inh_max_el / 25 + 8;
+        }
+        census = inherited.data();
+        h->plan_inherited = true;
+    } else {
     HIPCHK(h, h->ensure_pin(sizeof(float) * 4 * (size_t)S));
     float *px_pin = (float *)h->pin;
     census = (int *)(px_pin + S);
@@ -595,13 +620,16 @@ int plan_window(ppp_handle h, int S, double per)
     }
     const size_t slots = (size_t)std::max(1, h->win_nkept) * (size_t)h->win_stride;
     HIPCHK(h, h->wps_xyz.ensure(slots)); HIPCHK(h, h->wps_normal.ensure(slots)); HIPCHK(h, h->wps_nn.ensure(slots)); HIPCHK(h, h->wps_pre.ensure(6 * slots)); HIPCHK(h, h->wps_rec.ensure(4 * slots));
-    if (!from_auto) /* the windows' counters: every pass leaves them cleared again (in stream order ahead of the first pass: no wait); the census that came with the cloud has cleared its own */
+    if (!from_auto && !inherit) /* the windows' counters: every pass leaves them cleared again (in stream order ahead of the first pass: no wait); the census that came with the cloud has cleared its own */
         HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * (size_t)S * std::max<size_t>(3, WIN_CNT_STRIDE), h->stream));
     h->win_path = true;
+    if (!inherit && h->sb == 0 && h->se == S && !h->use_part) { /* what a later cloud of this size may inherit */
+        h->inh_valid = true; h->inh_S = S; h->inh_n = n_src; h->inh_max_w = max_w; h->inh_max_el = max_el; h->inh_pad = pad; h->inh_P = h->P;
+    }
     if (getenv("PPP_WIN_DEBUG"))
         fprintf(stderr, "[ppp] window plan: S %d [%d,%d) pad %.2f capw %d cap_el %d NBc %d (throughput %d) threads %d ppt %d lds %zu B max window %d max left side %d census %s\n",
                 S, h->sb, h->se, pad, capw, cap_el, NBc, h->win_NBc_thr, T, h->win_ppt, win_slice_lds_for(h, NBc), max_w, max_el,
-                from_auto ? "came with the cloud" : "at plan time");
+                from_auto ? "came with the cloud" : (inherit ? "inherited from an earlier cloud of this size" : "at plan time"));
     return PPP_OK;
 }
 
@@ -1031,7 +1059,14 @@ int map_dev_err(ppp_handle h)
 int rerun_with_arena(ppp_handle h)
 {
     const bool had_path = h->path_done;
-    if (h->win_path && h->hmeta.win_flag) {
+    if (h->win_path && h->hmeta.win_flag && getenv("PPP_WIN_DEBUG"))
+        fprintf(stderr, "[ppp] window pass handed back: flags %d (1 overflow, 2 reach, 4 stale plan)%s\n", h->hmeta.win_flag, h->plan_inherited ? ", capacities were inherited" : "");
+    if (h->win_path && h->hmeta.win_flag && h->plan_inherited && !(h->hmeta.win_flag & ~WIN_FLAG_OVERFLOW)) {
+        /* capacities inherited from an earlier cloud did not hold for this one: plan it from a census of its own, on the window path */
+        h->inh_valid = false;
+        int rcp = make_plan(h);
+        if (rcp) return rcp;
+    } else if (h->win_path && h->hmeta.win_flag) {
         /* the window path's capacities or reach did not hold for this cloud: the same cloud and parameters on the slab index
            from now on (a new cloud or new parameters try the window path again) */
         h->win_disabled = true;
@@ -1110,7 +1145,7 @@ bool window_params_ok(const ppp_handle h)
 int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stride_bytes = 0)
 {
     const size_t n = h->n;
-    h->auto_valid = false;
+    h->auto_valid = false; h->auto_px_only = false;
     h->win_disabled = false;
     h->big_path = false; /* (the plan turns the arena passes on again where this cloud needs them) */
     {
@@ -1124,6 +1159,8 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
                 HIPCHK(h, hipMemsetAsync(h->plan_ticket.p, 0, 2 * sizeof(int), h->stream));
             }
             const bool census = window_params_ok(h) && !h->part_given && (h->P.walk >= 0 && h->P.walk <= 4);
+            /* capacities of an earlier cloud of this size and these parameters: no census launch (plan_window decides with the walk in hand) */
+            const bool reuse = census && h->plan_reuse && h->inh_valid && h->inh_n == (int)n && memcmp(&h->inh_P, &h->P, sizeof(ppp_params)) == 0;
             if (census && (h->win_px.cap < WIN_AUTO_SCAP || h->win_cnt.cap < 3 * (size_t)WIN_AUTO_SCAP)) {
                 HIPCHK(h, h->win_px.ensure(WIN_AUTO_SCAP)); HIPCHK(h, h->win_cnt.ensure(3 * (size_t)WIN_AUTO_SCAP));
                 HIPCHK(h, hipMemsetAsync(h->win_cnt.p, 0, sizeof(int) * 3 * (size_t)WIN_AUTO_SCAP, h->stream)); /* every census and every pass leaves them cleared */
@@ -1132,12 +1169,13 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
             PA.ticket = h->plan_ticket.p; PA.dev = h->plan_auto.p; PA.host = (PlanAuto *)(h->pin + PIN_REC0);
             PA.walk = census ? h->P.walk : -1; PA.tool_radius = h->P.tool_radius; PA.normal_radius = h->P.normal_radius;
             PA.px = h->win_px.p; PA.px_cap = census ? WIN_AUTO_SCAP : 0;
+            PA.px_host = reuse ? (float *)(h->pin + PIN_PX) : nullptr;
             PlanAuto *rec0 = (PlanAuto *)(h->pin + PIN_REC0), *rec1 = (PlanAuto *)(h->pin + PIN_REC1);
             rec0->S = -2; rec1->census = 0; rec1->S = -2;
             hipLaunchKernelGGL(k_ingest_minmax, dim3(ingest_grid(n)), dim3(MM_T), 0, h->stream, raw, stride_bytes, (int)n, h->P.change_range, h->X.p, h->Y.p,
                                h->Z.p, h->mm_part.p, PA);
             HIPCHK(h, hipGetLastError());
-            if (census) {
+            if (census && !reuse) {
                 const int gc = std::max(1, std::min(((int)n + 4095) / 4096, 512));
                 hipLaunchKernelGGL(k_win_census_auto, dim3(gc), dim3(256), sizeof(int) * 3 * (size_t)WIN_AUTO_SCAP, h->stream, h->X.p, (int)n,
                                    h->win_px.p, h->plan_auto.p, 1.0f / (float)(int)(h->P.tool_radius * 2), h->win_cnt.p, h->plan_ticket.p + 1, rec1,
@@ -1157,7 +1195,8 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
             if (rec0->S == -2) return fail(h, PPP_ERR_HIP, "the bounds of the new cloud did not arrive");
             h->h_nvalid = rec0->fin.cnt;
             for (int d = 0; d < 3; ++d) { h->h_mn[d] = rec0->fin.mn[d]; h->h_mx[d] = rec0->fin.mx[d]; }
-            if (census && rec1->census == 1) { h->auto_valid = true; h->auto_S = rec1->S; h->auto_pad = rec1->pad; }
+            if (census && !reuse && rec1->census == 1) { h->auto_valid = true; h->auto_S = rec1->S; h->auto_pad = rec1->pad; }
+            if (reuse && rec0->S >= 1 && rec0->S <= WIN_AUTO_SCAP) { h->auto_px_only = true; h->auto_S = rec0->S; h->auto_pad = rec0->pad; }
         } else {
             hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
                                (int *)nullptr, 0.f, 0.f, (int *)nullptr);
@@ -2976,6 +3015,14 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps)
     int rc = ensure_ready(h, true, true);
     if (rc) return rc;
     *sweeps = h->hmeta.sweeps;
+    return PPP_OK;
+}
+
+int ppp_set_plan_reuse(ppp_handle h, int on)
+{
+    if (!h) return PPP_ERR_ARG;
+    h->plan_reuse = on != 0;
+    if (!h->plan_reuse) h->inh_valid = false;
     return PPP_OK;
 }
 

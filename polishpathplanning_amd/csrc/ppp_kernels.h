@@ -307,6 +307,7 @@ struct PlanAutoArgs {
     float normal_radius;
     float *px;            /* the plan's plane table (device) */
     int px_cap;
+    float *px_host;       /* pinned: a copy of that table for the host (nullptr: the census that follows hands it over) */
 };
 __global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__ raw, size_t stride, int n, int scale, float *__restrict__ X,
                                                        float *__restrict__ Y, float *__restrict__ Z, MinMaxPart *part, PlanAutoArgs PA)
@@ -426,8 +427,14 @@ __global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__
     __syncthreads();
     if (s_nfront >= 0) {
         const int istep = (int)(PA.tool_radius * 2);
-        for (int i = threadIdx.x; i < s_S && i < PA.px_cap; i += blockDim.x)
-            PA.px[i] = i < s_nfront ? (float)(s_cc - (s_nfront - i) * istep) : (i == s_nfront ? s_mid : (float)(s_cc + (i - s_nfront) * istep));
+        for (int i = threadIdx.x; i < s_S && i < PA.px_cap; i += blockDim.x) {
+            const float v = i < s_nfront ? (float)(s_cc - (s_nfront - i) * istep) : (i == s_nfront ? s_mid : (float)(s_cc + (i - s_nfront) * istep));
+            PA.px[i] = v;
+            if (PA.px_host) PA.px_host[i] = v;
+        }
+    } else if (PA.px_host && PA.walk >= 0) { /* (the sequential walks: one thread wrote the table above) */
+        const int Sw = PA.dev->S;
+        for (int i = threadIdx.x; i < Sw && i < PA.px_cap; i += blockDim.x) PA.px_host[i] = PA.px[i];
     }
 }
 

@@ -79,7 +79,7 @@ EXPORTS = [
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
-    "ppp_set_fast_path", "ppp_get_fast_path",
+    "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse",
 ]
 
 
@@ -172,6 +172,7 @@ def lib():
         L.ppp_spline_range.argtypes = [vp, dp, dp, szp]
         L.ppp_spline_destroy.argtypes = [vp]
         L.ppp_set_fast_path.argtypes = [vp, C.c_int]
+        L.ppp_set_plan_reuse.argtypes = [vp, C.c_int]
         L.ppp_get_fast_path.argtypes = [vp, ip]
         _lib = L
     return _lib
@@ -330,6 +331,11 @@ class Engine:
     def set_fast_path(self, on=True):
         """ppp_set_fast_path: False keeps this handle on the slab-index launch sequence (the window path is the default where it applies)."""
         self._chk(self.L.ppp_set_fast_path(self.h, 1 if on else 0))
+
+    def set_plan_reuse(self, on=True):
+        """ppp_set_plan_reuse: False makes every new cloud take its own window census (the default lets a cloud of the same size and
+        parameters inherit the capacities of the handle's earlier plan and skip that launch)."""
+        self._chk(self.L.ppp_set_plan_reuse(self.h, 1 if on else 0))
 
     def fast_path(self):
         """True when the current plan runs the window path (three launches), False for the slab-index path."""

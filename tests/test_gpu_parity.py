@@ -1680,6 +1680,49 @@ def test_window_path_hands_a_pass_back_when_a_search_leaves_its_window(engine_mo
     assert a.fast_path()                                   # ... a new cloud gets the window path again
 
 
+def test_plan_reuse_for_a_stream_of_clouds_of_one_size(engine_mod, oracle_mod):
+    """A handle that is fed one cloud after the other (same point count, same parameters) plans the first from a census of its
+    windows and lets the later ones inherit those capacities (ppp_set_plan_reuse, default on): their lists equal the lists of
+    fresh handles bit for bit; a later cloud whose windows do NOT fit the inherited capacities (the same number of points, piled
+    into a few windows) is planned again from its own census by itself -- still on the window path, still the right list."""
+    pts0, cfg = synth.make_config("small_40k")
+    handle = engine_mod.Engine(0, tool_radius=6.0)
+    for seed in (None, 77, 78, 79):
+        pts = pts0 if seed is None else synth.make_config("small_40k", seed=seed)[0]
+        handle.set_cloud(pts); S = handle.gen_path(); W = handle.get_path()
+        fresh = engine_mod.Engine(0, tool_radius=6.0); fresh.set_plan_reuse(False)
+        fresh.set_cloud(pts); assert (S, W) == (fresh.gen_path(), fresh.get_path())
+        assert handle.fast_path() and fresh.fast_path()
+        assert handle.waypoints().tobytes() == fresh.waypoints().tobytes()
+        for s in (1, S // 2, S - 2):
+            assert all(np.array_equal(x, y) for x, y in zip(handle.nodes(s), fresh.nodes(s)))
+        fresh.close()
+    # the same number of points, but 150 of them moved into the x range of one window (~560 points): it overflows the inherited plan
+    piled = pts0.copy()
+    px = handle.slice_positions()
+    x = piled[:, 0] * 1000.0
+    far = np.nonzero((x > px[len(px) * 3 // 4]) & (x < x.max() - 20.0) & (np.abs(x[:, None] - px[None, :]).min(axis=1) > 4.6))[0][:150]  # from between the windows
+    rng = np.random.default_rng(5)
+    donors = np.nonzero(np.abs(x - px[len(px) // 3]) < 3.5)[0]
+    src = piled[rng.choice(donors, len(far))]
+    piled[far, 0] = src[:, 0] + rng.uniform(-2e-4, 2e-4, len(far)).astype(np.float32)
+    piled[far, 1] = rng.uniform(piled[:, 1].min(), piled[:, 1].max(), len(far)).astype(np.float32)
+    piled[far, 2] = ((20.0 * np.sin(piled[far, 0].astype(np.float64) * 1000.0 / 600.0) * np.cos(piled[far, 1].astype(np.float64) * 1000.0 / 300.0) + 1500.0) / 1000.0).astype(np.float32)  # on the surface (synth: wavy, amp 20)
+    handle.set_cloud(piled)
+    fresh = engine_mod.Engine(0, tool_radius=6.0); fresh.set_plan_reuse(False); fresh.set_cloud(piled)
+    try:
+        ok_h = (handle.gen_path(), handle.get_path())
+    except engine_mod.PPPError as ex_h:
+        ok_h = str(ex_h)
+    try:
+        ok_f = (fresh.gen_path(), fresh.get_path())
+    except engine_mod.PPPError as ex_f:
+        ok_f = str(ex_f)
+    assert type(ok_h) == type(ok_f)
+    assert isinstance(ok_h, tuple) and ok_h == ok_f and handle.waypoints().tobytes() == fresh.waypoints().tobytes()
+    assert handle.fast_path() and fresh.fast_path()        # planned again from its own census, still on the window path
+
+
 def test_census_that_comes_with_a_new_cloud_equals_the_one_taken_at_plan_time(tmp_path):
     """A cloud that has just been set brings bounds, slice walk and window census along in the same stream
     (k_ingest_minmax's last workgroup + k_win_census_auto, results in pinned memory); a plan made later for the same cloud
@@ -1696,6 +1739,7 @@ def test_census_that_comes_with_a_new_cloud_equals_the_one_taken_at_plan_time(tm
         pts2 = pts2.copy(); pts2[::97] = np.nan
         for walk in range(5):
             e = engine.Engine(0, tool_radius=6.0, walk=walk)
+            e.set_plan_reuse(False)                                       # (every cloud takes its own census here: plan reuse has its own test)
             for cloud in (pts, pts2):
                 e.set_cloud(cloud); e.gen_path(); e.get_path()          # census came with the cloud
                 a = e.waypoints().copy(); assert e.fast_path()
