@@ -787,8 +787,10 @@ def test_dynamic_fit_paths_agree():
     src = os.path.join(root, "polishpathplanning_amd", "csrc")
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc to build the test variants with")
-    for name, defs in (("fitcount", "-DDYN_FIT_FORCE=1"), ("fitsort", "-DDYN_FIT_FORCE=3"), ("ellcheck", "-DDYN_ELL_CHECK")):
-        subprocess.run(["make", "-C", src, "variant", "NAME=%s" % name, "DEFS=%s" % defs], check=True, stdout=subprocess.DEVNULL, timeout=600)
+    jobs = [subprocess.Popen(["make", "-C", src, "variant", "NAME=%s" % name, "DEFS=%s" % defs], stdout=subprocess.DEVNULL)
+            for name, defs in (("fitcount", "-DDYN_FIT_FORCE=1"), ("fitsort", "-DDYN_FIT_FORCE=3"), ("ellcheck", "-DDYN_ELL_CHECK"))]
+    for j in jobs:
+        assert j.wait(timeout=900) == 0, j.args
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dyn_variants_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "the three paths agree" in r.stdout, r.stdout + r.stderr
 
