@@ -25,6 +25,9 @@
 #ifndef PPP_PPT8_FROM
 #define PPP_PPT8_FROM 500000 /* points from which a scatter workgroup takes 8 points per thread instead of 4: half the per-(workgroup, slab) reservations (1 M points: scatter 19.2 -> 16.2 us; 250 k points are better off with 4) */
 #endif
+#ifndef WIN_SLICE_WAVES_PER_CU
+#define WIN_SLICE_WAVES_PER_CU 16 /* waves of the slice kernel a CU holds (win_pick_threads shares them between the workgroups the LDS admits) */
+#endif
 #ifndef PPP_WIN_PPT8_FROM
 #define PPP_WIN_PPT8_FROM 1200000 /* the window path's binning launch: what it costs is its workgroups' reservations (one global atomic per workgroup and
                                      non-empty window) -- 1 M points / 256 windows: 122 workgroups of 8 points per thread 20.1 us, 244 of 4 18.8 us, 488 22.7-23.8, 977 33 us */
@@ -477,7 +480,7 @@ int win_pick_threads(const ppp_handle h, long long wgs)
 {
     const int capw = h->win_capw, cap_el = h->win_cap_el;
     int tmin = std::max(128, 64 * ((capw + 64 * WIN_EMAX - 1) / (64 * WIN_EMAX)));
-    tmin = std::max(tmin, 64 * ((cap_el + 64 * 4 - 1) / (64 * 4)));
+    tmin = std::max(tmin, 64 * ((cap_el + 64 * WIN_CE - 1) / (64 * WIN_CE)));
     if (tmin > 1024) return 0;
     const int wide = std::min(1024, std::max(256, 64 * (int)std::ceil(std::max(1.05 * (double)h->win_el_expect, 4.0 * (double)h->cnt_est) / 64.0)));
     const size_t lds = win_slice_lds_for(h, win_throughput_launch(h, wgs) ? h->win_NBc_thr : h->win_NBc) + 1024;
@@ -486,7 +489,9 @@ int win_pick_threads(const ppp_handle h, long long wgs)
     int T = wide;
     if (win_throughput_launch(h, wgs)) {
         const int conc = (int)std::min<long long>(by_lds, per_cu);
-        T = std::min(wide, 64 * std::max(1, 16 / conc));
+        int waves_cu = WIN_SLICE_WAVES_PER_CU;
+        if (const char *ev = tuning_env("PPP_WIN_WAVES_CU")) waves_cu = std::max(4, atoi(ev)); /* tuning runs only */
+        T = std::min(wide, 64 * std::max(1, waves_cu / conc));
     }
     T = std::max(T, tmin);
     if (const char *ev = tuning_env("PPP_WIN_T")) { /* tuning runs only */
@@ -583,6 +588,7 @@ int plan_window(ppp_handle h, int S, double per)
        3 workgroups 0.62 ms, 128 and 5 workgroups 0.49 ms) */
     h->win_NBc_thr = std::max(16, NBc / 2);
     while (h->win_NBc_thr * 2 <= NBc && h->win_NBc_thr < expect / 10.0) h->win_NBc_thr <<= 1;
+    if (const char *ev = tuning_env("PPP_WIN_NBC_THR")) { const int v = atoi(ev); if (v >= 16 && v <= NBc && (v & (v - 1)) == 0) h->win_NBc_thr = v; } /* tuning runs only */
     const int NB = WIN_CLASSES * NBc;
     h->win_el_expect = max_el;
     h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc;

@@ -37,7 +37,12 @@ __device__ inline void win_flag(DevMeta *m, int why) { atomicOr(&m->win_flag, wh
 #define WIN_CNT_STRIDE 1 /* ints between two windows' counters (a 128-byte line each, stride 32, changed nothing: 10 M points / 1024
                             windows 98 .. 107 us packed, 116 padded -- the scatter's bill is its 16-byte stores, not the atomics) */
 #endif
+#ifndef WIN_EMAX
 #define WIN_EMAX 8 /* staged points per thread at most (capw <= WIN_EMAX * blockDim) */
+#endif
+#ifndef WIN_CE
+#define WIN_CE 4 /* left points (pairing candidates) per thread at most (cap_el <= WIN_CE * blockDim) */
+#endif
 
 struct WinArgs {
     DevMeta *m;
@@ -571,9 +576,13 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     const int nEr = s_cs[2] - s_cs[1], nEl = s_cs[4] - el0;
     if (tid == 0) A.band_cnt[s] = s_cs[4] - s_cs[1]; /* |rangedX_index| */
     if (nEl == 0 || nEr == 0) { slice_fails(DERR_SLICE); return; }  /* empty map -> < 3 knots; empty FLANN tree */
+#ifdef WIN_NO_BRUTE /* (experiment builds: the kd kernel without the brute flavour's code) */
+    const bool brute = false;
+#else
     const bool brute = P.pairing != 0; /* ppp_params.pairing: 0 = PPP_PAIR_KD, 1 = PPP_PAIR_BRUTE (include/ppp_hip.h) */
+#endif
     if (nEl > cap_el || (brute && nEr > cap_el)) { slice_fails(-WIN_FLAG_OVERFLOW); return; }
-    constexpr int CE = 4; /* candidates per thread at most (cap_el <= CE * blockDim is checked by the plan) */
+    constexpr int CE = WIN_CE; /* candidates per thread at most (cap_el <= CE * blockDim is checked by the plan) */
     u64 kr[CE];
     int kb[CE];
     int ncand = nEl;      /* candidates of the std::map: one per left point (kd), one per pair of left_pair (brute) */
@@ -815,6 +824,45 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     const int per_round = (cnt + rounds - 1) / rounds; /* the waypoints spread evenly over the rounds */
     const bool has_plane_class = s_cs[3] > s_cs[2];
     const float r2 = P.normal_radius * P.normal_radius;
+    /* what is left of a waypoint once its searches are done: pcl::NormalEstimation's plane fit, the frame, the Euler angles, the
+       hand-eye transform, the stores into the slice's slots */
+    auto pose_and_store = [&](float *acc, const int count, const bool found, const int bidx, const float4 c0, const float4 q, const int t) {
+        const bool finite = q.y == q.y && q.z == q.z;
+        float n4[4] = {NAN, NAN, NAN, NAN};
+        if (found && count >= 3) {
+            const float cntf = (float)count;
+            for (int i = 0; i < 9; ++i) acc[i] /= cntf;
+            float cov[9];
+            cov[0] = acc[0] - acc[6] * acc[6];
+            cov[1] = acc[1] - acc[6] * acc[7];
+            cov[2] = acc[2] - acc[6] * acc[8];
+            cov[4] = acc[3] - acc[7] * acc[7];
+            cov[5] = acc[4] - acc[7] * acc[8];
+            cov[8] = acc[5] - acc[8] * acc[8];
+            cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+            float ev, nn[3];
+            pcl_eigen33_smallest<false>(cov, &ev, nn); /* continuous outputs only: the device float trig is enough */
+            const float eig_sum = cov[0] + cov[4] + cov[8];
+            const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+            const float vx = P.viewpoint[0] - c0.x, vy = P.viewpoint[1] - c0.y, vz = P.viewpoint[2] - c0.z;
+            if (vx * nn[0] + vy * nn[1] + vz * nn[2] < 0) { nn[0] *= -1; nn[1] *= -1; nn[2] *= -1; }
+            n4[0] = nn[0]; n4[1] = nn[1]; n4[2] = nn[2]; n4[3] = curv;
+        }
+        if (!finite) set_err(m, DERR_QUERY, -1);
+        float wp[6], rpy[3];
+        pose_from_normal(n4, rpy);
+        if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
+        else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
+        wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
+        handeye_apply(HE, P.handeye, wp);
+        /* Vector4f(point), std::reverse on every second slice (:166-168) */
+        const size_t slot = (size_t)k * A.stride + (size_t)((k & 1) ? (cnt - 1 - t) : t);
+        A.wps_xyz[slot] = q;
+        A.wps_nn[slot] = found ? bidx : -1;
+        A.wps_normal[slot] = make_float4(n4[0], n4[1], n4[2], n4[3]);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) A.wps_pre[6 * slot + d] = wp[d];
+    };
     for (int rd = 0; rd < rounds; ++rd) {
         const int lt = tid >> gshift;
         const int t = rd * per_round + lt;
@@ -940,7 +988,11 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         WIN_STOP(8, count ^ __float_as_int(acc[0] + acc[4] + acc[8]));
         /* What is left of a waypoint -- eigen33, frame, Euler angles, hand-eye: some 850 instructions, a third of this kernel's
            VALU work when the one lane in G that holds the sums runs them with the others idle -- is done below by one thread per
-           waypoint: the searches park their result in the waypoint's slot (the same workgroup reads it back: L2 / L1 of this CU). */
+           waypoint: the searches park their result in the waypoint's slot (the same workgroup reads it back: L2 / L1 of this CU).
+           (-DWIN_SPARSE_POSE: the earlier form, that lane finishes its waypoint here; kept for the A/B of DESIGN.md A.2.) */
+#ifdef WIN_SPARSE_POSE
+        if (act && g == 0) pose_and_store(acc, count, found, bidx, c0, q, t);
+#else
         if (act && g == 0) {
             float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t);
             rec[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -948,53 +1000,19 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             rec[2] = make_float4(acc[8], __int_as_float(found ? count : -1), c0.x, c0.y);
             rec[3] = make_float4(c0.z, q.y, q.z, __int_as_float(found ? bidx : -1));
         }
+#endif
     }
+#ifndef WIN_SPARSE_POSE
     __syncthreads();
     STAMP(6, 9); /* records parked */
     for (int t = tid; t < cnt; t += T) {
         const float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t);
         const float4 r0 = rec[0], r1 = rec[1], r2v = rec[2], r3 = rec[3];
         float acc[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2v.x};
-        const int count = __float_as_int(r2v.y), bidx = __float_as_int(r3.w);
-        const bool found = count >= 0;
-        const float4 c0 = make_float4(r2v.z, r2v.w, r3.x, 0.f);
-        const float4 q = make_float4((float)(double)Px, r3.y, r3.z, 1.f);
-        const bool finite = q.y == q.y && q.z == q.z;
-        float n4[4] = {NAN, NAN, NAN, NAN};
-        if (found && count >= 3) {
-            const float cntf = (float)count;
-            for (int i = 0; i < 9; ++i) acc[i] /= cntf;
-            float cov[9];
-            cov[0] = acc[0] - acc[6] * acc[6];
-            cov[1] = acc[1] - acc[6] * acc[7];
-            cov[2] = acc[2] - acc[6] * acc[8];
-            cov[4] = acc[3] - acc[7] * acc[7];
-            cov[5] = acc[4] - acc[7] * acc[8];
-            cov[8] = acc[5] - acc[8] * acc[8];
-            cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-            float ev, nn[3];
-            pcl_eigen33_smallest<false>(cov, &ev, nn); /* continuous outputs only: the device float trig is enough */
-            const float eig_sum = cov[0] + cov[4] + cov[8];
-            const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
-            const float vx = P.viewpoint[0] - c0.x, vy = P.viewpoint[1] - c0.y, vz = P.viewpoint[2] - c0.z;
-            if (vx * nn[0] + vy * nn[1] + vz * nn[2] < 0) { nn[0] *= -1; nn[1] *= -1; nn[2] *= -1; }
-            n4[0] = nn[0]; n4[1] = nn[1]; n4[2] = nn[2]; n4[3] = curv;
-        }
-        if (!finite) set_err(m, DERR_QUERY, -1);
-        float wp[6], rpy[3];
-        pose_from_normal(n4, rpy);
-        if (P.change_range) { wp[0] = q.x / 1000; wp[1] = q.y / 1000; wp[2] = q.z / 1000; }
-        else { wp[0] = q.x; wp[1] = q.y; wp[2] = q.z; }
-        wp[3] = rpy[0]; wp[4] = rpy[1]; wp[5] = rpy[2];
-        handeye_apply(HE, P.handeye, wp);
-        /* Vector4f(point), std::reverse on every second slice (:166-168) */
-        const size_t slot = (size_t)k * A.stride + (size_t)((k & 1) ? (cnt - 1 - t) : t);
-        A.wps_xyz[slot] = q;
-        A.wps_nn[slot] = found ? bidx : -1;
-        A.wps_normal[slot] = make_float4(n4[0], n4[1], n4[2], n4[3]);
-#pragma unroll
-        for (int d = 0; d < 6; ++d) A.wps_pre[6 * slot + d] = wp[d];
+        const int count = __float_as_int(r2v.y);
+        pose_and_store(acc, count, count >= 0, __float_as_int(r3.w), make_float4(r2v.z, r2v.w, r3.x, 0.f), make_float4((float)(double)Px, r3.y, r3.z, 1.f), t);
     }
+#endif
     STAMP(6, 10); /* eigen33, frame, Euler, hand-eye, stores: one thread per waypoint */
 }
 

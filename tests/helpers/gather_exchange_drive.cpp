@@ -2,9 +2,11 @@
 // ppp_gather_waypoints) with recording stand-ins for ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv and the
 // root's device copy, and prints every call as one line.  No GPU, no RCCL.
 //   usage: drive <rank> <nranks> <root> <fail_at> <count_0> ... <count_{nranks-1}>
+//          drive self <fail_at> <rows>      (ppp_gather_self_loop: the one-rank pre-flight, send to self + recv from self)
 //   fail_at: -1 none, 0 group_start, k > 0: the k-th send/recv returns ncclResult 5, 100: group_end returns 3, 200: the copy fails
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "ppp_gather.h"
 
@@ -34,6 +36,17 @@ static int local_copy(void *dst, const void *src, size_t bytes, void *stream)
 
 int main(int argc, char **argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "self") {
+        g_fail_at = atoi(argv[2]);
+        const size_t rows = (size_t)atoll(argv[3]);
+        std::vector<float> send(6 * (rows + 1)), recv(6 * (rows + 1));
+        g_send0 = send.data(); g_recv0 = recv.data();
+        PppGatherOps ops{group_start, group_end, do_send, do_recv, local_copy};
+        int nres = -1;
+        const int rc = ppp_gather_self_loop(ops, rows, send.data(), recv.data(), (void *)0x1234, (void *)0x5678, &nres);
+        printf("rc=%d nccl=%d\n", rc, nres);
+        return 0;
+    }
     if (argc < 5) return 2;
     const int rank = atoi(argv[1]), nranks = atoi(argv[2]), root = atoi(argv[3]);
     g_fail_at = atoi(argv[4]);

@@ -496,6 +496,11 @@ def test_gather_exchange_call_pattern(tmp_path):
     assert _gather_drive(d, 1, 3, 0, 0, 4, 4, 4) == ["group_start", "rc=2 nccl=2"]
     # the root's own copy fails before any group call
     assert _gather_drive(d, 0, 3, 0, 200, 4, 4, 4)[1:] == ["rc=1 nccl=0"]
+    # the one-rank pre-flight (ppp_gather_self_loop): send to self + recv from self inside ONE group, no copy; the group is closed when the send fails
+    assert _gather_drive(d, "self", -1, 9) == ["group_start", "send off=0 count=54 dtype=7 peer=0 comm=0x1234 stream=0x5678",
+                                               "recv off=0 count=54 dtype=7 peer=0 comm=0x1234 stream=0x5678", "group_end", "rc=0 nccl=0"]
+    assert _gather_drive(d, "self", 1, 9) == ["group_start", "send off=0 count=54 dtype=7 peer=0 comm=0x1234 stream=0x5678", "group_end", "rc=3 nccl=5"]
+    assert _gather_drive(d, "self", -1, 0) == ["rc=0 nccl=0"]
 
 
 def test_bench_refuses_to_start_ranks_from_under_a_profiler():
