@@ -161,6 +161,7 @@ struct ppp_handle_s {
     float win_pad = 4.f;
     int win_NBc_thr = 0; /* y-buckets per class in launches of several workgroups per CU: the most that cost no workgroup its place in the LDS */
     int win_capw = 0, win_cap_el = 0, win_NB = 0, win_NBc = 0, win_stride = 1, win_threads = 256, win_ppt = 4, win_gs = 1;
+    int win_rec_lds = 0; /* waypoint records parked in the slice workgroup's LDS (0: in global slots) */
     int win_nkept = 0, win_first_kept = 0, win_el_expect = 0;
     float win_px0 = 0.f;
     DevBuf<float> win_px;
@@ -471,7 +472,7 @@ constexpr size_t PIN_REC0 = 0, PIN_REC1 = 64, PIN_PX = 128, PIN_CENSUS = PIN_PX 
    waves shared between them (measured, 64 x 250 k points: 256 threads 0.42 ms, 320 .. 512 threads 0.58 .. 0.64 ms). */
 size_t win_slice_lds_for(const ppp_handle h, int NBc)
 {   /* (the checking workgroup of the launch keeps the walk and its scratch there) */
-    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, WIN_CLASSES * NBc), sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
+    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, WIN_CLASSES * NBc) + (size_t)64 * (size_t)h->win_rec_lds, sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
 }
 /* several workgroups per CU, at once or one after the other? */
 bool win_throughput_launch(const ppp_handle h, long long wgs) { return wgs > (long long)h->num_cus; }
@@ -592,6 +593,7 @@ int plan_window(ppp_handle h, int S, double per)
     const int NB = WIN_CLASSES * NBc;
     h->win_el_expect = max_el;
     h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc;
+    h->win_rec_lds = 0; /* (decided below, and so that it never changes how many workgroups share a CU) */
     int T = win_pick_threads(h, std::max(1, h->se - h->sb));
     if (!T) return PPP_OK;
     /* points per thread of the binning launch: 8 from 1.2 million points on (16 was slower at 10 M points: 107 against 100 us) */
@@ -613,6 +615,16 @@ int plan_window(ppp_handle h, int S, double per)
     if (h->win_staged) h->win_gs = std::min(h->win_gs, std::max(1, h->num_cus)); /* the staged form loops over its chunks: a workgroup per CU (its LDS admits no second) */
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
+    {   /* the waypoints' records between their searches and their pose (64 bytes each): in the workgroup's LDS where that costs no
+           workgroup per CU, else through their global slots (10 M points / 1024 slices: the window alone fills the CU's LDS) */
+        h->win_rec_lds = 0;
+        const size_t rec = (size_t)64 * (size_t)h->win_stride, cu = (size_t)h->max_lds;
+        const size_t a = win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) + 1024, b = win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * h->win_NBc_thr) + 1024;
+        if (a + rec <= budget && cu / (a + rec) == cu / a && cu / (b + rec) == cu / b) h->win_rec_lds = h->win_stride;
+#ifdef WIN_REC_GLOBAL /* (A/B builds) */
+        h->win_rec_lds = 0;
+#endif
+    }
     h->win_first_kept = h->P.drop_ends ? 1 : 0;
     h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
     h->win_px0 = px[0];
@@ -655,7 +667,7 @@ WinArgs win_args(const ppp_handle h)
     { const float yr = h->h_mx[1] - h->h_mn[1]; A.yscale = yr > 0.f ? (float)h->win_NBc / yr : 0.f; }
     for (int d = 0; d < 3; ++d) { A.plan_mn[d] = h->h_mn[d]; A.plan_mx[d] = h->h_mx[d]; }
     A.plan_nvalid = h->h_nvalid;
-    A.capw = h->win_capw; A.cap_el = h->win_cap_el; A.NB = h->win_NB; A.NBc = h->win_NBc; A.stride = h->win_stride;
+    A.capw = h->win_capw; A.cap_el = h->win_cap_el; A.NB = h->win_NB; A.NBc = h->win_NBc; A.stride = h->win_stride; A.rec_lds = h->win_rec_lds;
     A.W_cap = h->W_cap; A.node_cap = h->node_cap;
     A.g_scatter = h->win_gs; A.g_slice = std::max(0, h->se - h->sb); A.g_finish = h->sm_tiles;
     A.finish = h->ranged ? 0 : 1;

@@ -56,6 +56,7 @@ struct WinArgs {
     float plan_mn[3], plan_mx[3];
     int plan_nvalid;
     int capw, cap_el, NB, NBc, stride, W_cap, node_cap;
+    int rec_lds; /* waypoint records a slice workgroup parks in its LDS (behind the pairing scratch); 0: in the waypoints' global slots (wps_rec) */
     int g_scatter, g_slice, g_finish; /* workgroups of this workpiece per launch */
     int finish; /* 0: a slice-range handle stops after HandEyeTransform (the list is compacted only) */
     int *win_cnt;
@@ -471,6 +472,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     u64 *ckeys = (u64 *)(cz + cap_el);        /* candidates sorted by y; later the knots as (y, z) pairs */
     int *hc = (int *)(ckeys + cap_el);        /* histogram of that sort, then the kept candidates */
     float2 *knot = (float2 *)ckeys;
+    float4 *rec_lds = (float4 *)(s_raw + win_slice_lds_bytes(capw, cap_el, NB)); /* A.rec_lds records of 64 bytes, when the plan gave them room */
 
     const int s = A.sb + bx;
     if (s >= A.se) return;
@@ -994,11 +996,11 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         if (act && g == 0) pose_and_store(acc, count, found, bidx, c0, q, t);
 #else
         if (act && g == 0) {
-            float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t);
-            rec[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            rec[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            rec[2] = make_float4(acc[8], __int_as_float(found ? count : -1), c0.x, c0.y);
-            rec[3] = make_float4(c0.z, q.y, q.z, __int_as_float(found ? bidx : -1));
+            const float4 v0 = make_float4(acc[0], acc[1], acc[2], acc[3]), v1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            const float4 v2 = make_float4(acc[8], __int_as_float(found ? count : -1), c0.x, c0.y);
+            const float4 v3 = make_float4(c0.z, q.y, q.z, __int_as_float(found ? bidx : -1));
+            if (A.rec_lds) { float4 *rec = rec_lds + 4 * t; rec[0] = v0; rec[1] = v1; rec[2] = v2; rec[3] = v3; }
+            else { float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t); rec[0] = v0; rec[1] = v1; rec[2] = v2; rec[3] = v3; }
         }
 #endif
     }
@@ -1006,8 +1008,9 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     __syncthreads();
     STAMP(6, 9); /* records parked */
     for (int t = tid; t < cnt; t += T) {
-        const float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t);
-        const float4 r0 = rec[0], r1 = rec[1], r2v = rec[2], r3 = rec[3];
+        float4 r0, r1, r2v, r3;
+        if (A.rec_lds) { const float4 *rec = rec_lds + 4 * t; r0 = rec[0]; r1 = rec[1]; r2v = rec[2]; r3 = rec[3]; }
+        else { const float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t); r0 = rec[0]; r1 = rec[1]; r2v = rec[2]; r3 = rec[3]; }
         float acc[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2v.x};
         const int count = __float_as_int(r2v.y);
         pose_and_store(acc, count, count >= 0, __float_as_int(r3.w), make_float4(r2v.z, r2v.w, r3.x, 0.f), make_float4((float)(double)Px, r3.y, r3.z, 1.f), t);
