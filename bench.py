@@ -266,13 +266,12 @@ def main():
         engine_gather = None
         if force_dist and args.batch == 1:
             # the engine's own exchange (ppp_gather_waypoints: ncclSend / ncclRecv group on the PLANNER's stream) rehearsed against the real
-            # librccl with a one-rank communicator -- the block sent to itself and received (PPP_GATHER_REHEARSE) -- beside the framework's
+            # librccl with a one-rank communicator -- the block sent to itself and received -- beside the framework's
             # gather above: step time with and without it, same handle, same stream, host wait once per loop
             try:
                 from polishpathplanning_amd.robot_path import RcclComm
                 comm = RcclComm(0, 1)
                 rbuf = torch.empty((max(w_all[0], 1), 6), dtype=torch.float32, device=dev)
-                os.environ["PPP_GATHER_REHEARSE"] = "1"
 
                 def loop(with_gather, count):
                     t = time.perf_counter()
@@ -289,7 +288,6 @@ def main():
                 engine_gather = {"step_ms_with_group_send_recv": t_with, "step_ms_without_exchange": t_without, "added_us": (t_with - t_without) * 1e3,
                                  "received_block_equals_the_list": same,
                                  "note": "one rank, real librccl: ncclSend to self + ncclRecv from self in one group on the planner's stream"}
-                del os.environ["PPP_GATHER_REHEARSE"]
                 comm.close()
             except Exception as ex:
                 engine_gather = {"error": "%s: %s" % (type(ex).__name__, ex)}

@@ -178,8 +178,8 @@ int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed);
  * ncclComm_t (one rank per process / GPU); librccl is looked up at the first call (dlopen), the engine itself does not
  * link it.  Frameworks that own the communicator (torch.distributed) use their own collective on the list's device
  * pointer instead -- polishpathplanning_amd/robot_path.py.
- * Pre-flight on one GPU: with nranks == 1, a real one-rank communicator and PPP_GATHER_REHEARSE set in the environment the
- * block goes through librccl's group (ncclSend to self + ncclRecv from self) instead of the plain copy a lone rank needs. */
+ * nranks == 1: with nccl_comm == NULL the list is copied to recv_dev; with a (one-rank) communicator it goes through librccl's
+ * group -- ncclSend to self + ncclRecv from self -- which is the pre-flight of this exchange on one GPU. */
 int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, int root, const size_t *counts_rows, float *recv_dev);
 /* the handle's HIP stream (hipStream_t), so a framework can order its own work after the planner's on the GPU
  * (e.g. torch.cuda.ExternalStream + wait_stream before the RCCL gather) instead of waiting on the host */

@@ -704,10 +704,11 @@ int enqueue_window_gen(ppp_handle h)
     else LAUNCH(h, "k_win_scatter", (k_win_scatter<4, false>), A.g_scatter, WSC_T, scat_lds, A);
     const int T = h->win_threads;
     const size_t lds = win_slice_lds_for(h, A.NBc);
-    if (T <= 256) LAUNCH(h, "k_win_slice", k_win_slice<256>, A.g_slice + 1, T, lds, A);
-    else if (T <= 512) LAUNCH(h, "k_win_slice", k_win_slice<512>, A.g_slice + 1, T, lds, A);
-    else if (T <= 768) LAUNCH(h, "k_win_slice", k_win_slice<768>, A.g_slice + 1, T, lds, A);
-    else LAUNCH(h, "k_win_slice", k_win_slice<1024>, A.g_slice + 1, T, lds, A);
+    const int extra = tuning_env("PPP_WIN_NO_VERIFY") ? 0 : 1; /* (tuning runs only: what the checking workgroup costs the launch) */
+    if (T <= 256) LAUNCH(h, "k_win_slice", k_win_slice<256>, A.g_slice + extra, T, lds, A);
+    else if (T <= 512) LAUNCH(h, "k_win_slice", k_win_slice<512>, A.g_slice + extra, T, lds, A);
+    else if (T <= 768) LAUNCH(h, "k_win_slice", k_win_slice<768>, A.g_slice + extra, T, lds, A);
+    else LAUNCH(h, "k_win_slice", k_win_slice<1024>, A.g_slice + extra, T, lds, A);
     h->stage_compact = false;
     return PPP_OK;
 }
@@ -2425,8 +2426,9 @@ int ppp_gather_waypoints(ppp_handle h, void *nccl_comm, int rank, int nranks, in
     if (!h->path_done || !h->list_final) return fail(h, PPP_ERR_ARG, "no finished list on this handle (call ppp_get_path_async / ppp_run_async first)");
     if (counts_rows[rank] > (size_t)h->W_cap) return fail(h, PPP_ERR_CAPACITY, "counts_rows[rank] exceeds this handle's list capacity");
     if (rank == root && !recv_dev) return fail(h, PPP_ERR_ARG, "the root needs a receive buffer");
-    /* rehearsal (one rank, a real one-rank communicator): the block travels through librccl's send / recv group instead of the copy */
-    const bool rehearse = nranks == 1 && nccl_comm != nullptr && getenv("PPP_GATHER_REHEARSE") != nullptr;
+    /* one rank WITH a communicator (a one-rank group: the pre-flight of this exchange on one GPU): the block travels through librccl's
+       send / recv group -- to itself -- instead of the plain copy a lone rank without a communicator gets */
+    const bool rehearse = nranks == 1 && nccl_comm != nullptr;
     if (nranks == 1 && !rehearse) { /* nothing to exchange: the list goes to the receive buffer */
         if (counts_rows[0]) HIPCHK(h, hipMemcpyAsync(recv_dev, h->wp_out.p, counts_rows[0] * 24, hipMemcpyDeviceToDevice, h->stream));
         return PPP_OK;

@@ -51,7 +51,7 @@ static inline int ppp_gather_exchange(const PppGatherOps &ops, int rank, int nra
 
 /* Pre-flight of the group path on ONE rank (no second GPU needed): the rank sends its block to itself and receives it, both
    inside one ncclGroupStart / ncclGroupEnd -- the same calls, datatype, communicator and stream a multi-rank gather hands to
-   librccl, with real transfers behind them (ppp_gather_waypoints with nranks == 1 and PPP_GATHER_REHEARSE=1;
+   librccl, with real transfers behind them (ppp_gather_waypoints with nranks == 1 and a one-rank communicator;
    tests/test_gpu_parity.py::test_gather_rehearsal_through_the_real_rccl). */
 static inline int ppp_gather_self_loop(const PppGatherOps &ops, size_t rows, const float *send, float *recv, void *comm, void *stream,
                                        int *nccl_result)

@@ -1564,7 +1564,7 @@ def test_gather_waypoints_multi_rank_pattern_through_a_recording_rccl(tmp_path):
 
 def test_gather_rehearsal_through_the_real_rccl():
     """Pre-flight of ppp_gather_waypoints' send / recv group against the REAL librccl on one GPU: a one-rank
-    communicator, PPP_GATHER_REHEARSE=1, the handle's list sent to itself and received inside one ncclGroupStart / ncclGroupEnd on
+    communicator handed to ppp_gather_waypoints with nranks == 1, the handle's list sent to itself and received inside one ncclGroupStart / ncclGroupEnd on
     the handle's stream; the received block equals the list byte for byte.  In a child process with a deadline: a collective
     that never completes must not take the suite with it."""
     import os
@@ -1585,7 +1585,6 @@ comm = RcclComm(0, 1)
 recv = DeviceBuffer(W * 24)
 plain = DeviceBuffer(W * 24)
 e.gather_waypoints(0, 0, 1, 0, [W], plain.ptr); e.sync()          # the lone rank's plain copy
-os.environ["PPP_GATHER_REHEARSE"] = "1"
 for _ in range(3):                                                   # the group path, more than once on the same communicator
     e.gather_waypoints(comm.ptr, 0, 1, 0, [W], recv.ptr)
 e.sync()

@@ -10,13 +10,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from polishpathplanning_amd import engine, synth  # noqa: E402
 
 args = sys.argv[1:]
-if args and args[0] == "--lib":
-    engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), args[1])
-    args = args[2:]
 loose = False
-if args and args[0] == "--loose":          # diagnostic builds whose results are wrong on purpose (tools/phase_costs.sh): errors are reported, not raised
-    loose = True
-    args = args[1:]
+while args and args[0] in ("--lib", "--loose"):
+    if args[0] == "--lib":
+        engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), args[1])
+        args = args[2:]
+    else:                                  # diagnostic builds whose results are wrong on purpose (tools/phase_costs.sh): errors are reported, not raised
+        loose = True
+        args = args[1:]
 rng_kw = {}
 if args and args[0] == "--range":          # one slice-range handle: --range begin:end
     b, e_ = args[1].split(":")
