@@ -8,7 +8,11 @@
  * There is no CPU fallback: without a HIP device every entry point fails loudly.
  */
 #include "ppp_kernels.h"
+#ifdef PPP_SINGLE_TU /* diagnostic builds (in-kernel stamps share one g_stamps array): the window kernels in this translation unit */
 #include "ppp_window.h"
+#else
+#include "ppp_window_decl.h" /* their kernels are ppp_window.hip's */
+#endif
 #include "ppp_preproc.h"
 #include "ppp_sort.h"
 #include "ppp_align.h"

@@ -13,6 +13,14 @@
  * LDS bandwidth and by dependent-load latency.
  */
 #pragma once
+/* The kernels of this header belong to the engine's translation unit.  A translation unit that needs the header's types and device
+   helpers only (ppp_window.hip) defines PPP_KERNELS_FOREIGN: the non-template kernels are templates there and, never launched,
+   never instantiated (a static kernel would still be compiled and emitted: 47 functions in that translation unit's code object). */
+#ifdef PPP_KERNELS_FOREIGN
+#define PPP_KERNEL template <typename PPP_NEVER_ = void> __global__
+#else
+#define PPP_KERNEL __global__
+#endif
 #include "ppp_device.h"
 
 struct DevMeta {
@@ -93,7 +101,7 @@ __device__ inline int ytab_bucket(const DevMeta *m, float y)
 /* points are canonicalised to NaN: PassThrough, getMinMax3D and the   */
 /* kd-tree all skip them.                 */
 /* ------------------------------------------------------------------ */
-__global__ void k_ingest(const char *raw, size_t stride, int n, int scale, float *X, float *Y, float *Z)
+PPP_KERNEL void k_ingest(const char *raw, size_t stride, int n, int scale, float *X, float *Y, float *Z)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -309,7 +317,7 @@ struct PlanAutoArgs {
     int px_cap;
     float *px_host;       /* pinned: a copy of that table for the host (nullptr: the census that follows hands it over) */
 };
-__global__ void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__ raw, size_t stride, int n, int scale, float *__restrict__ X,
+PPP_KERNEL void __launch_bounds__(MM_T) k_ingest_minmax(const char *__restrict__ raw, size_t stride, int n, int scale, float *__restrict__ X,
                                                        float *__restrict__ Y, float *__restrict__ Z, MinMaxPart *part, PlanAutoArgs PA)
 {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -933,7 +941,7 @@ __device__ inline int flatten_nodes(const SliceLds &L, int ncand, float *out_y, 
     return s_m;
 }
 
-__global__ void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                const float *__restrict__ hi, int pairing, int capb, float *node_x, float *node_y,
                                                float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list)
@@ -987,7 +995,7 @@ __host__ __device__ inline size_t slice_brute_bytes(size_t n)
 {   /* a4 16 + keys 8 + el er rstar lstar pairL pairR 24 + hist 4 (NB <= n) + flags */
     return n * 52 + (n / 4) + 256;
 }
-__global__ void __launch_bounds__(1024) k_slice_brute_arena(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void __launch_bounds__(1024) k_slice_brute_arena(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                             DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                             const float *__restrict__ hi, int pairing, int ncloud, float *node_x, float *node_y,
                                                             float *node_z, int node_cap, int *node_start, int *node_cnt, const int *band_cnt,
@@ -1464,7 +1472,7 @@ __device__ __forceinline__ void slice_kd_body(const float4 *__restrict__ sorted4
 }
 
 /* API mirrors: rangedX_index(position) and insert_point(indices, plane) on one workgroup */
-__global__ void __launch_bounds__(256) k_band_indices(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void __launch_bounds__(256) k_band_indices(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                       DevMeta *m, float lo, float hi, int capb, int *out, int out_cap)
 {
     extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -1478,7 +1486,7 @@ __global__ void __launch_bounds__(256) k_band_indices(const float4 *__restrict__
 
 /* rangedX_index for a band that does not fit LDS: same result from global scratch
    (tmp, sorted: n keys each; hist: NB + 1 ints), one workgroup. */
-__global__ void __launch_bounds__(256) k_band_indices_big(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void __launch_bounds__(256) k_band_indices_big(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                           DevMeta *m, float lo, float hi, int npts, u64 *tmp, u64 *sorted,
                                                           int *hist, int NB, int cap, int *out)
 {
@@ -1508,7 +1516,7 @@ __global__ void __launch_bounds__(256) k_band_indices_big(const float4 *__restri
     if (threadIdx.x == 0) { m->api_cnt = n; m->api_flag = 0; }
 }
 
-__global__ void __launch_bounds__(256) k_insert_api(const float *__restrict__ X, const float *__restrict__ Y,
+PPP_KERNEL void __launch_bounds__(256) k_insert_api(const float *__restrict__ X, const float *__restrict__ Y,
                                                     const float *__restrict__ Z, int npts, const int *__restrict__ indices,
                                                     int n, float Px, int pairing, int capb, DevMeta *m, float *out_y,
                                                     float *out_z, int out_cap)
@@ -1537,7 +1545,7 @@ __global__ void __launch_bounds__(256) k_insert_api(const float *__restrict__ X,
 /* ------------------------------------------------------------------ */
 /* ppp_finish_path_async: the list was sampled elsewhere (slice-range handles); rebuild the per-run state
    getPath's second half needs from the per-slice counts: offsets, TailIndex, the B.6 flag, W. */
-__global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,
+PPP_KERNEL void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, int nk, int W_given, int *wp_cnt, int *wp_off, int *tail,
                                                       int W_cap)
 {
     __shared__ int scratch[17];
@@ -1574,7 +1582,7 @@ __global__ void __launch_bounds__(1024) k_count_given(DevMeta *m, DevParams P, i
 }
 
 /* ... and the list itself into the buffer k_pose leaves it in */
-__global__ void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float *__restrict__ pre6, float *wp_pre)
+PPP_KERNEL void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float *__restrict__ pre6, float *wp_pre)
 {
     const int W = m->W;
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1582,7 +1590,7 @@ __global__ void __launch_bounds__(256) k_load_pre(const DevMeta *m, const float 
     for (int d = 0; d < 6; ++d) wp_pre[6 * (size_t)w + d] = pre6[6 * (size_t)w + d];
 }
 
-__global__ void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const float *__restrict__ node_y,
+PPP_KERNEL void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const float *__restrict__ node_y,
                            const float *__restrict__ node_z, const int *__restrict__ node_start,
                            const int *__restrict__ node_cnt, int s, const double *__restrict__ yq, int kq, double *out)
 {
@@ -1608,7 +1616,7 @@ __global__ void k_eval_api(DevMeta *m, const float *__restrict__ node_x, const f
 /* Spline::point(y) on caller-supplied knots (include/Spline.h:10-25: two gsl_interp_steffen splines y->x, y->z over the
    same strictly increasing y): the same steffen.c restatement as above, on double knots.  Outside [y_0, y_{m-1}] GSL
    raises GSL_EDOM (and its default handler aborts): NaN + the flag here. */
-__global__ void k_spline_eval_d(const double *__restrict__ ky, const double *__restrict__ kx, const double *__restrict__ kz, int mm,
+PPP_KERNEL void k_spline_eval_d(const double *__restrict__ ky, const double *__restrict__ kx, const double *__restrict__ kz, int mm,
                                 const double *__restrict__ yq, int kq, double *out, int *flag)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2246,7 +2254,7 @@ __device__ __forceinline__ void pose_body(DevMeta *m, const DevParams &P, const 
     }
 }
 
-__global__ void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void k_normals_api(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                               const float *__restrict__ slab_xmin, const float *__restrict__ slab_xmax,
                               const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
                               int npts, const int *__restrict__ idx, int k, float *out4)
@@ -2379,7 +2387,7 @@ __device__ inline void normal_at_indexed_point(const SlabView &V, NrmLds &L, con
     out[0] = n[0]; out[1] = n[1]; out[2] = n[2]; out[3] = curv;
 }
 
-__global__ void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
+PPP_KERNEL void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, const float4 *__restrict__ sorted4,
                                                      const int *__restrict__ slab_start, const float *__restrict__ slab_xmin,
                                                      const float *__restrict__ slab_xmax, const int *__restrict__ ytab, int nsorted, float4 *out4)
 {
@@ -2393,7 +2401,7 @@ __global__ void __launch_bounds__(256) k_normals_all(DevMeta *m, DevParams P, co
     out4[idx_of(p)] = make_float4(n4[0], n4[1], n4[2], n4[3]);
 }
 
-__global__ void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+PPP_KERNEL void k_nearest_api(DevMeta *m, const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                               const float *__restrict__ slab_xmin, const float *__restrict__ slab_xmax,
                               const float *__restrict__ q, int k, int *out)
 {
@@ -2684,7 +2692,7 @@ struct BatchMember {
     int *ytab, *slice_wpcnt;
 };
 
-__global__ void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
+PPP_KERNEL void __launch_bounds__(SETUP_T) k_setup(DevMeta *m, DevParams P, const MinMaxPart *__restrict__ part, int nparts,
                                                float *px, float *lo, float *hi, int S_cap, int B, int *slab_cnt, float slab_x0,
                                                float slab_invw, int *slab_start, int *slab_cursor, int *coarse_cursor)
 {
@@ -2797,7 +2805,7 @@ __global__ void __launch_bounds__(TMAX) k_pose(DevMeta *m, DevParams P, const fl
     pose_body<ALIGNED, (TMAX <= 768 ? POSE_PRE : 0)>(m, P, sorted4, slab_start, slab_xmin, slab_xmax, px, node_x, node_y, node_z, node_start, node_cnt, wp_cnt, wp_off,
                        tail, W_cap, arena_ran, knot_cap, stage_cap, tab_slabs, pad, wp_xyz, wp_nn, wp_normal, wp_pre, back, ytab, slice_wpcnt, blockIdx.x);
 }
-__global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
+PPP_KERNEL void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P, int W_cap, const float *__restrict__ wp_pre,
                                                         float *wp_smooth, float *wp_out, const int *__restrict__ tail,
                                                         float *dst2, int cap2)
 {
@@ -2805,13 +2813,13 @@ __global__ void __launch_bounds__(SMF_T) k_smooth_solve(DevMeta *m, DevParams P,
 }
 
 /* ---- batched forms ---- */
-__global__ void __launch_bounds__(MM_T) k_minmax_b(const BatchMember *__restrict__ mem)
+PPP_KERNEL void __launch_bounds__(MM_T) k_minmax_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_minmax) return;
     minmax_body<true>(M.X, M.Y, M.Z, M.n, M.mm_part, M.slab_x0, M.slab_invw, M.B, M.slab_cnt, M.incl_lo, M.incl_hi, M.slab_cursor, blockIdx.x, M.g_minmax);
 }
-__global__ void __launch_bounds__(SETUP_T) k_setup_b(const BatchMember *__restrict__ mem)
+PPP_KERNEL void __launch_bounds__(SETUP_T) k_setup_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     setup_body(M.m, M.P, M.mm_part, M.g_minmax, M.px, M.lo, M.hi, M.S_cap, M.B, M.slab_cnt, M.slab_x0, M.slab_invw, M.slab_start,
@@ -2831,13 +2839,13 @@ __global__ void __launch_bounds__(SCAT_T) k_slab_scatter_b(const BatchMember *__
     }
     slab_scatter_fused_body<PPT>(M.X, M.Y, M.Z, M.n, G, M.slab_cnt, M.slab_cursor, M.unsorted4, nullptr, blockIdx.x);
 }
-__global__ void __launch_bounds__(SORT_T) k_slab_sort_b(const BatchMember *__restrict__ mem)
+PPP_KERNEL void __launch_bounds__(SORT_T) k_slab_sort_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_sort) return;
     slab_sort_body<false>(M.unsorted4, M.slab_start, M.sorted4, M.slab_xmin, M.slab_xmax, M.m, M.slab_cap, M.big_slabs, nullptr, 0ull, M.ytab, M.slab_cnt, blockIdx.x);
 }
-__global__ void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__restrict__ mem)
+PPP_KERNEL void __launch_bounds__(SLICE_KD_T) k_slice_kd_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_slice) return;
@@ -2854,14 +2862,14 @@ __global__ void __launch_bounds__(TMAX) k_pose_b(const BatchMember *__restrict__
     pose_body<false, (TMAX <= 768 ? POSE_PRE : 0)>(M.m, M.P, M.sorted4, M.slab_start, M.slab_xmin, M.slab_xmax, M.px, M.node_x, M.node_y, M.node_z, M.node_start, M.node_cnt,
                      M.wp_cnt, M.wp_off, M.tail, M.W_cap, 0, M.knot_cap, M.stage_cap, M.tab_slabs, M.pose_pad, M.wp_xyz, M.wp_nn, M.wp_normal, M.wp_pre, none, M.ytab, M.slice_wpcnt, blockIdx.x);
 }
-__global__ void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
+PPP_KERNEL void __launch_bounds__(SMF_T) k_smooth_solve_b(const BatchMember *__restrict__ mem)
 {
     const BatchMember &M = mem[blockIdx.y];
     if ((int)blockIdx.x >= M.g_smooth) return;
     smooth_solve_body(M.m, M.P, M.W_cap, M.wp_pre, M.wp_smooth, M.wp_out, M.tail, M.out2, M.out2_cap, blockIdx.x);
 }
 /* the members' meta blocks side by side, so that ONE copy publishes the batch to the host */
-__global__ void __launch_bounds__(64) k_collect_meta(const BatchMember *__restrict__ mem, int count, DevMeta *out)
+PPP_KERNEL void __launch_bounds__(64) k_collect_meta(const BatchMember *__restrict__ mem, int count, DevMeta *out)
 {
     const int i = blockIdx.x;
     if (i >= count) return;

@@ -25,76 +25,11 @@
  */
 #pragma once
 #include "ppp_kernels.h"
-
-/* DevMeta.win_flag: why this pass must be repeated on the slab-index path (not an error of the input) */
-enum { WIN_FLAG_OVERFLOW = 1,  /* a window or its left side holds more points than the plan's LDS capacity      */
-       WIN_FLAG_REACH = 2,     /* a nearest-neighbour ball or a normal neighbourhood reaches beyond its window  */
-       WIN_FLAG_STALE = 4 };   /* bounds or slice walk of this pass differ from the plan the launches were sized by */
-__device__ inline void win_flag(DevMeta *m, int why) { atomicOr(&m->win_flag, why); }
-
-#define WIN_CLASSES 5
-#ifndef WIN_CNT_STRIDE
-#define WIN_CNT_STRIDE 1 /* ints between two windows' counters (a 128-byte line each, stride 32, changed nothing: 10 M points / 1024
-                            windows 98 .. 107 us packed, 116 padded -- the scatter's bill is its 16-byte stores, not the atomics) */
-#endif
-#ifndef WIN_EMAX
-#define WIN_EMAX 8 /* staged points per thread at most (capw <= WIN_EMAX * blockDim) */
-#endif
-#ifndef WIN_CE
-#define WIN_CE 4 /* left points (pairing candidates) per thread at most (cap_el <= WIN_CE * blockDim) */
-#endif
-
-struct WinArgs {
-    DevMeta *m;
-    DevParams P;
-    const float *X, *Y, *Z;
-    const int *idmap;
-    int n;
-    const float *plan_px; /* the plan's slice positions (host walk over the cached bounds) */
-    int S, sb, se, first_kept, nkept;
-    float pad, px0, inv_step, y0, yscale; /* bucket(y) = (int)((y - y0) * yscale), clamped to [0, NBc) */
-    float plan_mn[3], plan_mx[3];
-    int plan_nvalid;
-    int capw, cap_el, NB, NBc, stride, W_cap, node_cap;
-    int rec_lds; /* waypoint records a slice workgroup parks in its LDS (behind the pairing scratch); 0: in the waypoints' global slots (wps_rec) */
-    int g_scatter, g_slice, g_finish; /* workgroups of this workpiece per launch */
-    int finish; /* 0: a slice-range handle stops after HandEyeTransform (the list is compacted only) */
-    int *win_cnt;
-    float4 *win_pts;
-    MinMaxPart *win_part;
-    float *px, *lo, *hi;
-    float *node_x, *node_y, *node_z;
-    int *node_start, *node_cnt, *band_cnt;
-    int *wp_cnt, *wp_off, *tail;
-    float4 *wps_xyz, *wps_normal;
-    float4 *wps_rec; /* per waypoint slot, 4 x float4: what the searches of a waypoint leave for its pose (covariance sums, count, nearest point, sample) */
-    int *wps_nn;
-    float *wps_pre;
-    float *wp_pre, *wp_smooth, *wp_out, *out2;
-    int out2_cap;
-    DevMeta *meta_host; /* pinned host memory: the last workgroup of the finish launch leaves the meta block there (no copy command behind a pass) */
-    int *fin_ticket;    /* arrivals of that launch's workgroups (cleared by the last) */
-};
-
-__host__ __device__ inline size_t win_slice_lds_bytes(int capw, int cap_el, int NB)
-{
-    return (size_t)capw * 16 + (((size_t)NB + 1) * 4 + 15) / 16 * 16 + (size_t)cap_el * 16 + 16;
-}
+#include "ppp_window_decl.h"
 
 /* ------------------------------------------------------------------ */
 /* launch 1: bounds + window binning                                    */
 /* ------------------------------------------------------------------ */
-#ifndef WSC_T
-#define WSC_T 1024
-#endif
-/* STAGED (large clouds): the workgroup's kept points leave through LDS in window order, so that a wave stores runs of
-   consecutive 16-byte pieces instead of 64 pieces in 64 different lines.  With thousands of workgroups' partial lines in
-   flight the L2 no longer merges the pieces of a line before it evicts it: 10 M points wrote 229 MB for 107 MB of points
-   (2 M points: 42 for 21), against 1.09 x at 1 M points, where the plain form stays. */
-__host__ __device__ inline size_t win_scatter_lds_bytes(int S, int ppt, int threads, bool staged)
-{
-    return staged ? (size_t)12 * S + 16 + (size_t)18 * ppt * threads : (size_t)8 * S;
-}
 template <int PPT, bool STAGED>
 __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
 {
@@ -441,9 +376,6 @@ __device__ __forceinline__ int win_unit_class(int G, int round, int g)
     return round == 0 ? (g < 2 ? 1 : 3) : (round == 1 ? (g < 2 ? 0 : 4) : 2);
 }
 
-#ifndef WSL_T
-#define WSL_T 1024
-#endif
 /* diagnostic builds (tools/phase_costs.sh): the slice kernel leaves after phase WIN_STOP_AFTER, so that the difference of two
    builds' durations and instruction counters is that phase's bill.  `sink` keeps the phase's register results alive.  Never
    defined in the product. */
@@ -1095,9 +1027,7 @@ __device__ __forceinline__ void win_verify_body(const WinArgs &A)
 /* words of the meta block written by the finish launch: agent-scope (write-through) stores, so that the workgroup that publishes
    the block to the host (win_publish_meta) sees them without any workgroup paying a release fence -- on this device a fence at
    agent scope writes back the whole L2, once per workgroup that executes it (64 x 250 k points: the finish launch 25 -> 126 us) */
-#define WIN_FIN_GROUPS 32 /* first-level arrival counters of the finish launch (win_publish_meta) */
 #define META_PUT(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define WIN_S_MAX 8192 /* slices of a plan on this path (plane table and counters of the scatter, offsets of the finish live in LDS) */
 __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) int s_off[]; /* nkept + 1 offsets */
@@ -1367,7 +1297,6 @@ __global__ void __launch_bounds__(256) k_win_census(const float *__restrict__ X,
    from the record that kernel's last workgroup left (PlanAuto), so the host is not needed in between; the last workgroup here
    hands the counters, the plane table and the record to pinned host memory and clears the counters again -- no copy or fill
    command on the way (each costs the host 10-20 us on this runtime; a new cloud's plan was 150 us of which 30 us were kernels). */
-#define WIN_AUTO_SCAP 4096 /* slices the LDS counters of this form have room for */
 __global__ void __launch_bounds__(256) k_win_census_auto(const float *__restrict__ X, int n, const float *px, const PlanAuto *plan, float inv_step,
                                                          int *cnt, int *ticket, PlanAuto *plan_host, float *px_host, int *census_host)
 {

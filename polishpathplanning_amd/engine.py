@@ -89,7 +89,7 @@ def build(force=False):
     newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
     newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "ppp_hip.h")))
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j4", "-C", src_dir], stdout=subprocess.DEVNULL)  # the engine and the window kernels build side by side
     return LIB_PATH
 
 
