@@ -123,6 +123,18 @@ def test_point_order_changes_nothing_but_indices(engine_mod):
     assert np.abs(e1.waypoints() - e2.waypoints()).max() < 1e-5
 
 
+@pytest.mark.parametrize("axis", [0, 1])
+def test_scan_ordered_clouds(engine_mod, oracle_mod, axis):
+    """The synthetic clouds are randomly permuted (the reference's results depend on index order); a scanner delivers rows.  The same
+    plate sorted by x (rows along y: a binning workgroup's points fall into one or two windows) and by y: full parity with the oracle
+    on the window path, nothing handed back."""
+    pts, cfg = synth.make_config("small_40k")
+    pts = np.ascontiguousarray(pts[np.argsort(pts[:, axis], kind="stable")])
+    e, o = run_pair(engine_mod, oracle_mod, pts, tool_radius=cfg["tool_radius"])
+    assert_full_parity(engine_mod, e, o)
+    assert e.fast_path()
+
+
 def test_stride_32_pointxyzrgb_layout(engine_mod):
     pts, cfg = synth.make_config("tiny_5k")
     aos = np.zeros((len(pts), 8), np.float32)  # pcl::PointXYZRGB: xyz + pad, rgba + pad
