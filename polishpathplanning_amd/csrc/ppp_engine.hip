@@ -476,7 +476,7 @@ constexpr size_t PIN_REC0 = 0, PIN_REC1 = 64, PIN_PX = 128, PIN_CENSUS = PIN_PX 
    waves shared between them (measured, 64 x 250 k points: 256 threads 0.42 ms, 320 .. 512 threads 0.58 .. 0.64 ms). */
 size_t win_slice_lds_for(const ppp_handle h, int NBc)
 {   /* (the checking workgroup of the launch keeps the walk and its scratch there) */
-    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, WIN_CLASSES * NBc) + (size_t)64 * (size_t)h->win_rec_lds, sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
+    return std::max(win_slice_lds_bytes(h->win_capw, h->win_cap_el, WIN_CLASSES * NBc), sizeof(float) * ((size_t)h->S_cap + 2048) + 64);
 }
 /* several workgroups per CU, at once or one after the other? */
 bool win_throughput_launch(const ppp_handle h, long long wgs) { return wgs > (long long)h->num_cus; }
@@ -597,7 +597,6 @@ int plan_window(ppp_handle h, int S, double per)
     const int NB = WIN_CLASSES * NBc;
     h->win_el_expect = max_el;
     h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc;
-    h->win_rec_lds = 0; /* (decided below, and so that it never changes how many workgroups share a CU) */
     int T = win_pick_threads(h, std::max(1, h->se - h->sb));
     if (!T) return PPP_OK;
     /* points per thread of the binning launch: 8 from 1.2 million points on (16 was slower at 10 M points: 107 against 100 us) */
@@ -619,16 +618,13 @@ int plan_window(ppp_handle h, int S, double per)
     if (h->win_staged) h->win_gs = std::min(h->win_gs, std::max(1, h->num_cus)); /* the staged form loops over its chunks: a workgroup per CU (its LDS admits no second) */
     h->win_pad = pad; h->win_capw = capw; h->win_cap_el = cap_el; h->win_NB = NB; h->win_NBc = NBc; h->win_threads = T;
     h->win_stride = std::max(1, (int)per);
-    {   /* the waypoints' records between their searches and their pose (64 bytes each): in the workgroup's LDS where that costs no
-           workgroup per CU, else through their global slots (10 M points / 1024 slices: the window alone fills the CU's LDS) */
-        h->win_rec_lds = 0;
-        const size_t rec = (size_t)64 * (size_t)h->win_stride, cu = (size_t)h->max_lds;
-        const size_t a = win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * NBc) + 1024, b = win_slice_lds_bytes(capw, cap_el, WIN_CLASSES * h->win_NBc_thr) + 1024;
-        if (a + rec <= budget && cu / (a + rec) == cu / a && cu / (b + rec) == cu / b) h->win_rec_lds = h->win_stride;
+    /* the waypoints' records between their searches and their pose (13 words each) wait in the pairing scratch the knots leave free
+       -- seven word rows in the 4 bytes per left point of `cz`, six in the candidate histogram's -- when a slice's waypoints fit a row
+       (every BASELINE configuration: a left point per 1.1 mm of y, a waypoint per 7); else in global slots */
+    h->win_rec_lds = (h->win_stride <= cap_el / 7) ? cap_el / 7 : 0;
 #ifdef WIN_REC_GLOBAL /* (A/B builds) */
-        h->win_rec_lds = 0;
+    h->win_rec_lds = 0;
 #endif
-    }
     h->win_first_kept = h->P.drop_ends ? 1 : 0;
     h->win_nkept = std::max(0, h->P.drop_ends ? S - 2 : S);
     h->win_px0 = px[0];

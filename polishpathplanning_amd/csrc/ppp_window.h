@@ -404,7 +404,6 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     u64 *ckeys = (u64 *)(cz + cap_el);        /* candidates sorted by y; later the knots as (y, z) pairs */
     int *hc = (int *)(ckeys + cap_el);        /* histogram of that sort, then the kept candidates */
     float2 *knot = (float2 *)ckeys;
-    float4 *rec_lds = (float4 *)(s_raw + win_slice_lds_bytes(capw, cap_el, NB)); /* A.rec_lds records of 64 bytes, when the plan gave them room */
 
     const int s = A.sb + bx;
     if (s >= A.se) return;
@@ -797,6 +796,20 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
 #pragma unroll
         for (int d = 0; d < 6; ++d) A.wps_pre[6 * slot + d] = wp[d];
     };
+    /* Where a waypoint's record waits between its searches and its pose: in the pairing scratch that the knots do not use (cz and
+       the candidate histogram, 4 bytes per left point each: word w of waypoint t at [w][t], seven words in the one, six in the other),
+       when the plan found room there (A.rec_lds = waypoints per word row); else in the waypoint's global slot. */
+    float *rec_a = cz, *rec_b = (float *)hc;
+    const int rcap = A.rec_lds;
+    float *rec_g = (float *)(A.wps_rec + 4 * (size_t)k * A.stride);
+    auto rec_put = [&](int t, int w, float v) {
+        if (rcap) { if (w < 7) rec_a[w * rcap + t] = v; else rec_b[(w - 7) * rcap + t] = v; }
+        else rec_g[16 * (size_t)t + w] = v;
+    };
+    auto rec_get = [&](int t, int w) -> float {
+        if (rcap) return w < 7 ? rec_a[w * rcap + t] : rec_b[(w - 7) * rcap + t];
+        return rec_g[16 * (size_t)t + w];
+    };
     for (int rd = 0; rd < rounds; ++rd) {
         const int lt = tid >> gshift;
         const int t = rd * per_round + lt;
@@ -824,8 +837,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         WIN_STOP(6, __float_as_int(q.z) ^ iv);
         /* -- kdtree.nearestKSearch(q, 1) (:189): inner classes first, the outer ones are closed by their x gap almost always -- */
         float best = P.nn_hint2;
-        int bidx = 0x7fffffff;
-        float4 bp = make_float4(NAN, NAN, NAN, 0.f);
+        int bidx = 0x7fffffff, bpos = 0; /* cloud index (the tie rule) and place in the staged window of the best candidate so far */
         for (int pass = 0; pass < 2; ++pass) {
             for (int round = 0; round <= plane_round; ++round) {
                 if (round == plane_round && !has_plane_class) break;
@@ -837,27 +849,27 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
                     const float gap = c == 0 ? q.x - blo : (c == 4 ? bhi - q.x : 0.f);
                     if (!(gap > 0.f && gap * gap > best)) {
                         const int p0 = V.lower_bound(c, q.y);
-                        win_walk(V, c, p0, up, [&](const float4 &kk, int) {
+                        win_walk(V, c, p0, up, [&](const float4 &kk, int at) {
                             const float dyy = q.y - kk.y;
                             if (dyy * dyy > best) return false;
                             const float d = dist2_flann(q.x, q.y, q.z, kk.x, kk.y, kk.z);
                             const int id = idx_of(kk);
-                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bp = kk; }
+                            if (d < best || (d == best && id < bidx)) { best = d; bidx = id; bpos = at; }
                             return true;
                         });
                     }
                 }
                 for (int o = G >> 1; o > 0; o >>= 1) { /* minimum of the waypoint's lanes on (distance, cloud index) */
                     const float od = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(bidx, o, 64);
-                    const float ox = __shfl_xor(bp.x, o, 64), oy = __shfl_xor(bp.y, o, 64), oz = __shfl_xor(bp.z, o, 64), ow = __shfl_xor(bp.w, o, 64);
-                    if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bp = make_float4(ox, oy, oz, ow); }
+                    const int oi = __shfl_xor(bidx, o, 64), op = __shfl_xor(bpos, o, 64);
+                    if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; bpos = op; }
                 }
             }
             if (__all(bidx != 0x7fffffff || !on)) break;
             best = INFINITY; /* nothing within the hint: the same search without a bound */
         }
         const bool found = on && bidx != 0x7fffffff;
+        const float4 bp = found ? pts[bpos] : make_float4(NAN, NAN, NAN, 0.f); /* (the lanes passed its place around, not the point) */
         STAMP(6, 7); /* nearest point */
         WIN_STOP(7, bidx ^ __float_as_int(bp.z));
         /* the window holds every point within `pad` of the plane: the answers are the whole cloud's as long as the ball that
@@ -927,12 +939,13 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
 #ifdef WIN_SPARSE_POSE
         if (act && g == 0) pose_and_store(acc, count, found, bidx, c0, q, t);
 #else
-        if (act && g == 0) {
-            const float4 v0 = make_float4(acc[0], acc[1], acc[2], acc[3]), v1 = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            const float4 v2 = make_float4(acc[8], __int_as_float(found ? count : -1), c0.x, c0.y);
-            const float4 v3 = make_float4(c0.z, q.y, q.z, __int_as_float(found ? bidx : -1));
-            if (A.rec_lds) { float4 *rec = rec_lds + 4 * t; rec[0] = v0; rec[1] = v1; rec[2] = v2; rec[3] = v3; }
-            else { float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t); rec[0] = v0; rec[1] = v1; rec[2] = v2; rec[3] = v3; }
+        if (act && g == 0) { /* 13 words: the nine sums, the count (-1: no nearest point), the nearest point's place in the window, the sample */
+#pragma unroll
+            for (int w = 0; w < 9; ++w) rec_put(t, w, acc[w]);
+            rec_put(t, 9, __int_as_float(found ? count : -1));
+            rec_put(t, 10, __int_as_float(bpos));
+            rec_put(t, 11, q.y);
+            rec_put(t, 12, q.z);
         }
 #endif
     }
@@ -940,12 +953,13 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     __syncthreads();
     STAMP(6, 9); /* records parked */
     for (int t = tid; t < cnt; t += T) {
-        float4 r0, r1, r2v, r3;
-        if (A.rec_lds) { const float4 *rec = rec_lds + 4 * t; r0 = rec[0]; r1 = rec[1]; r2v = rec[2]; r3 = rec[3]; }
-        else { const float4 *rec = A.wps_rec + 4 * ((size_t)k * A.stride + (size_t)t); r0 = rec[0]; r1 = rec[1]; r2v = rec[2]; r3 = rec[3]; }
-        float acc[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2v.x};
-        const int count = __float_as_int(r2v.y);
-        pose_and_store(acc, count, count >= 0, __float_as_int(r3.w), make_float4(r2v.z, r2v.w, r3.x, 0.f), make_float4((float)(double)Px, r3.y, r3.z, 1.f), t);
+        float acc[9];
+#pragma unroll
+        for (int w = 0; w < 9; ++w) acc[w] = rec_get(t, w);
+        const int count = __float_as_int(rec_get(t, 9));
+        const bool found = count >= 0;
+        const float4 c0 = found ? pts[__float_as_int(rec_get(t, 10))] : make_float4(NAN, NAN, NAN, 0.f);
+        pose_and_store(acc, count, found, idx_of(c0), c0, make_float4((float)(double)Px, rec_get(t, 11), rec_get(t, 12), 1.f), t);
     }
 #endif
     STAMP(6, 10); /* eigen33, frame, Euler, hand-eye, stores: one thread per waypoint */

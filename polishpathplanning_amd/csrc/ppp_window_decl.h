@@ -37,7 +37,7 @@ struct WinArgs {
     float plan_mn[3], plan_mx[3];
     int plan_nvalid;
     int capw, cap_el, NB, NBc, stride, W_cap, node_cap;
-    int rec_lds; /* waypoint records a slice workgroup parks in its LDS (behind the pairing scratch); 0: in the waypoints' global slots (wps_rec) */
+    int rec_lds; /* waypoint records in the slice workgroup's LDS (the pairing scratch the knots leave free): waypoints per word row; 0: in the waypoints' global slots (wps_rec) */
     int g_scatter, g_slice, g_finish; /* workgroups of this workpiece per launch */
     int finish; /* 0: a slice-range handle stops after HandEyeTransform (the list is compacted only) */
     int *win_cnt;
