@@ -277,7 +277,7 @@ __device__ __forceinline__ void win_scatter_staged_loop(const WinArgs &A, const 
 /* ------------------------------------------------------------------ */
 struct WinView {
     const float4 *pts;
-    const int *tab; /* tab[b] = end of bucket b */
+    const int *tab; /* tab[b] = first place of bucket b (tab[NB] = the window's population) */
     int NBc;
     float y0, yscale;
     const int *cs; /* LDS: class c = pts[cs[c], cs[c + 1]) (a private array indexed by a run-time class would live in scratch memory) */
@@ -291,8 +291,8 @@ struct WinView {
     __device__ inline int lower_bound(int c, float qy) const
     {
         const int b = c * NBc + ybucket(qy);
-        int lo = b ? tab[b - 1] : 0;
-        int hi = tab[b];
+        int lo = tab[b];
+        int hi = tab[b + 1];
         while (hi - lo > 4) { const int mid = (lo + hi) >> 1; if (pts[mid].y < qy) lo = mid + 1; else hi = mid; } /* (dense windows: buckets of a dozen points) */
         while (lo < hi && pts[lo].y < qy) ++lo;
         return lo;
@@ -453,8 +453,8 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
             }
             int q = (int)((p.y - A.y0) * A.yscale);
             q = q < 0 ? 0 : (q >= NBc ? NBc - 1 : q);
-            pb[e] = c * NBc + q;
-            atomicAdd(&tab[pb[e]], 1);
+            const int b = c * NBc + q;
+            pb[e] = b | (atomicAdd(&tab[b], 1) << 15); /* bucket (< 5 x 4096) and the point's arrival number in it: ONE LDS atomic per point */
         }
     }
     __syncthreads();
@@ -466,14 +466,15 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         int total;
         int pre = block_exscan_w(sum, s_scr, &total);
         for (int q = 0; q < per; ++q) if (b0 + q < NB) { const int c = tab[b0 + q]; tab[b0 + q] = pre; pre += c; }
+        if (tid == 0) tab[NB] = total;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) pts[atomicAdd(&tab[pb[e]], 1)] = pr[e];
+    for (int e = 0; e < WIN_EMAX; ++e) if (pb[e] >= 0) { const int b = pb[e] & 0x7fff; pts[tab[b] + (pb[e] >> 15)] = pr[e]; pb[e] = b; }
     __syncthreads();
     STAMP(6, 1); /* histogram, scan, placement */
     WIN_STOP(1, pb[0] ^ pb[WIN_EMAX - 1]);
-    /* tab[b] is now the END of bucket b.  Inside a bucket (a point or two, a dozen in the densest windows) the points stand in
+    /* tab[b] is the first place of bucket b, tab[b + 1] its end.  Inside a bucket (a point or two, a dozen in the densest windows) the points stand in
        arrival order: every point counts the members of its bucket that precede it on (y, cloud index) -- independent reads, no
        chain of dependent moves as in an insertion sort -- and takes that place. */
 #pragma unroll
@@ -481,7 +482,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         const int b = pb[e];
         pb[e] = -1;
         if (b >= 0) {
-            const int s0 = b ? tab[b - 1] : 0, s1 = tab[b];
+            const int s0 = tab[b], s1 = tab[b + 1];
             if (s1 - s0 > 1) {
                 const float my = pr[e].y;
                 const int mi = idx_of(pr[e]);
@@ -501,7 +502,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     __syncthreads();
     STAMP(6, 2); /* buckets finished */
     WIN_STOP(2, pb[0] ^ __float_as_int(pts[tid % 64].y));
-    if (tid < WIN_CLASSES) s_cs[tid + 1] = tab[(tid + 1) * NBc - 1];
+    if (tid < WIN_CLASSES) s_cs[tid + 1] = tab[(tid + 1) * NBc];
     __syncthreads();
     WinView V;
     V.pts = pts; V.tab = tab; V.NBc = NBc; V.y0 = A.y0; V.yscale = A.yscale; V.cs = s_cs;
@@ -641,7 +642,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
     STAMP(6, 3); /* pairing: two nearest-neighbour queries per left point + lerp */
     WIN_STOP(3, (int)kr[0] ^ kb[0] ^ kb[CE - 1] ^ (int)(kr[CE - 1] >> 32));
 #pragma unroll
-    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) atomicAdd(&hc[kb[e]], 1);
+    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) kb[e] |= atomicAdd(&hc[kb[e]], 1) << 13; /* bucket (< 4096) and arrival number in it: one LDS atomic per candidate */
     __syncthreads();
     {
         const int per = (NBcand + T - 1) / T;
@@ -651,17 +652,18 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         int total;
         int pre = block_exscan_w(sum, s_scr, &total);
         for (int q = 0; q < per; ++q) if (b0 + q < NBcand) { const int c = hc[b0 + q]; hc[b0 + q] = pre; pre += c; }
+        if (tid == 0) hc[NBcand] = total;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) ckeys[atomicAdd(&hc[kb[e]], 1)] = kr[e];
+    for (int e = 0; e < CE; ++e) if (kb[e] >= 0) { const int b = kb[e] & 0x1fff; ckeys[hc[b] + (kb[e] >> 13)] = kr[e]; kb[e] = b; }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < CE; ++e) { /* buckets finished by rank, as above (the keys are all different: they carry the candidate's number) */
         const int b = kb[e];
         kb[e] = -1;
         if (b >= 0) {
-            const int s0 = b ? hc[b - 1] : 0, s1 = hc[b];
+            const int s0 = hc[b], s1 = hc[b + 1];
             if (s1 - s0 > 1) {
                 int rank = 0;
                 for (int q = s0; q < s1; ++q) rank += ckeys[q] < kr[e] ? 1 : 0;
