@@ -262,18 +262,21 @@ __device__ inline void block_sort_regs(u64 (&k)[E], u64 *lds /* 256*E keys of sc
     const int t = threadIdx.x;
     const int base_i = t * E;
     constexpr int P = 256 * E;
+    const bool live = t < 256; /* a wider workgroup (k_slice's 512 threads): its other waves hold padding, keep the barriers and stay out of the scratch */
     sort_reg_phase<E, 2>(k, base_i);
     for (int size = 2 * E; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride >= E; stride >>= 1) {
             if (stride >= 64 * E) {
                 __syncthreads();
+                if (live) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) lds[base_i + r] = k[r];
+                    for (int r = 0; r < E; ++r) lds[base_i + r] = k[r];
+                }
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < E; ++r) {
                     const int i = base_i + r;
-                    u64 o = lds[i ^ stride];
+                    u64 o = live ? lds[i ^ stride] : ~0ull;
                     const bool keep_min = (((i & stride) == 0) == ((i & size) == 0));
                     u64 a = k[r];
                     k[r] = keep_min ? (a < o ? a : o) : (a > o ? a : o);
@@ -294,7 +297,7 @@ __device__ inline void block_sort_regs(u64 (&k)[E], u64 *lds /* 256*E keys of sc
     }
 }
 
-/* Sorts keys[0..n) (LDS, n <= 4096) ascending with a 256-thread workgroup; on return the
+/* Sorts keys[0..n) (LDS, n <= 4096) ascending with the first 256 threads of a workgroup (wider ones keep the barriers); on return the
    keys are back in LDS.  Picks the smallest register tile that covers n. */
 template <int E>
 __device__ inline void block_sort_lds_e(u64 *keys, int n)
@@ -305,8 +308,10 @@ __device__ inline void block_sort_lds_e(u64 *keys, int n)
     for (int r = 0; r < E; ++r) k[r] = (base_i + r) < n ? keys[base_i + r] : ~0ull;
     block_sort_regs<E>(k, keys);
     __syncthreads();
+    if (threadIdx.x < 256) {
 #pragma unroll
-    for (int r = 0; r < E; ++r) keys[base_i + r] = k[r]; /* slots >= n hold the ~0 padding */
+        for (int r = 0; r < E; ++r) keys[base_i + r] = k[r]; /* slots >= n hold the ~0 padding */
+    }
     __syncthreads();
 }
 /* keys must have room for 256 * E entries, E = max(1, next_pow2(n) / 256) */

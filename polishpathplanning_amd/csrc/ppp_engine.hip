@@ -1864,7 +1864,7 @@ int ppp_gen_path_async(ppp_handle h)
                    h->lo.p, h->hi.p, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p, h->node_cnt.p,
                    h->band_cnt.p, h->big_slices.p, h->arena.p, (unsigned long long)h->arena.cap, h->P.trim, h->P.path_resolution, h->W_cap, cnt_out);
     } else {
-        LAUNCH(h, "k_slice", k_slice, h->S_cap, 256, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
+        LAUNCH(h, "k_slice", k_slice, h->S_cap, K_SLICE_T, slice_lds_bytes(h->capb), h->sorted4.p, h->slab_start.p, h->meta.p, h->px.p,
                h->lo.p, h->hi.p, h->P.pairing, h->capb, h->node_x.p, h->node_y.p, h->node_z.p, h->node_cap, h->node_start.p,
                h->node_cnt.p, h->band_cnt.p, h->big_slices.p);
         if (h->big_path)

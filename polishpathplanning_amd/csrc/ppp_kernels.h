@@ -763,9 +763,27 @@ __device__ inline int band_gather_sorted(const SliceLds &L, int capb, const floa
     __syncthreads();
     n = *s_n;
     if (n > capb) return -1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) L.keys[i] = ((u64)(u32)idx_of(L.a4[i]) << 32) | (u32)i;
+    /* ascending cloud index: a bucket sort on the index (the candidate-z area is free here and takes the histogram) -- the 64-bit
+       bitonic network this replaces was ~60 us of the kernel for a 1300-point band */
+    __shared__ int s_imax, s_bscr[17];
+    if (threadIdx.x == 0) s_imax = 0;
     __syncthreads();
-    block_sort_lds(L.keys, n);
+    {
+        int mx = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) mx = max(mx, idx_of(L.a4[i]));
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_imax, mx);
+    }
+    __syncthreads();
+    {
+        int NB = next_pow2(max(n, 64));
+        while (NB >= capb) NB >>= 1;
+        const u64 span = (u64)(u32)s_imax + 1ull;
+        auto gen = [&](int i) { return ((u64)(u32)idx_of(L.a4[i]) << 32) | (u64)(u32)i; };
+        auto bucket = [&](u64 k) { return (int)(((k >> 32) * (u64)NB) / span); };
+        auto less = [&](u64 a, u64 b) { return a < b; };
+        block_bucket_sort(L.keys, n, (int *)L.candz, NB, s_bscr, gen, bucket, less);
+    }
     return n;
 }
 
@@ -865,30 +883,33 @@ __device__ inline int insert_point_lds(const SliceLds &L, int n, float Px, int p
         __syncthreads();
         u16 *pairL = (u16 *)L.candz;        /* left_pair  (as El positions) */
         u16 *pairR = pairL + nEl;            /* right_pair (as Er positions); |right| <= nEl */
-        u64 *flags = L.keys;                 /* bit flags: [0..) El, [(nEl+63)/64 ..) Er */
-        const int wl = (nEl + 63) >> 6, wr = (nEr + 63) >> 6;
-        for (int i = threadIdx.x; i < wl + wr; i += blockDim.x) flags[i] = 0;
+        /* the walk's records made beforehand, in parallel -- step i: j*(i) | k*(j*) << 16 -- and the two flag arrays as bytes: a step
+           is one record (requested a step ahead) and three flag bytes instead of a chain of table look-ups and 64-bit
+           read-modify-writes (1 M points / 256 slices: 650 of them a slice, the kernel 409 -> see DESIGN.md A.2) */
+        u32 *trip = (u32 *)L.keys;           /* keys: 8 bytes per band point; the first half */
+        unsigned char *lf = (unsigned char *)(trip + nEl), *rf = lf + nEl; /* El_flag / Er_flag: nEl + nEr <= n bytes of the rest */
+        for (int i = threadIdx.x; i < nEl; i += blockDim.x) { const int j = L.rstar[i]; trip[i] = (u32)j | ((u32)L.lstar[j] << 16); }
+        for (int i = threadIdx.x; i < (n + 3) / 4; i += blockDim.x) ((u32 *)lf)[i] = 0u;
         __syncthreads();
         if (threadIdx.x == 0) {
             int nl = 0, nr = 0;
+            u32 nx = trip[0];
             for (int i = 0; i < nEl; ++i) {
-                if ((flags[i >> 6] >> (i & 63)) & 1) continue;
-                int j = L.rstar[i];
-                if ((flags[wl + (j >> 6)] >> (j & 63)) & 1) continue;
-                pairR[nr++] = (u16)j;
-                flags[wl + (j >> 6)] |= 1ull << (j & 63);
-                int k = L.lstar[j];
-                if (!((flags[k >> 6] >> (k & 63)) & 1)) {
-                    pairL[nl++] = (u16)k;
-                    flags[k >> 6] |= 1ull << (k & 63);
-                }
+                const u32 tr = nx;
+                if (i + 1 < nEl) nx = trip[i + 1];
+                const int j = (int)(tr & 0xffffu), k = (int)(tr >> 16);
+                const int fi = lf[i], fj = rf[j], fk = lf[k];
+                if (fi) continue;                   /* if (El_flag[i] == 0) */
+                if (fj) continue;                   /* Er_flag[compare.begin()->second] != 0: continue */
+                pairR[nr++] = (u16)j; rf[j] = 1;
+                if (!fk) { pairL[nl++] = (u16)k; lf[k] = 1; }
             }
             s_np = nl; /* the reference loops i < left_pair.size() (Path_Generation.cpp:189) */
         }
         __syncthreads();
         ncand = s_np;
         /* read pairs to registers, then overwrite the scratch with keys / z */
-        float ys[16], zs[16]; /* ncand <= capb <= 4096, blockDim 256 -> <= 16 per thread */
+        float ys[16], zs[16]; /* ncand <= capb <= 4096, blockDim >= 256 (k_insert_api's) -> <= 16 per thread */
         int cntl = 0;
         for (int i = threadIdx.x; i < ncand; i += blockDim.x) {
             const float4 R = L.a4[L.erpos[pairR[i]]];
@@ -908,8 +929,27 @@ __device__ inline int insert_point_lds(const SliceLds &L, int n, float Px, int p
         }
     }
     __syncthreads();
-    /* --- std::map semantics: ascending key, last writer wins --- */
-    block_sort_lds(L.keys, ncand);
+    /* --- std::map semantics: ascending key, last writer wins: a bucket sort over the candidates' own y range (keys made once, held in
+           registers between its two passes; the side tables are used up and take the histogram) --- */
+    {
+        __shared__ u32 s_ylo, s_yhi;
+        if (threadIdx.x == 0) { s_ylo = 0xffffffffu; s_yhi = 0u; }
+        __syncthreads();
+        u32 lo = 0xffffffffu, hi = 0u;
+        for (int i = threadIdx.x; i < ncand; i += blockDim.x) { const u32 y = (u32)(L.keys[i] >> 32); lo = min(lo, y); hi = max(hi, y); }
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (u32)__shfl_xor((int)lo, o, 64)); hi = max(hi, (u32)__shfl_xor((int)hi, o, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_ylo, lo); atomicMax(&s_yhi, hi); }
+        __syncthreads();
+        int NB = next_pow2(max(ncand, 64));
+        const int room = (int)(((char *)(L.lstar) - (char *)(L.elpos)) / 3); /* the four u16 side tables = 2 ints per band point: lstar - elpos is three of them, 6 bytes a point */
+        while (NB >= room) NB >>= 1;
+        const float y0 = ord2f(s_ylo), y1 = ord2f(s_yhi);
+        const float scale = (ncand > 0 && y1 > y0) ? (float)NB / (y1 - y0) : 0.f;
+        auto gen = [&](int i) { return L.keys[i]; };
+        auto bucket = [&](u64 k) { const int q = (int)((ord2f((u32)(k >> 32)) - y0) * scale); return q < 0 ? 0 : (q >= NB ? NB - 1 : q); };
+        auto less = [&](u64 a, u64 b) { return a < b; };
+        block_bucket_sort_cached<16>(L.keys, ncand, (int *)L.elpos, NB, s_scr, gen, bucket, less);
+    }
     return ncand;
 }
 
@@ -941,7 +981,10 @@ __device__ inline int flatten_nodes(const SliceLds &L, int ncand, float *out_y, 
     return s_m;
 }
 
-PPP_KERNEL void __launch_bounds__(256) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
+#ifndef K_SLICE_T
+#define K_SLICE_T 512 /* threads of the generic insert_point kernel (brute flavour, API mirror): 1 M points / 256 slices 663 (256 threads) -> 409 us; 1024: 404 */
+#endif
+PPP_KERNEL void __launch_bounds__(K_SLICE_T) k_slice(const float4 *__restrict__ sorted4, const int *__restrict__ slab_start,
                                                DevMeta *m, const float *__restrict__ px, const float *__restrict__ lo,
                                                const float *__restrict__ hi, int pairing, int capb, float *node_x, float *node_y,
                                                float *node_z, int node_cap, int *node_start, int *node_cnt, int *band_cnt, int *big_list)
