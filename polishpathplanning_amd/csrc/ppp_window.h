@@ -54,6 +54,8 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
         DevMeta *m = A.m;
         m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
         m->node_cursor = 0; m->smooth_done = -1; m->emit_ticket = 0; m->big_slabs = 0; m->big_slices = 0; m->arena_cursor = 0; m->win_flag = 0;
+        /* (the finish launch's arrival counters: its last workgroup clears them; a pass that was cut short must not leave them counting) */
+        if (A.fin_ticket) for (int q = 0; q <= WIN_FIN_GROUPS; ++q) A.fin_ticket[q] = 0;
     }
     __syncthreads();
     STAMP(7, 0); /* loads issued, plane table staged */
@@ -181,6 +183,8 @@ __device__ __forceinline__ void win_scatter_staged_loop(const WinArgs &A, const 
         DevMeta *m = A.m;
         m->W = 0; m->err = 0; m->err_slice = 0x7fffffff; m->sweeps = 0; m->any_short = 0; m->rpy_oob = 0;
         m->node_cursor = 0; m->smooth_done = -1; m->emit_ticket = 0; m->big_slabs = 0; m->big_slices = 0; m->arena_cursor = 0; m->win_flag = 0;
+        /* (the finish launch's arrival counters: its last workgroup clears them; a pass that was cut short must not leave them counting) */
+        if (A.fin_ticket) for (int q = 0; q <= WIN_FIN_GROUPS; ++q) A.fin_ticket[q] = 0;
     }
     float4 p[PPT], pn[PPT];
     auto request = [&](int chunk, float4 *dst) {
