@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -47,11 +48,76 @@ typedef std::map<double, std::vector<double>> MAP; /* Path_Generate_Algorithm.h:
 
 namespace ppp {
 
+/* Engine handles handed back by the planners of this process, for the next planner to take.  The reference builds a planner
+   per workpiece from the file name (path_slicing_alg.cpp:3-30, Path_Generate.cpp:8-33); a handle is a HIP stream plus the
+   engine's device buffers and its plan, so the second workpiece of a process pays neither ppp_create nor -- for a cloud of the
+   same size and parameters -- the window census (ppp_set_plan_reuse).  A taken handle is given its cloud and parameters
+   anew by open(); nothing of the earlier workpiece is readable through it.  PPP_NO_HANDLE_POOL=1 in the environment (or
+   HandlePool::keep(0)) switches it off.  Handles still pooled when the process ends go with the HIP runtime. */
+class HandlePool {
+public:
+    static ppp_handle take(int device)
+    {
+        std::lock_guard<std::mutex> g(mu());
+        std::vector<std::pair<int, ppp_handle>> &f = free_list();
+        for (size_t i = f.size(); i-- > 0;)
+            if (f[i].first == device) {
+                ppp_handle h = f[i].second;
+                f.erase(f.begin() + (long)i);
+                ++reused();
+                return h;
+            }
+        return nullptr;
+    }
+    static void give(int device, ppp_handle h)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu());
+            if (free_list().size() < limit()) {
+                free_list().push_back(std::make_pair(device, h));
+                return;
+            }
+        }
+        ppp_destroy(h);
+    }
+    /* how many handles may wait in the pool (default 4; 0 = every planner creates and destroys its own) */
+    static void keep(size_t n)
+    {
+        std::vector<ppp_handle> out;
+        {
+            std::lock_guard<std::mutex> g(mu());
+            limit() = n;
+            while (free_list().size() > n) { out.push_back(free_list().back().second); free_list().pop_back(); }
+        }
+        for (ppp_handle h : out) ppp_destroy(h);
+    }
+    static size_t taken_from_pool()
+    {
+        std::lock_guard<std::mutex> g(mu());
+        return reused();
+    }
+
+private:
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::vector<std::pair<int, ppp_handle>> &free_list() { static std::vector<std::pair<int, ppp_handle>> f; return f; }
+    static size_t &reused() { static size_t r = 0; return r; }
+    static size_t &limit()
+    {
+        static size_t n = [] { const char *e = std::getenv("PPP_NO_HANDLE_POOL"); return (e && *e && *e != '0') ? 0 : 4; }();
+        return n;
+    }
+};
+
 /* One engine handle + the state every planner class of the reference keeps. */
 class Planner {
 public:
     Planner() { ppp_default_config(&cfg_); }
-    ~Planner() { if (h_) ppp_destroy(h_); }
+    ~Planner()
+    {
+        if (!h_) return;
+        /* every method of the classes returns with its results on the host, so the stream is idle here */
+        HandlePool::give(dev_, h_);
+    }
     Planner(const Planner &) = delete;
     Planner &operator=(const Planner &) = delete;
 
@@ -62,10 +128,19 @@ public:
     /* constructor body of the reference classes: load, recolour (no-op here), scale, keep */
     bool open(const std::string &cloud_name)
     {
-        if (!h_ && ppp_create(device_from_env(), &h_) != PPP_OK) {
-            std::fprintf(stderr, "ppp: no MI355X device available (the engine has no CPU fallback)\n");
-            h_ = nullptr;
-            return false;
+        if (!h_) {
+            dev_ = device_from_env();
+            h_ = HandlePool::take(dev_);
+            if (h_) {
+                /* switches a caller may have thrown through handle() on the earlier workpiece: back to the defaults */
+                ppp_set_fast_path(h_, 1);
+                ppp_enable_timing(h_, 0);
+                ppp_set_plan_reuse(h_, 1);
+            } else if (ppp_create(dev_, &h_) != PPP_OK) {
+                std::fprintf(stderr, "ppp: no MI355X device available (the engine has no CPU fallback)\n");
+                h_ = nullptr;
+                return false;
+            }
         }
         if (!apply_params()) return false;
         float *xyz = nullptr;
@@ -300,6 +375,7 @@ public:
 
 private:
     ppp_handle h_ = nullptr;
+    int dev_ = 0;
     ppp_config cfg_;
     bool loaded_ = false;
     std::vector<float> normals_;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cerrno>
+#include <charconv>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -103,6 +104,52 @@ std::vector<unsigned char> lzf_compress(const unsigned char *in, size_t n)
     flush_literals(n);
     return out;
 }
+/* A decimal token to float, correctly rounded (= strtof, which is what `istringstream >> float` calls).  Fast path: up to 19
+   significant digits w and a decimal exponent with |e| <= 22 make w and 10^|e| exact doubles, so d = w * 10^e (or w / 10^-e) is
+   the correctly rounded double; its cast to float is the correctly rounded float unless d sits within an ulp of the midpoint of
+   two floats (the 29 bits a float drops read 0x0fffffff .. 0x10000001) -- then, and for anything that is not a plain decimal
+   in the comfortable range, strtof decides.  (std::from_chars of this compiler's library takes 48 ns a number: it wraps strtod.) */
+static float parse_float_token(const char *t0, const char *lim, const char **tok_end)
+{
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *q = t0;
+    bool neg = false;
+    if (q < lim && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    uint64_t w = 0;
+    int digits = 0, e10 = 0;
+    bool any = false, plain = true;
+    while (q < lim && (unsigned)(*q - '0') <= 9u) { any = true; if (w || *q != '0') { if (digits < 19) { w = w * 10 + (uint64_t)(*q - '0'); ++digits; } else plain = false; } ++q; }
+    if (q < lim && *q == '.') {
+        ++q;
+        while (q < lim && (unsigned)(*q - '0') <= 9u) { any = true; if (w || *q != '0') { if (digits < 19) { w = w * 10 + (uint64_t)(*q - '0'); ++digits; --e10; } else plain = false; } else --e10; ++q; }
+    }
+    if (any && q < lim && (*q == 'e' || *q == 'E')) {
+        const char *r = q + 1;
+        bool eneg = false;
+        if (r < lim && (*r == '-' || *r == '+')) { eneg = *r == '-'; ++r; }
+        int ev = 0, ed = 0;
+        while (r < lim && (unsigned)(*r - '0') <= 9u) { if (ed < 6) ev = ev * 10 + (*r - '0'); ++ed; ++r; }
+        if (ed == 0 || ed >= 6) plain = false; else { e10 += eneg ? -ev : ev; q = r; }
+    }
+    const bool at_end = q >= lim || (unsigned char)*q <= ' '; /* the token is over where the number is */
+    if (at_end) *tok_end = q;
+    else { while (q < lim && (unsigned char)*q > ' ') ++q; *tok_end = q; plain = false; }
+    if (any && plain && w < ((uint64_t)1 << 53) && e10 >= -22 && e10 <= 22) {
+        if (w == 0) return neg ? -0.f : 0.f;
+        const double d = e10 >= 0 ? (double)w * P10[e10] : (double)w / P10[-e10];
+        if (d > 1e-30 && d < 1e30) {
+            uint64_t bits;
+            memcpy(&bits, &d, 8);
+            const uint32_t low = (uint32_t)(bits & 0x1fffffff);
+            if (low < 0x0fffffffu || low > 0x10000001u) return neg ? -(float)d : (float)d;
+        }
+    }
+    char tmp[64];
+    const size_t tl = std::min<size_t>((size_t)(*tok_end - t0), sizeof(tmp) - 1);
+    memcpy(tmp, t0, tl);
+    tmp[tl] = 0;
+    return strtof(tmp, nullptr); /* 0 for no number at all, nan / inf in any spelling, hex */
+}
 } // namespace
 
 extern "C" {
@@ -181,34 +228,79 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     float *out = (float *)malloc(sizeof(float) * 3 * std::max<size_t>(points, 1));
     if (!out) return PPP_ERR_IO;
     if (data_kind == "ascii") {
+        /* One read of the rest of the file, then a walk over its lines: token number j of a line belongs to the field that
+           covers column j (COUNT columns per field); the first column of x, y and z is parsed, everything else skipped.
+           A number becomes the correctly rounded float (parse_float_token), what `istringstream >> float` -- PCL's
+           copyStringValue -- gives through strtof; (float)strtod would round twice.  (The first version parsed
+           every line through an istringstream: 0.55 s for a 1 M-point file; this: see DESIGN.md 4e.) */
+        char *text = (char *)malloc(remaining + 1);
+        if (!text) { free(out); return PPP_ERR_IO; }
+        f.read(text, (std::streamsize)remaining);
+        const size_t len = (size_t)f.gcount();
+        text[len] = 0;
+        int col_x = -1, col_y = -1, col_z = -1, cols = 0;
+        for (size_t i = 0; i < fields.size(); ++i) {
+            if ((int)i == ix) col_x = cols;
+            if ((int)i == iy) col_y = cols;
+            if ((int)i == iz) col_z = cols;
+            cols += std::max(1, fields[i].count);
+        }
+        const int last_col = std::max(col_x, std::max(col_y, col_z));
         size_t got = 0;
-        while (got < points && std::getline(f, line)) {
-            if (line.empty()) continue;
-            std::istringstream ls(line);
-            std::string tok;
+        const char *p = text, *end = text + len;
+        while (got < points && p < end) {
+            const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!eol) eol = end;
             float v[3] = {NAN, NAN, NAN};
-            for (size_t i = 0; i < fields.size(); ++i) {
-                for (int c = 0; c < std::max(1, fields[i].count); ++c) {
-                    if (!(ls >> tok)) break;
-                    if (c == 0 && ((int)i == ix || (int)i == iy || (int)i == iz)) {
-                        float val = (float)strtod(tok.c_str(), nullptr); /* accepts nan / inf */
-                        v[(int)i == ix ? 0 : ((int)i == iy ? 1 : 2)] = val;
-                    }
-                }
+            int col = 0;
+            const char *q = p;
+            bool any = false;
+            while (col <= last_col) { /* (columns are separated by blanks; any control character counts as one) */
+                while (q < eol && (unsigned char)*q <= ' ') ++q;
+                if (q >= eol) break;
+                any = true;
+                if (col == col_x || col == col_y || col == col_z) {
+                    const char *te;
+                    v[col == col_x ? 0 : (col == col_y ? 1 : 2)] = parse_float_token(q, eol, &te);
+                    q = te;
+                } else while (q < eol && (unsigned char)*q > ' ') ++q;
+                ++col;
             }
+            p = eol < end ? eol + 1 : end;
+            if (!any) continue; /* an empty line */
             memcpy(out + 3 * got, v, 12);
             ++got;
         }
+        free(text);
         if (got != points) { free(out); return PPP_ERR_IO; }
     } else if (data_kind == "binary") {
-        std::vector<unsigned char> rec((size_t)off * points);
-        f.read((char *)rec.data(), (std::streamsize)rec.size());
-        if ((size_t)f.gcount() != rec.size()) { free(out); return PPP_ERR_IO; }
-        for (size_t i = 0; i < points; ++i) {
-            const unsigned char *p = rec.data() + i * off;
-            out[3 * i + 0] = (float)read_scalar(p + fields[ix].offset, fields[ix].size, fields[ix].type);
-            out[3 * i + 1] = (float)read_scalar(p + fields[iy].offset, fields[iy].size, fields[iy].type);
-            out[3 * i + 2] = (float)read_scalar(p + fields[iz].offset, fields[iz].size, fields[iz].type);
+        const bool f4 = fields[ix].type == 'F' && fields[ix].size == 4 && fields[iy].type == 'F' && fields[iy].size == 4 &&
+                        fields[iz].type == 'F' && fields[iz].size == 4;
+        const int ox = fields[ix].offset, oy = fields[iy].offset, oz = fields[iz].offset;
+        if (f4 && off == 12 && ox == 0 && oy == 4 && oz == 8) { /* records ARE the output: read in place */
+            f.read((char *)out, (std::streamsize)(12 * points));
+            if ((size_t)f.gcount() != 12 * points) { free(out); return PPP_ERR_IO; }
+        } else {
+            unsigned char *rec = (unsigned char *)malloc(std::max<size_t>((size_t)off * points, 1));
+            if (!rec) { free(out); return PPP_ERR_IO; }
+            f.read((char *)rec, (std::streamsize)((size_t)off * points));
+            if ((size_t)f.gcount() != (size_t)off * points) { free(rec); free(out); return PPP_ERR_IO; }
+            if (f4) { /* the usual "x y z rgb" records: three 4-byte moves per point */
+                for (size_t i = 0; i < points; ++i) {
+                    const unsigned char *p = rec + i * off;
+                    memcpy(out + 3 * i + 0, p + ox, 4);
+                    memcpy(out + 3 * i + 1, p + oy, 4);
+                    memcpy(out + 3 * i + 2, p + oz, 4);
+                }
+            } else {
+                for (size_t i = 0; i < points; ++i) {
+                    const unsigned char *p = rec + i * off;
+                    out[3 * i + 0] = (float)read_scalar(p + ox, fields[ix].size, fields[ix].type);
+                    out[3 * i + 1] = (float)read_scalar(p + oy, fields[iy].size, fields[iy].type);
+                    out[3 * i + 2] = (float)read_scalar(p + oz, fields[iz].size, fields[iz].type);
+                }
+            }
+            free(rec);
         }
     } else if (data_kind == "binary_compressed") {
         /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream; the decoded block is
@@ -341,20 +433,92 @@ static int read_config_impl(const char *path, ppp_config *c)
     return PPP_OK;
 }
 
+/* printf("%g") of a float (promoted, precision 6) -- what `ofstream << float` prints -- without the general-purpose machinery:
+   six significant digits of |v| are round(|v| x 10^k) for the k that brings it into [1e5, 1e6).  10^|k| is exact in double up
+   to 10^22 and the one multiplication or division is correctly rounded, so the scaled value is within 2^-53 of the truth (1e-10
+   absolute; for 0 <= k <= 12 it IS the truth: a 24-bit significand times 5^k fits a double).  Its rounding to nearest, ties to
+   even, is then the correctly rounded decimal printf prints -- unless an inexact scaled value lies within 1e-7 of a half:
+   then, and for magnitudes beyond those powers of ten, std::to_chars (specified as printf's %.6g) decides.  Returns the end. */
+static char *format_g6(char *o, float vf)
+{
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    uint32_t bits;
+    memcpy(&bits, &vf, 4);
+    if (vf != vf) { /* vsnprintf shows a NaN's sign bit */
+        if (bits >> 31) *o++ = '-';
+        memcpy(o, "nan", 3);
+        return o + 3;
+    }
+    if (bits >> 31) *o++ = '-';
+    const double a = std::fabs((double)vf);
+    if (a == 0.0) { *o++ = '0'; return o; }
+    if (a >= 1e-16 && a < 1e21) {
+        /* floor(log10 a) guessed from the binary exponent (log10(2) = 1233 / 4096 to five digits: at most one off), settled on
+           the scaled value below */
+        const int e2 = (int)((bits >> 23) & 0xff) - 127;
+        int X = (e2 * 1233) >> 12;
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const int k = 5 - X;
+            if (k < -22 || k > 22) break;
+            const double scaled = k >= 0 ? a * P10[k] : a / P10[-k];
+            if (scaled < 1e5) { --X; continue; }
+            if (scaled >= 1e6) { ++X; continue; }
+            long n = (long)scaled;             /* scaled >= 1e5: truncation is the floor */
+            const double fr = scaled - (double)n;
+            const bool exact = k >= 0 && k <= 12; /* 24 bits x 5^k fit a double's 53: the product has no rounding at all */
+            if (!exact && std::fabs(fr - 0.5) < 1e-7) break; /* too close to call here */
+            if (fr > 0.5 || (fr == 0.5 && (n & 1))) ++n; /* to nearest, ties to even */
+            if (n >= 1000000) { n = 100000; ++X; }
+            char d[6];
+            for (int i = 5; i >= 0; --i) { d[i] = (char)('0' + n % 10); n /= 10; }
+            int last = 5;
+            while (last > 0 && d[last] == '0') --last; /* %g drops trailing zeros */
+            if (X < -4 || X >= 6) {
+                *o++ = d[0];
+                if (last > 0) { *o++ = '.'; for (int i = 1; i <= last; ++i) *o++ = d[i]; }
+                *o++ = 'e';
+                int e = X;
+                if (e < 0) { *o++ = '-'; e = -e; } else *o++ = '+';
+                *o++ = (char)('0' + e / 10); *o++ = (char)('0' + e % 10);
+            } else if (X >= 0) {
+                for (int i = 0; i <= X; ++i) *o++ = d[i];
+                if (last > X) { *o++ = '.'; for (int i = X + 1; i <= last; ++i) *o++ = d[i]; }
+            } else {
+                *o++ = '0'; *o++ = '.';
+                for (int i = -1; i > X; --i) *o++ = '0';
+                for (int i = 0; i <= last; ++i) *o++ = d[i];
+            }
+            return o;
+        }
+    }
+    const std::to_chars_result r = std::to_chars(o, o + 15, a, std::chars_format::general, 6);
+    return r.ptr;
+}
+
+/* pathFile as path_translation_alg.cpp:216-228 writes it: six `ofstream << float << " "` per waypoint, then std::endl.  The
+   bytes are the reference's; the way there is not: std::endl's flush per line (one write() per waypoint: 0.1 s for the 26 k
+   waypoints of a 1 M-point workpiece, against 0.07 ms of planning) becomes one write of the whole text. */
 static int write_path_file_impl(const char *path, const float *wp6, size_t W)
 {
     if (!path || (!wp6 && W)) return PPP_ERR_ARG;
-    std::ofstream outputFile(path);
-    if (!outputFile.is_open()) {
+    FILE *f = fopen(path, "wb");
+    if (!f) {
         std::cerr << "Unable to open file: " << path << std::endl;
         return PPP_ERR_IO;
     }
+    const size_t per = 6 * 16 + 1; /* "-1.23457e-38 " is 13 characters */
+    std::vector<char> text(std::max<size_t>(W, 1) * per);
+    char *o = text.data();
     for (size_t w = 0; w < W; ++w) {
-        for (int i = 0; i < 6; i++) outputFile << wp6[6 * w + i] << " ";
-        outputFile << std::endl;
+        for (int i = 0; i < 6; i++) {
+            o = format_g6(o, wp6[6 * w + i]);
+            *o++ = ' ';
+        }
+        *o++ = '\n';
     }
-    outputFile.close();
-    return PPP_OK;
+    const size_t len = (size_t)(o - text.data());
+    const bool ok = fwrite(text.data(), 1, len, f) == len;
+    return (fclose(f) == 0 && ok) ? PPP_OK : PPP_ERR_IO;
 }
 
 

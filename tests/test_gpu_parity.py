@@ -399,6 +399,46 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
             assert os.path.exists(str(tmp_path / "smooth_workpiece.pcd"))
 
 
+def test_planners_of_one_process_share_engine_handles(engine_mod, tmp_path):
+    """A planner per workpiece, one after the other in one process (examples/workpieces.cpp): the second and third take the
+    handle the one before gave back (ppp::HandlePool in ppp_planner.hpp).  Nothing of an earlier workpiece may show: every
+    pathFile equals, byte for byte, the one a process of its own writes for that cloud -- a cloud of the same size as the last
+    (plan inherited), a smaller one, and the first again."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "connect", "workpieces"], stdout=subprocess.DEVNULL)
+    pts, cfg = synth.make_config("small_40k")
+    rng = np.random.default_rng(21)
+    clouds = [pts, pts[rng.permutation(len(pts))] + np.float32([0, 0, 0.002]), pts[pts[:, 1] < np.median(pts[:, 1])], pts]
+    names = []
+    for i, c in enumerate(clouds):
+        names.append(str(tmp_path / ("w%d.pcd" % i)))
+        engine_mod.save_pcd(names[-1], np.ascontiguousarray(c, dtype=np.float32), binary=True)
+    out = str(tmp_path / "WayPoints.txt")
+    conf = tmp_path / "config.txt"
+    conf.write_text("Tool_Radius = 6\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
+                    "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n"
+                    "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n" % out)
+    env = dict(os.environ, PPP_CONFIG=str(conf))
+    alone = []
+    for nm in names:
+        r = subprocess.run([os.path.join(root, "examples", "connect"), nm], env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        alone.append(open(out, "rb").read())
+        os.remove(out)
+    assert len(set(alone[:3])) == 3 and alone[0] == alone[3]
+    r = subprocess.run([os.path.join(root, "examples", "workpieces")] + names, env=env, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4 planned, 3 planners served from the handle pool" in r.stdout, r.stdout
+    for i in range(4):
+        assert open(out + ".%d" % i, "rb").read() == alone[i], i
+    # and with the pool switched off: four handles made and destroyed, the same files
+    r = subprocess.run([os.path.join(root, "examples", "workpieces")] + names, env=dict(env, PPP_NO_HANDLE_POOL="1"), capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0 and "4 planned, 0 planners served" in r.stdout, r.stdout + r.stderr
+    for i in range(4):
+        assert open(out + ".%d" % i, "rb").read() == alone[i], i
+
+
 def _read_rgb_pcd(path):
     raw = open(path, "rb").read()
     k = raw.index(b"DATA binary\n") + len(b"DATA binary\n")

@@ -371,6 +371,64 @@ def test_write_path_file_c_abi_matches_python_writer(engine_mod, tmp_path):
     assert open(a).readline() == "0.5 -0.25 1 3.14159 -1e-05 123457 \n"
 
 
+def test_path_file_bytes_are_printf_g_for_every_kind_of_float(engine_mod, tmp_path):
+    """pathFile is `ofstream << float` (path_translation_alg.cpp:216-228), i.e. printf("%g") of the promoted value.  The writer
+    formats with a routine of its own (ppp_io.cpp: format_g6): random bit patterns of every exponent, values that scale to exact
+    and near ties at the sixth digit, powers of ten, denormals, infinities -- against Python's '%g' of the same double."""
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2**32, 240000, dtype=np.uint64).astype(np.uint32)
+    v = bits.view(np.float32).copy()
+    v[np.isnan(v)] = np.float32(np.nan)                       # (a NaN's sign shows as "-nan" in C and not in Python: positive only)
+    ties = (rng.integers(1, 2000000, 60000) * 0.5).astype(np.float32) * np.float32(10.0) ** rng.integers(-6, 7, 60000).astype(np.float32)
+    near = np.nextafter(ties, np.float32(np.inf) * np.where(rng.integers(0, 2, ties.size) == 1, 1, -1).astype(np.float32))
+    special = np.float32([0.0, -0.0, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, np.inf, -np.inf, 1e5, 1e6, 999999.5, 9999995, 99999.95,
+                          0.0001, 0.00001, 0.000099999997, 123456.5, 1234565, 0.5, 1e21, 1e22, 1e-16, 9.9999994e-17, 1e15, 999999.44])
+    p10 = (np.float64(10.0) ** np.arange(-45, 39)).astype(np.float32)
+    allv = np.concatenate([v, ties, near, special, p10, np.nextafter(p10, np.float32(0)), np.nextafter(p10, np.float32(np.inf))])
+    allv = np.concatenate([allv, np.zeros((-len(allv)) % 6, np.float32)]).reshape(-1, 6)
+    out = str(tmp_path / "wp.txt")
+    engine_mod.write_path_file(out, allv)
+    want = "".join("".join("%g " % float(x) for x in row) + "\n" for row in allv)
+    got = open(out).read()
+    if got != want:
+        g, w = got.split(), want.split()
+        bad = [(a, b, float(x)) for a, b, x in zip(g, w, allv.ravel()) if a != b][:5]
+        raise AssertionError("pathFile differs from printf %%g: %r" % (bad,))
+
+
+def test_ascii_pcd_numbers_are_the_correctly_rounded_floats(engine_mod, tmp_path):
+    """An ascii PCD goes through PCL's `istringstream >> float`, i.e. strtof: ONE rounding from the decimal text.  The loader's
+    own parser (ppp_io.cpp: parse_float_token) against the C library's strtof, on nine-digit prints, long prints, decimal
+    midpoints of neighbouring floats (exact ties), their neighbours, and the spellings strtof takes and a digit loop does not."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.strtof.restype = ctypes.c_float
+    libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    rng = np.random.default_rng(6)
+    f = (rng.standard_normal(20000) * 10.0 ** rng.integers(-5, 6, 20000)).astype(np.float32)
+    toks = ["%.9g" % x for x in f[:6000]] + ["%.6e" % x for x in f[6000:9000]] + ["%f" % x for x in f[9000:12000]]
+    from decimal import Decimal
+    g = np.nextafter(f[12000:16000], np.float32(np.inf))
+    for a, b in zip(f[12000:16000], g):                          # the midpoint of two neighbouring floats, all its digits: a tie
+        mid = (Decimal(float(a)) + Decimal(float(b))) / 2
+        toks.append(format(mid, "f") if abs(mid) > Decimal("1e-4") else "%.17g" % float(mid))
+    for a, b in zip(f[16000:20000], np.nextafter(f[16000:20000], np.float32(np.inf))):   # ... and a double next to it
+        mid = (float(a) + float(b)) / 2
+        toks.append("%.17g" % np.nextafter(mid, np.inf if rng.integers(0, 2) else -np.inf))
+    toks += ["nan", "NaN", "-inf", "inf", "0x1.8p1", "1e", ".5", "5.", "-0", "+2.5", "1e-50", "3.4028236e38", "1e39", "1.17549435e-38",
+             "1e-45", "7e-46", "00012.500", "1E+2", "1e+0007", "0.000000000000000000001", "123456789012345678901234567890", "abc"]
+    toks += ["0"] * ((-len(toks)) % 3)
+    n = len(toks) // 3
+    p = tmp_path / "t.pcd"
+    p.write_text("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+                 "POINTS %d\nDATA ascii\n" % (n, n) + "".join("%s\t%s  %s \r\n" % tuple(toks[3 * i:3 * i + 3]) for i in range(n)))
+    xyz, _ = engine_mod.load_pcd(str(p))
+    want = np.array([libc.strtof(t.encode(), None) for t in toks], np.float32)
+    got = xyz.ravel()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), [(toks[i], float(want[i]), float(got[i])) for i in np.nonzero(~same)[0][:5]]
+
+
 def test_pcd_and_config_parsers_under_address_sanitizer(tmp_path):
     """The host I/O of the C ABI (ppp_io.cpp: PCD ascii / binary / binary_compressed, LZF, config.txt, pathFile) compiled alone
     with -fsanitize=address,undefined and fed 4500 mutated / truncated PCD files and 800 mutated config files: every file is
