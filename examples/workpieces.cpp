@@ -31,17 +31,23 @@ int main(int argc, char **argv)
         ppp_default_config(&c);
         if (ppp_read_config(configFile.c_str(), &c) == PPP_OK) pathFile = c.path_file;
     }
-    std::vector<double> ms;
+    std::vector<double> ms, ms_open, ms_gen, ms_get;
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     for (size_t i = 0; i < pcds.size(); ++i) {
         const auto t0 = std::chrono::steady_clock::now();
         size_t W = 0;
         {
-            path_generater path_planner = {configFile, pcds[i]};
+            path_generater path_planner = {configFile, pcds[i]}; /* file -> HBM, plan */
+            ms_open.push_back(since(t0));
+            const auto t1 = std::chrono::steady_clock::now();
             path_planner.GenPath();
-            path_planner.getPath();
+            ms_gen.push_back(since(t1));
+            const auto t2 = std::chrono::steady_clock::now();
+            path_planner.getPath();                              /* the pass's second half, list to the host, pathFile */
+            ms_get.push_back(since(t2));
             W = path_planner.waypoints().size();
         }
-        ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        ms.push_back(since(t0));
         if (!W) {
             std::fprintf(stderr, "workpieces: no path for %s\n", pcds[i].c_str());
             return 1;
@@ -54,6 +60,8 @@ int main(int argc, char **argv)
     }
     std::printf("workpieces: %zu planned, %zu planners served from the handle pool; ms per workpiece:", pcds.size(), ppp::HandlePool::taken_from_pool());
     for (double m : ms) std::printf(" %.2f", m);
+    std::printf("\nworkpieces: of which constructor / GenPath / getPath:");
+    for (size_t i = 0; i < ms.size(); ++i) std::printf(" %.2f/%.2f/%.2f", ms_open[i], ms_gen[i], ms_get[i]);
     std::printf("\n");
     return 0;
 }

@@ -102,6 +102,14 @@ int ppp_set_params(ppp_handle h, const ppp_params *p);
 int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_bytes, const float *viewpoint);
 /* same, the buffer already lives on this handle's device */
 int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
+/* The constructors' first line and their loop in one call (pcl::io::loadPCDFile<PointXYZRGB>(name, *cloud) + the x1000 loop:
+ * path_slicing_alg.cpp:10-25, path_dynamic_alg.cpp:12-28, Path_Generation.cpp:8-34): the file's records go straight to HBM.
+ * A `DATA binary` file whose x, y, z are consecutive float32 fields is streamed in pieces through two pinned buffers that
+ * belong to the handle (several readers fill one while the other is on its way to the device; the conversion kernel then picks
+ * x, y, z out of the records: no host copy of the cloud is ever made); every other flavour (ascii, binary_compressed, F8
+ * or integer coordinates) goes through ppp_load_pcd + ppp_set_cloud.  *n = the points of the file, viewpoint_out (7 floats,
+ * may be NULL) its VIEWPOINT line; the translation part becomes the handle's viewpoint as in ppp_set_cloud. */
+int ppp_set_cloud_pcd(ppp_handle h, const char *path, size_t *n, float viewpoint_out[7]);
 /* Slice-range sharding without the whole cloud on every GPU (SURVEY.md 8e case ii, pre-partitioned by x).
  * ppp_range_interval: the x interval [lo, hi] -- planner units: the file's values x 1000 (as floats) when ChangeRange -- whose
  * points a handle with p->slice_begin / slice_end / range_margin indexes, for a cloud with the given x bounds (host arithmetic
@@ -287,6 +295,17 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps);
  * *xyz receives n x 3 packed floats allocated by the library (release with ppp_free); viewpoint = the 7
  * VIEWPOINT numbers (tx ty tz qw qx qy qz). */
 int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7]);
+/* the header alone: how the file stores its points (what ppp_set_cloud_pcd decides on) */
+typedef struct ppp_pcd_layout {
+    int data_kind;                    /* 0 = ascii, 1 = binary, 2 = binary_compressed */
+    size_t points;                    /* POINTS (or WIDTH x HEIGHT) */
+    size_t record_bytes;              /* bytes of one point's record: the sum of SIZE x COUNT over FIELDS */
+    int x_offset, y_offset, z_offset; /* where x, y, z sit in it */
+    int xyz_float32;                  /* 1 when all three are F 4 */
+    long long data_offset;            /* the byte after the DATA line */
+    float viewpoint[7];
+} ppp_pcd_layout;
+int ppp_pcd_probe(const char *path, ppp_pcd_layout *layout);
 /* binary: 0 = ascii (pcl::io::savePCDFileASCII, path_slicing_alg.cpp:138), 1 = binary, 2 = binary_compressed */
 int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary);
 /* a pcl::PointXYZRGB cloud (FIELDS x y z rgb, colour packed 0x00RRGGBB): what show() would hand to the viewer

@@ -143,16 +143,20 @@ public:
             }
         }
         if (!apply_params()) return false;
-        float *xyz = nullptr;
+        /* pcl::io::loadPCDFile + the x1000 loop: the file's records go straight to HBM (ppp_set_cloud_pcd) */
         size_t n = 0;
-        float vp[7];
-        if (ppp_load_pcd(cloud_name.c_str(), &xyz, &n, vp) != PPP_OK) {
+        ppp_pcd_layout lay;
+        if (ppp_pcd_probe(cloud_name.c_str(), &lay) != PPP_OK) {
             std::fprintf(stderr, "Cloudn't read file!\n"); /* path_slicing_alg.cpp:11 */
             loaded_ = false;
             return false;
         }
-        int rc = ppp_set_cloud(h_, xyz, n, 12, vp);
-        ppp_free(xyz);
+        int rc = ppp_set_cloud_pcd(h_, cloud_name.c_str(), &n, nullptr);
+        if (rc == PPP_ERR_IO || rc == PPP_ERR_UNSUPPORTED) {
+            std::fprintf(stderr, "Cloudn't read file!\n");
+            loaded_ = false;
+            return false;
+        }
         if (rc != PPP_OK) return report(rc);
         loaded_ = true;
         return true;

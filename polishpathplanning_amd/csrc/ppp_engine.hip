@@ -17,6 +17,11 @@
 #include "ppp_sort.h"
 #include "ppp_align.h"
 #include "ppp_gather.h"
+#include <atomic>
+#include <cerrno>
+#include <fcntl.h>
+#include <thread>
+#include <unistd.h>
 /* LDS slots of a slab's sort workgroup, as a multiple of the mean slab population (rounded up to a power of two): only
    clouds beyond the 8192-slab cap see it (mean > 1024), where 1.6 keeps the workgroup at 24 KiB of LDS -- twice as many
    slabs in flight, cfg 5's sort 125 -> 110 us -- and a slab denser than that goes through the arena pass */
@@ -96,6 +101,14 @@ struct ppp_handle_s {
     float vp[3] = {0, 0, 0};
     size_t n = 0;
     bool have_cloud = false, planned = false, index_built = false, gen_done = false, path_done = false;
+    /* host copy of the knots of the last pass (slice tables + node arrays), fetched whole by the first ppp_get_nodes after a pass:
+       the planner classes ask slice by slice (a Spline view per slice: 2 calls x 256 slices), and a synchronous copy of a few
+       bytes costs ~20 us on this runtime -- 60 ms of GenPath() for 0.07 ms of planning before this cache */
+    unsigned long long gen_serial = 0, hn_serial = ~0ull;
+    std::vector<int> hn_off;    /* S + 1 offsets into ... */
+    std::vector<float> hn_xyz;  /* ... three planes (x | y | z) of hn_off[S] floats */
+    DevBuf<int> pack_tab;       /* device: node_start as the host validated it, then the offsets */
+    DevBuf<float> pack_out;
     int max_lds = 65536;
     int num_cus = 256;
 
@@ -209,7 +222,11 @@ struct ppp_handle_s {
         if (e == hipSuccess) pin_bytes = want;
         return e;
     }
+    char *pcd_stage[2] = {nullptr, nullptr}; /* ppp_set_cloud_pcd: two pinned pieces ... */
+    size_t pcd_stage_bytes = 0;
+    hipEvent_t pcd_ev[2] = {nullptr, nullptr}; /* ... and the event behind each one's copy */
     bool meta_in_flight = false;
+    bool meta_fresh = false; /* hmeta is the device's block as of now: nothing was launched on this handle since it was fetched (every launch clears it) */
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
     float *out2 = nullptr;          /* batched form: the emitting launch also writes the list here (at most out2_cap rows) */
     int out2_cap = 0;
@@ -247,11 +264,12 @@ struct ppp_handle_s {
         normals4.release(); dyn_bnd_pts.release(); dyn_adj_pts.release(); dyn_first_ab.release(); dyn_first_snap.release(); dyn_first_node.release(); ell_cs.release(); dyn_bnd_knots.release(); dyn_bnd_n.release(); plan_ticket.release(); plan_auto.release();
         node_start.release(); node_cnt.release(); band_cnt.release(); wp_cnt.release(); wp_off.release(); tail.release(); slice_wpcnt.release();
         wp_xyz.release(); wp_normal.release(); wp_nn.release(); wp_pre.release(); wp_smooth.release(); wp_out.release();
-        mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release();
+        mm_part.release(); big_slabs.release(); big_slices.release(); arena.release(); scratch.release(); pack_tab.release(); pack_out.release();
         win_px.release(); win_cnt.release(); win_pts.release(); win_part.release(); wps_xyz.release(); wps_normal.release(); wps_nn.release(); wps_pre.release(); wps_rec.release();
         drop_graph();
         drop_batch();
         if (hmeta_pinned) (void)hipHostFree(hmeta_pinned);
+        for (int b = 0; b < 2; ++b) { if (pcd_stage[b]) (void)hipHostFree(pcd_stage[b]); if (pcd_ev[b]) (void)hipEventDestroy(pcd_ev[b]); }
         if (pin) (void)hipHostFree(pin);
         for (auto &t : timers) { for (auto e : t.e0) (void)hipEventDestroy(e); for (auto e : t.e1) (void)hipEventDestroy(e); }
         if (stream) (void)hipStreamDestroy(stream);
@@ -368,6 +386,7 @@ hipError_t copy_sync(ppp_handle h, void *dst, const void *src, size_t bytes, hip
         KTimer *_t = (h)->timing ? timer_for((h), name) : nullptr;                                    \
         if (_t) (void)hipEventRecord(_t->e0[_t->used], (h)->stream);                                  \
         (void)hipGetLastError(); /* the check below must not pick up an older, unrelated error */     \
+        (h)->meta_fresh = false;                                                                      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (h)->stream, __VA_ARGS__);         \
         if (_t) { (void)hipEventRecord(_t->e1[_t->used], (h)->stream); _t->used++; }                  \
         hipError_t _le = hipGetLastError();                                                           \
@@ -727,7 +746,7 @@ int make_plan(ppp_handle h)
     /* from here on the handle's members are rewritten step by step: a re-plan that fails half way (a slice range wider
        than the part this handle holds, an allocation) must leave no old plan, no finished-looking results and no
        captured graph behind for a later ppp_run_async to replay against the new members */
-    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
+    h->planned = false; h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false; h->list_final = false;
     h->drop_graph();
     const int n = (int)h->n;
     /* exact slice count from the cached bounds (the device recomputes the same walk) */
@@ -887,7 +906,7 @@ int make_plan(ppp_handle h)
     { int rcw = plan_window(h, S, per); if (rcw) return rcw; }
     h->stage_compact = true;
     h->planned = true;
-    h->index_built = false; h->gen_done = false; h->path_done = false; h->list_final = false;
+    h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false; h->list_final = false;
     h->drop_graph(); /* buffer addresses and launch geometry are baked into the captured graph */
     return PPP_OK;
 }
@@ -1037,10 +1056,15 @@ int fetch_meta(ppp_handle h)
         HIPCHK(h, hipStreamSynchronize(h->stream));
         h->hmeta = (h->meta_from_batch && h->bmetas) ? h->bmetas->pinned[h->bslot] : *h->hmeta_pinned;
         h->meta_in_flight = false;
+        h->meta_fresh = true;
         return PPP_OK;
     }
+    /* (a planner class asks per slice -- a Spline view per slice, two questions each: a copy and a wait per question were
+       11 ms of GenPath() at 256 slices) */
+    if (h->meta_fresh) return PPP_OK;
     HIPCHK(h, hipMemcpyAsync(&h->hmeta, h->meta.p, sizeof(DevMeta), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->meta_fresh = true;
     return PPP_OK;
 }
 
@@ -1236,7 +1260,7 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
         if (!h->h_nvalid) for (int d = 0; d < 3; ++d) { h->h_mn[d] = 3.402823466e+38f; h->h_mx[d] = -3.402823466e+38f; }
     }
     h->have_cloud = true;
-    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->planned = false; h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false;
     h->normals_valid = false;
 #ifdef PPP_TUNING
     if (getenv("PPP_COLD_DEBUG")) {
@@ -1401,6 +1425,92 @@ int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_b
     return set_cloud_common(h, h->scratch.p, n, stride_bytes, viewpoint);
 }
 
+/* ---- a PCD file straight into HBM ---- */
+namespace {
+constexpr size_t PCD_PIECE = (size_t)8 << 20; /* bytes of one piece in flight (two pinned buffers of this size per handle) */
+constexpr int PCD_READERS = 4;                /* threads that fill a piece from the page cache (one memcpy stream does ~5 GB/s) */
+
+/* fills buf[0, len) from the file at `pos`, with PCD_READERS preads side by side; false on a short read */
+bool read_piece(int fd, char *buf, size_t len, long long pos)
+{
+    std::atomic<bool> ok{true};
+    auto part = [&](size_t a, size_t b) {
+        while (a < b) {
+            const ssize_t r = pread(fd, buf + a, b - a, (off_t)(pos + (long long)a));
+            if (r <= 0) { if (r < 0 && errno == EINTR) continue; ok = false; return; }
+            a += (size_t)r;
+        }
+    };
+    const int nt = len >= ((size_t)1 << 20) ? PCD_READERS : 1;
+    const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) { const size_t a = std::min(len, per * t), b = std::min(len, per * (t + 1)); if (a < b) th.emplace_back(part, a, b); }
+    part(0, std::min(len, per));
+    for (auto &t : th) t.join();
+    return ok;
+}
+} // namespace
+
+int ppp_set_cloud_pcd(ppp_handle h, const char *path, size_t *n_out, float viewpoint_out[7])
+{
+    if (!h || !path) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
+    if (n_out) *n_out = 0;
+    ppp_pcd_layout L;
+    int rc = ppp_pcd_probe(path, &L);
+    if (rc != PPP_OK) return fail(h, rc, std::string("not a readable PCD file: ") + path);
+    if (viewpoint_out) memcpy(viewpoint_out, L.viewpoint, sizeof(L.viewpoint));
+    const bool direct = L.data_kind == 1 && L.xyz_float32 && L.y_offset == L.x_offset + 4 && L.z_offset == L.x_offset + 8 &&
+                        (L.x_offset & 3) == 0 && (L.record_bytes & 3) == 0 && L.record_bytes >= 12 && L.points > 0;
+    if (!direct) { /* ascii, compressed, F8 / integer coordinates, x y z apart: through the host */
+        float *xyz = nullptr;
+        size_t n = 0;
+        float vp[7];
+        rc = ppp_load_pcd(path, &xyz, &n, vp);
+        if (rc != PPP_OK) return fail(h, rc, std::string("not a readable PCD file: ") + path);
+        rc = ppp_set_cloud(h, xyz, n, 12, vp);
+        ppp_free(xyz);
+        if (rc == PPP_OK && n_out) *n_out = n;
+        return rc;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    const size_t bytes = L.points * L.record_bytes;
+    HIPCHK(h, h->scratch.ensure(bytes));
+    const size_t piece = std::min(PCD_PIECE, (bytes + 4095) & ~(size_t)4095);
+    if (h->pcd_stage_bytes < piece) {
+        for (int b = 0; b < 2; ++b) { if (h->pcd_stage[b]) (void)hipHostFree(h->pcd_stage[b]); h->pcd_stage[b] = nullptr; }
+        h->pcd_stage_bytes = 0;
+        for (int b = 0; b < 2; ++b) HIPCHK(h, hipHostMalloc((void **)&h->pcd_stage[b], piece, hipHostMallocDefault));
+        h->pcd_stage_bytes = piece;
+    }
+    for (int b = 0; b < 2; ++b) if (!h->pcd_ev[b]) HIPCHK(h, hipEventCreateWithFlags(&h->pcd_ev[b], hipEventDisableTiming));
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(h, PPP_ERR_IO, std::string("cannot open ") + path);
+    bool io_ok = true;
+    hipError_t he = hipSuccess;
+    size_t done = 0;
+    for (int k = 0; done < bytes && io_ok && he == hipSuccess; ++k) {
+        const int b = k & 1;
+        const size_t len = std::min(h->pcd_stage_bytes, bytes - done);
+        if (k >= 2) he = hipEventSynchronize(h->pcd_ev[b]); /* the copy that last read this buffer */
+        if (he != hipSuccess) break;
+        io_ok = read_piece(fd, h->pcd_stage[b], len, L.data_offset + (long long)done);
+        if (!io_ok) break;
+        he = hipMemcpyAsync(h->scratch.p + done, h->pcd_stage[b], len, hipMemcpyHostToDevice, h->stream);
+        if (he == hipSuccess) he = hipEventRecord(h->pcd_ev[b], h->stream);
+        done += len;
+    }
+    close(fd);
+    if (!io_ok || he != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream); /* nothing may still read the pinned buffers */
+        if (he != hipSuccess) return fail(h, PPP_ERR_HIP, std::string("PCD upload: ") + hipGetErrorString(he));
+        return fail(h, PPP_ERR_IO, std::string("short read: ") + path);
+    }
+    rc = set_cloud_common(h, h->scratch.p + L.x_offset, L.points, L.record_bytes, L.viewpoint);
+    if (rc == PPP_OK && n_out) *n_out = L.points;
+    return rc;
+}
+
 int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint)
 {
     if (!h || (!xyz_dev && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
@@ -1465,7 +1575,7 @@ int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_
     h->win_disabled = false;
     h->big_path = false;
     h->have_cloud = true;
-    h->planned = false; h->index_built = false; h->gen_done = false; h->path_done = false;
+    h->planned = false; h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false;
     h->normals_valid = false;
     h->drop_graph();
     return make_plan(h);
@@ -1649,7 +1759,7 @@ int ppp_remove_outlier(ppp_handle h, int mean_k, double stddev_mul, size_t *n_ke
         return PPP_OK;
     };
     rc = run();
-    if (rc == PPP_OK) { h->meta_in_flight = false; rc = fetch_meta(h); }
+    if (rc == PPP_OK) { h->meta_in_flight = false; h->meta_fresh = false; rc = fetch_meta(h); }
     if (rc == PPP_OK) rc = map_dev_err(h);
     if (rc != PPP_OK) { cleanup(); return rc; }
     /* the filtered cloud replaces the resident one (sor.filter(*cloud)) */
@@ -1797,7 +1907,7 @@ int ppp_smooth_mls(ppp_handle h, double search_radius, int order, size_t *n_out)
         return PPP_OK;
     };
     rc = run();
-    if (rc == PPP_OK) { h->meta_in_flight = false; rc = fetch_meta(h); }
+    if (rc == PPP_OK) { h->meta_in_flight = false; h->meta_fresh = false; rc = fetch_meta(h); }
     if (rc == PPP_OK) rc = map_dev_err(h);
     if (rc != PPP_OK) { cleanup(); return rc; }
     std::swap(h->X, X2); std::swap(h->Y, Y2); std::swap(h->Z, Z2);
@@ -1845,7 +1955,7 @@ int ppp_gen_path_async(ppp_handle h)
     if (h->win_path) { /* bounds + binning into the slices' windows, then everything per slice in one launch (ppp_window.h) */
         int rcw = enqueue_window_gen(h);
         if (rcw) return rcw;
-        h->gen_done = true;
+        h->gen_done = true; ++h->gen_serial;
         h->path_done = false;
         if (h->chain_calls) return PPP_OK;
         return enqueue_meta_copy(h);
@@ -1876,7 +1986,7 @@ int ppp_gen_path_async(ppp_handle h)
         int rc2 = enqueue_dynamic(h);
         if (rc2) return rc2;
     }
-    h->gen_done = true;
+    h->gen_done = true; ++h->gen_serial;
     h->path_done = false;
     if (h->chain_calls) return PPP_OK; /* getPath follows in the same enqueue and ends with the copy */
     return enqueue_meta_copy(h);
@@ -1962,7 +2072,7 @@ int ppp_finish_path_async(ppp_handle h, const float *pre6_dev, size_t W, const i
     if (W) LAUNCH(h, "k_load_pre", k_load_pre, (unsigned)((W + 255) / 256), 256, 0, h->meta.p, pre6_dev, h->wp_pre.p);
     int rc = enqueue_finish(h, D);
     if (rc) return rc;
-    h->gen_done = true; h->path_done = true; h->list_final = true;
+    h->gen_done = true; ++h->gen_serial; h->path_done = true; h->list_final = true;
     h->stage_compact = true; /* (no per-waypoint stage lists belong to a list finished from gathered blocks) */
     return PPP_OK;
 }
@@ -2008,10 +2118,11 @@ int ppp_run_async(ppp_handle h)
         e = hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0);
         if (e != hipSuccess) { h->drop_graph(); return fail(h, PPP_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     }
+    h->meta_fresh = false;
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     if (!h->win_path) h->index_built = true;
     h->stage_compact = !h->win_path;
-    h->gen_done = true; h->path_done = true;
+    h->gen_done = true; ++h->gen_serial; h->path_done = true;
     h->list_final = !h->ranged;
     h->meta_in_flight = true; /* the captured sequence ends with the meta copy */
     h->meta_from_batch = false;
@@ -2373,8 +2484,9 @@ int ppp_run_batch_async(ppp_handle *hs, size_t count, float *dst_dev, const size
         ppp_handle h = hs[i];
         if (!(bg->batched && bg->win) && !(!bg->batched && h->win_path)) h->index_built = true;
         h->stage_compact = !((bg->batched && bg->win) || (!bg->batched && h->win_path));
-        h->gen_done = true; h->path_done = true;
+        h->gen_done = true; ++h->gen_serial; h->path_done = true;
         h->list_final = !h->ranged;
+        h->meta_fresh = false;
         h->meta_in_flight = !(bg->batched && count == 1); /* a batch of one does not publish its meta block: fetched on demand */
         h->meta_from_batch = bg->batched && count > 1;
         if (bg->batched && count > 1) { h->bmetas = bg->hmetas; h->bslot = i; }
@@ -2644,7 +2756,7 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
     HIPCHK(h, h->scratch.ensure(sizeof(int) * (size_t)capb));
     LAUNCH(h, "k_band_indices", k_band_indices, 1, 256, slice_lds_bytes(capb), h->sorted4.p, h->slab_start.p, h->meta.p, lo, hi,
            capb, (int *)h->scratch.p, capb);
-    h->meta_in_flight = false; /* the kernel above wrote meta: take a fresh copy */
+    h->meta_in_flight = false; h->meta_fresh = false; /* the kernel above wrote meta: take a fresh copy */
     int rc = fetch_meta(h);
     if (rc) return rc;
     const int *src = (const int *)h->scratch.p;
@@ -2660,7 +2772,7 @@ static int band_indices(ppp_handle h, float lo, float hi, int *out, size_t cap, 
         int *hist = (int *)(srt + cnt);
         LAUNCH(h, "k_band_indices_big", k_band_indices_big, 1, 256, 0, h->sorted4.p, h->slab_start.p, h->meta.p, lo, hi, (int)h->n, tmp,
                srt, hist, NB, (int)cnt, dout);
-        h->meta_in_flight = false;
+        h->meta_in_flight = false; h->meta_fresh = false;
         rc = fetch_meta(h);
         if (rc) return rc;
         if (h->hmeta.api_flag) return fail(h, PPP_ERR_CAPACITY, "rangedX_index: band changed size between passes");
@@ -2699,24 +2811,41 @@ int ppp_get_nodes(ppp_handle h, int s, double *y, double *x, double *z, size_t c
     int rc = ensure_ready(h, true, false);
     if (rc) return rc;
     if (s < 0 || s >= h->hmeta.S) return fail(h, PPP_ERR_ARG, "slice out of range");
-    int st = 0, cnt = 0;
-    float pxs = 0;
-    HIPCHK(h, copy_sync(h, &st, h->node_start.p + s, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, copy_sync(h, &cnt, h->node_cnt.p + s, 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, copy_sync(h, &pxs, h->px.p + s, 4, hipMemcpyDeviceToHost));
-    if (m) *m = (size_t)cnt;
-    size_t k = std::min(cap, (size_t)cnt);
-    (void)pxs;
-    if (k && (y || z || x)) {
-        std::vector<float> fx(k), fy(k), fz(k);
-        HIPCHK(h, copy_sync(h, fx.data(), h->node_x.p + st, k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, copy_sync(h, fy.data(), h->node_y.p + st, k * 4, hipMemcpyDeviceToHost));
-        HIPCHK(h, copy_sync(h, fz.data(), h->node_z.p + st, k * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < k; ++i) {
-            if (y) y[i] = (double)fy[i];
-            if (x) x[i] = (double)fx[i];
-            if (z) z[i] = (double)fz[i];
+    if (h->hn_serial != h->gen_serial) { /* first question about this pass: every slice's knots, packed on the device, in one copy */
+        const size_t S = (size_t)h->hmeta.S;
+        std::vector<int> tab(2 * S + 1);
+        int *start = tab.data(), *off = tab.data() + S;
+        std::vector<int> cnt(S);
+        HIPCHK(h, copy_sync(h, start, h->node_start.p, S * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_sync(h, cnt.data(), h->node_cnt.p, S * 4, hipMemcpyDeviceToHost));
+        size_t total = 0;
+        for (size_t i = 0; i < S; ++i) {
+            /* (a slice-range handle fills the rows of its own slices only: whatever the others hold reads as "no knots") */
+            if (start[i] < 0 || cnt[i] < 0 || (size_t)start[i] + (size_t)cnt[i] > (size_t)h->node_cap) { start[i] = 0; cnt[i] = 0; }
+            off[i] = (int)total;
+            total += (size_t)cnt[i];
         }
+        if (total > 0x7fffffffu / 3) return fail(h, PPP_ERR_CAPACITY, "more knots than one copy holds");
+        off[S] = (int)total;
+        h->hn_off.assign(off, off + S + 1);
+        h->hn_xyz.resize(3 * total);
+        if (total) {
+            HIPCHK(h, h->pack_tab.ensure(2 * S + 1));
+            HIPCHK(h, h->pack_out.ensure(3 * total));
+            HIPCHK(h, copy_sync(h, h->pack_tab.p, tab.data(), (2 * S + 1) * 4, hipMemcpyHostToDevice));
+            LAUNCH(h, "k_nodes_pack", k_nodes_pack, (unsigned)S, 256, 0, h->pack_tab.p, h->pack_tab.p + S, (int)S, (int)total, h->node_x.p, h->node_y.p, h->node_z.p,
+                   h->pack_out.p);
+            HIPCHK(h, copy_sync(h, h->hn_xyz.data(), h->pack_out.p, 3 * total * 4, hipMemcpyDeviceToHost));
+        }
+        h->hn_serial = h->gen_serial;
+    }
+    const size_t st = (size_t)h->hn_off[(size_t)s], cnt = (size_t)(h->hn_off[(size_t)s + 1] - h->hn_off[(size_t)s]), total = (size_t)h->hn_off.back();
+    if (m) *m = cnt;
+    const size_t k = std::min(cap, cnt);
+    for (size_t i = 0; i < k; ++i) {
+        if (x) x[i] = (double)h->hn_xyz[st + i];
+        if (y) y[i] = (double)h->hn_xyz[total + st + i];
+        if (z) z[i] = (double)h->hn_xyz[2 * total + st + i];
     }
     return PPP_OK;
 }
@@ -2764,7 +2893,7 @@ int ppp_eval_spline(ppp_handle h, int s, const double *y, size_t k, double *xyz)
     LAUNCH(h, "k_eval_api", k_eval_api, (unsigned)((k + 127) / 128), 128, 0, h->meta.p, h->node_x.p, h->node_y.p, h->node_z.p,
            h->node_start.p, h->node_cnt.p, s, dq, (int)k, dout);
     HIPCHK(h, hipMemcpyAsync(xyz, dout, k * 24, hipMemcpyDeviceToHost, h->stream));
-    h->meta_in_flight = false;
+    h->meta_in_flight = false; h->meta_fresh = false;
     rc = fetch_meta(h);
     if (rc) return rc;
     if (h->hmeta.api_flag == DERR_DOMAIN) return fail(h, PPP_ERR_DOMAIN, "y outside [miny, bigy] (GSL_EDOM)");
@@ -2787,7 +2916,7 @@ int ppp_insert_point(ppp_handle h, const int *indices, size_t n, float plane_x, 
     if (n) HIPCHK(h, hipMemcpyAsync(didx, indices, n * 4, hipMemcpyHostToDevice, h->stream));
     LAUNCH(h, "k_insert_api", k_insert_api, 1, 256, slice_lds_bytes(capb), h->X.p, h->Y.p, h->Z.p, (int)h->n, didx, (int)n, plane_x,
            h->P.pairing, capb, h->meta.p, dy, dz, capb);
-    h->meta_in_flight = false;
+    h->meta_in_flight = false; h->meta_fresh = false;
     int rc = fetch_meta(h);
     if (rc) return rc;
     if (h->hmeta.api_flag == DERR_SLICE) return fail(h, PPP_ERR_SLICE, "insert_point: empty right side (the reference crashes here)");

@@ -15,8 +15,10 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -156,17 +158,22 @@ extern "C" {
 
 void ppp_free(void *p) { free(p); }
 
-static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoint[7])
-{
-    if (!path || !xyz || !n) return PPP_ERR_ARG;
-    *xyz = nullptr; *n = 0;
-    std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) return PPP_ERR_IO;
+/* the header of a PCD v0.7 file, checked: where the payload starts, how many bytes follow it, where x, y, z sit in a record */
+struct PcdHeader {
     std::vector<Field> fields;
-    size_t points = 0, width = 0, height = 1;
-    bool have_points = false;
+    size_t points = 0, remaining = 0;
     float vp[7] = {0, 0, 0, 1, 0, 0, 0};
-    std::string data_kind, line;
+    std::string data_kind;
+    std::streamoff data_pos = 0;
+    int off = 0, ix = -1, iy = -1, iz = -1;
+};
+
+static int parse_pcd_header(std::ifstream &f, PcdHeader &H)
+{
+    std::vector<Field> &fields = H.fields;
+    size_t width = 0, height = 1;
+    bool have_points = false;
+    std::string line;
     while (std::getline(f, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         if (line.empty() || line[0] == '#') continue;
@@ -180,19 +187,19 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
         else if (key == "COUNT") { for (auto &fd : fields) ls >> fd.count; }
         else if (key == "WIDTH") ls >> width;
         else if (key == "HEIGHT") ls >> height;
-        else if (key == "VIEWPOINT") { for (int i = 0; i < 7; ++i) ls >> vp[i]; }
-        else if (key == "POINTS") { ls >> points; have_points = true; }
-        else if (key == "DATA") { ls >> data_kind; break; }
+        else if (key == "VIEWPOINT") { for (int i = 0; i < 7; ++i) ls >> H.vp[i]; }
+        else if (key == "POINTS") { ls >> H.points; have_points = true; }
+        else if (key == "DATA") { ls >> H.data_kind; break; }
     }
-    if (!have_points) points = width * height;
-    if (fields.empty() || data_kind.empty()) return PPP_ERR_IO;
+    if (!have_points) H.points = width * height;
+    if (fields.empty() || H.data_kind.empty()) return PPP_ERR_IO;
     /* bytes left after the header: sizes the header (or a compressed block) claims beyond that are refused before
        anything is allocated for them */
-    const std::streamoff data_pos = f.tellg();
+    H.data_pos = f.tellg();
     f.seekg(0, std::ios::end);
-    const size_t remaining = (size_t)std::max<std::streamoff>(0, f.tellg() - data_pos);
-    f.seekg(data_pos);
-    int off = 0, ix = -1, iy = -1, iz = -1;
+    H.remaining = (size_t)std::max<std::streamoff>(0, f.tellg() - H.data_pos);
+    f.seekg(H.data_pos);
+    int off = 0;
     for (size_t i = 0; i < fields.size(); ++i) {
         /* PCL's field sizes are 1, 2, 4 or 8 bytes; a negative or absurd SIZE / COUNT would turn the record offsets below
            into reads outside the record */
@@ -202,16 +209,58 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
         if ((long long)off + step > (1ll << 30)) return PPP_ERR_IO;
         fields[i].offset = off;
         off += (int)step;
-        if (fields[i].name == "x") ix = (int)i;
-        if (fields[i].name == "y") iy = (int)i;
-        if (fields[i].name == "z") iz = (int)i;
+        if (fields[i].name == "x") H.ix = (int)i;
+        if (fields[i].name == "y") H.iy = (int)i;
+        if (fields[i].name == "z") H.iz = (int)i;
     }
-    if (ix < 0 || iy < 0 || iz < 0) return PPP_ERR_IO;
-    for (int q : {ix, iy, iz}) { /* x, y, z are read as F4 / F8 (or an integer type of their size) from inside the record */
+    H.off = off;
+    if (H.ix < 0 || H.iy < 0 || H.iz < 0) return PPP_ERR_IO;
+    for (int q : {H.ix, H.iy, H.iz}) { /* x, y, z are read as F4 / F8 (or an integer type of their size) from inside the record */
         if (fields[q].offset < 0 || fields[q].offset + fields[q].size > off) return PPP_ERR_IO;
     }
-    if (data_kind == "binary" && (points > remaining || (size_t)off * points > remaining)) return PPP_ERR_IO;
-    if (data_kind == "ascii" && points > remaining) return PPP_ERR_IO; /* a point takes at least one byte */
+    if (H.data_kind == "binary" && (H.points > H.remaining || (size_t)off * H.points > H.remaining)) return PPP_ERR_IO;
+    if (H.data_kind == "ascii" && H.points > H.remaining) return PPP_ERR_IO; /* a point takes at least one byte */
+    if (off <= 0 || H.points > ((size_t)1 << 40)) return PPP_ERR_IO;
+    return PPP_OK;
+}
+
+static int probe_pcd_impl(const char *path, ppp_pcd_layout *L)
+{
+    if (!path || !L) return PPP_ERR_ARG;
+    memset(L, 0, sizeof(*L));
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return PPP_ERR_IO;
+    PcdHeader H;
+    const int rc = parse_pcd_header(f, H);
+    if (rc != PPP_OK) return rc;
+    if (H.data_kind == "ascii") L->data_kind = 0;
+    else if (H.data_kind == "binary") L->data_kind = 1;
+    else if (H.data_kind == "binary_compressed") L->data_kind = 2;
+    else return PPP_ERR_UNSUPPORTED;
+    const Field &fx = H.fields[H.ix], &fy = H.fields[H.iy], &fz = H.fields[H.iz];
+    L->points = H.points;
+    L->record_bytes = (size_t)H.off;
+    L->x_offset = fx.offset; L->y_offset = fy.offset; L->z_offset = fz.offset;
+    L->xyz_float32 = fx.type == 'F' && fx.size == 4 && fy.type == 'F' && fy.size == 4 && fz.type == 'F' && fz.size == 4;
+    L->data_offset = (long long)H.data_pos;
+    memcpy(L->viewpoint, H.vp, sizeof(H.vp));
+    return PPP_OK;
+}
+
+static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoint[7])
+{
+    if (!path || !xyz || !n) return PPP_ERR_ARG;
+    *xyz = nullptr; *n = 0;
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return PPP_ERR_IO;
+    PcdHeader H;
+    { const int rc = parse_pcd_header(f, H); if (rc != PPP_OK) return rc; }
+    const std::vector<Field> &fields = H.fields;
+    const size_t points = H.points, remaining = H.remaining;
+    const float *vp = H.vp;
+    const std::string &data_kind = H.data_kind;
+    const int off = H.off, ix = H.ix, iy = H.iy, iz = H.iz;
+    std::string line;
     uint32_t csize = 0, usize = 0;
     if (data_kind == "binary_compressed") {
         /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream.  Both sizes are checked against the
@@ -224,7 +273,6 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
         if ((size_t)csize + 8 > remaining || (size_t)usize > (size_t)csize * 90 + 64) return PPP_ERR_IO;
         if (off <= 0 || points > (size_t)usize || (size_t)usize != (size_t)off * points) return PPP_ERR_IO;
     }
-    if (off <= 0 || points > ((size_t)1 << 40)) return PPP_ERR_IO;
     float *out = (float *)malloc(sizeof(float) * 3 * std::max<size_t>(points, 1));
     if (!out) return PPP_ERR_IO;
     if (data_kind == "ascii") {
@@ -305,23 +353,24 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
     } else if (data_kind == "binary_compressed") {
         /* pcl::PCDReader: uint32 compressed size, uint32 uncompressed size, LZF stream; the decoded block is
            field-major (all x, then all y, ...) */
-        std::vector<unsigned char> comp(csize), raw(usize);
-        f.read((char *)comp.data(), (std::streamsize)csize);
+        std::unique_ptr<unsigned char[]> comp(new unsigned char[(size_t)csize + 1]), raw(new unsigned char[(size_t)usize + 1]); /* (no zero fill) */
+        f.read((char *)comp.get(), (std::streamsize)csize);
         if ((size_t)f.gcount() != (size_t)csize) { free(out); return PPP_ERR_IO; }
-        if (usize && lzf_decompress(comp.data(), csize, raw.data(), usize) != usize) { free(out); return PPP_ERR_IO; }
+        if (usize && lzf_decompress(comp.get(), csize, raw.get(), usize) != usize) { free(out); return PPP_ERR_IO; }
         const int idx3[3] = {ix, iy, iz};
         for (int d = 0; d < 3; ++d) {
             const Field &fd = fields[idx3[d]];
             const size_t per = (size_t)fd.size * std::max(1, fd.count);
-            const unsigned char *base = raw.data() + (size_t)fd.offset * points; /* blocks follow the record order */
-            for (size_t i = 0; i < points; ++i) out[3 * i + d] = (float)read_scalar(base + i * per, fd.size, fd.type);
+            const unsigned char *base = raw.get() + (size_t)fd.offset * points; /* blocks follow the record order */
+            if (fd.type == 'F' && fd.size == 4) for (size_t i = 0; i < points; ++i) memcpy(out + 3 * i + d, base + i * per, 4);
+            else for (size_t i = 0; i < points; ++i) out[3 * i + d] = (float)read_scalar(base + i * per, fd.size, fd.type);
         }
     } else {
         free(out);
         return PPP_ERR_UNSUPPORTED;
     }
     *xyz = out; *n = points;
-    if (viewpoint) memcpy(viewpoint, vp, sizeof(vp));
+    if (viewpoint) memcpy(viewpoint, vp, 7 * sizeof(float));
     return PPP_OK;
 }
 
@@ -507,17 +556,32 @@ static int write_path_file_impl(const char *path, const float *wp6, size_t W)
         return PPP_ERR_IO;
     }
     const size_t per = 6 * 16 + 1; /* "-1.23457e-38 " is 13 characters */
-    std::vector<char> text(std::max<size_t>(W, 1) * per);
-    char *o = text.data();
-    for (size_t w = 0; w < W; ++w) {
-        for (int i = 0; i < 6; i++) {
-            o = format_g6(o, wp6[6 * w + i]);
-            *o++ = ' ';
+    /* long lists are formatted by several threads, each its own run of waypoints into its own text; written in order */
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = W >= 16384 ? std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), W / 8192)) : 1;
+    std::vector<std::unique_ptr<char[]>> text(parts);
+    std::vector<size_t> len(parts, 0);
+    auto run = [&](size_t pi) {
+        const size_t w0 = W * pi / parts, w1 = W * (pi + 1) / parts;
+        text[pi].reset(new char[std::max<size_t>(w1 - w0, 1) * per]);
+        char *o = text[pi].get();
+        for (size_t w = w0; w < w1; ++w) {
+            for (int i = 0; i < 6; i++) {
+                o = format_g6(o, wp6[6 * w + i]);
+                *o++ = ' ';
+            }
+            *o++ = '\n';
         }
-        *o++ = '\n';
+        len[pi] = (size_t)(o - text[pi].get());
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t pi = 1; pi < parts; ++pi) th.emplace_back(run, pi);
+        run(0);
+        for (auto &t : th) t.join();
     }
-    const size_t len = (size_t)(o - text.data());
-    const bool ok = fwrite(text.data(), 1, len, f) == len;
+    bool ok = true;
+    for (size_t pi = 0; pi < parts && ok; ++pi) ok = fwrite(text[pi].get(), 1, len[pi], f) == len[pi];
     return (fclose(f) == 0 && ok) ? PPP_OK : PPP_ERR_IO;
 }
 
@@ -526,6 +590,10 @@ static int write_path_file_impl(const char *path, const float *wp6, size_t W)
 int ppp_load_pcd(const char *path, float **xyz, size_t *n, float viewpoint[7])
 {
     try { return load_pcd_impl(path, xyz, n, viewpoint); } catch (...) { if (xyz) *xyz = nullptr; if (n) *n = 0; return PPP_ERR_IO; }
+}
+int ppp_pcd_probe(const char *path, ppp_pcd_layout *layout)
+{
+    try { return probe_pcd_impl(path, layout); } catch (...) { return PPP_ERR_IO; }
 }
 int ppp_save_pcd(const char *path, const float *xyz, size_t n, size_t stride_floats, const float viewpoint[7], int binary)
 {

@@ -1583,6 +1583,22 @@ PPP_KERNEL void __launch_bounds__(256) k_insert_api(const float *__restrict__ X,
     if (threadIdx.x == 0) { m->api_cnt = mm; m->api_flag = 0; }
 }
 
+/* ppp_get_nodes: the knots of every slice, packed (slice s at off[s], x | y | z planes of `total` floats each), for ONE copy to the
+   host -- the slices' segments lie cap_el apart in the knot arrays (window path) and are a quarter full */
+PPP_KERNEL void __launch_bounds__(256) k_nodes_pack(const int *__restrict__ start, const int *__restrict__ off, int S, int total,
+                                                    const float *__restrict__ nx, const float *__restrict__ ny, const float *__restrict__ nz,
+                                                    float *__restrict__ out)
+{
+    const int s = (int)blockIdx.x;
+    if (s >= S) return;
+    const int st = start[s], o = off[s], cnt = off[s + 1] - o;
+    for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) {
+        out[o + i] = nx[st + i];
+        out[total + o + i] = ny[st + i];
+        out[2 * total + o + i] = nz[st + i];
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* a9: getPath sampling (path_translation_alg.cpp:149-169)              */
 /* ------------------------------------------------------------------ */

@@ -79,7 +79,7 @@ EXPORTS = [
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
-    "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse",
+    "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse", "ppp_set_cloud_pcd", "ppp_pcd_probe",
 ]
 
 
@@ -173,6 +173,8 @@ def lib():
         L.ppp_spline_destroy.argtypes = [vp]
         L.ppp_set_fast_path.argtypes = [vp, C.c_int]
         L.ppp_set_plan_reuse.argtypes = [vp, C.c_int]
+        L.ppp_set_cloud_pcd.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_float)]
+        L.ppp_pcd_probe.argtypes = [C.c_char_p, C.c_void_p]
         L.ppp_get_fast_path.argtypes = [vp, ip]
         _lib = L
     return _lib
@@ -209,6 +211,20 @@ def load_pcd(path):
     xyz = np.ctypeslib.as_array(p, shape=(max(n.value, 1) * 3,))[: n.value * 3].reshape(-1, 3).copy()
     L.ppp_free(p)
     return xyz, vp
+
+
+class PcdLayout(C.Structure):
+    _fields_ = [("data_kind", C.c_int), ("points", C.c_size_t), ("record_bytes", C.c_size_t), ("x_offset", C.c_int), ("y_offset", C.c_int),
+                ("z_offset", C.c_int), ("xyz_float32", C.c_int), ("data_offset", C.c_longlong), ("viewpoint", C.c_float * 7)]
+
+
+def pcd_probe(path):
+    """The header of a PCD file: ppp_pcd_layout (data_kind 0 ascii / 1 binary / 2 binary_compressed, points, record layout)."""
+    lay = PcdLayout()
+    rc = lib().ppp_pcd_probe(path.encode(), C.byref(lay))
+    if rc:
+        raise PPPError(rc, "cannot read PCD %s" % path)
+    return lay
 
 
 def save_pcd(path, xyz, viewpoint=None, binary=True):
@@ -374,6 +390,14 @@ class Engine:
         vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
         self._chk(self.L.ppp_set_cloud(self.h, xyz.ctypes.data, xyz.shape[0], xyz.shape[1] * 4, vp))
         self.n = xyz.shape[0]
+
+    def set_cloud_pcd(self, path):
+        """The constructors' loadPCDFile + scale loop in one call: the file goes straight to HBM.  Returns (n, viewpoint[7])."""
+        n = C.c_size_t()
+        vp = np.zeros(7, np.float32)
+        self._chk(self.L.ppp_set_cloud_pcd(self.h, path.encode(), C.byref(n), _f(vp)))
+        self.n = n.value
+        return n.value, vp
 
     def range_interval(self, min_x, max_x):
         """(lo, hi, S): the planner-unit x interval this handle's slice range indexes for a cloud with these x bounds."""

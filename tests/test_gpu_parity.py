@@ -399,6 +399,71 @@ def test_connect_cli_end_to_end(engine_mod, oracle_mod, tmp_path, dynamic, remov
             assert os.path.exists(str(tmp_path / "smooth_workpiece.pcd"))
 
 
+def test_set_cloud_pcd_streams_the_file_into_hbm(engine_mod, tmp_path):
+    """ppp_set_cloud_pcd: `DATA binary` records with consecutive float32 x y z go to HBM in pieces through the handle's two pinned
+    buffers (here 20 MB of 16-byte and 24-byte records: three pieces, x at offset 0 and at offset 4) and the conversion kernel
+    picks the coordinates out of them; every other flavour takes the host loader.  The resident cloud must be, bit for bit,
+    what ppp_set_cloud makes of ppp_load_pcd's points; the same handle then takes a small file and a refused one."""
+    import os
+    rng = np.random.default_rng(31)
+    n = 1_300_000
+    pts = (rng.random((n, 3), dtype=np.float32) * np.float32([3.0, 0.24, 0.05])).astype(np.float32)
+    pts[5] = [np.nan, 0.1, 0.2]
+    e = engine_mod.Engine()
+    ref = engine_mod.Engine()
+
+    def check(path, want_pts, vp_want=None):
+        got_n, vp = e.set_cloud_pcd(path)
+        xyz, vp_file = engine_mod.load_pcd(path)
+        assert np.array_equal(xyz.view(np.uint32), np.ascontiguousarray(want_pts, np.float32).view(np.uint32))
+        ref.set_cloud(xyz, viewpoint=vp_file[:3])
+        assert got_n == len(want_pts) == e.n == ref.n
+        a, b = e.cloud(), ref.cloud()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(vp, vp_file) and (vp_want is None or list(vp) == vp_want)
+        assert all(np.array_equal(u, v) for u, v in zip(e.minmax(), ref.minmax()))
+
+    rec = np.zeros(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgb", "<u4")])
+    rec["x"], rec["y"], rec["z"], rec["rgb"] = pts[:, 0], pts[:, 1], pts[:, 2], 0x00ff00
+    p = str(tmp_path / "xyzrgb.pcd")
+    open(p, "wb").write(("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+                         "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0.5 -1 2 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n)).encode() + rec.tobytes())
+    assert engine_mod.pcd_probe(p).record_bytes == 16
+    check(p, pts, [0.5, -1, 2, 1, 0, 0, 0])
+    rec2 = np.zeros(n, dtype=[("rgb", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("normal", "<f4", (2,))])
+    rec2["x"], rec2["y"], rec2["z"] = pts[::-1, 0], pts[::-1, 1], pts[::-1, 2]
+    p2 = str(tmp_path / "rgbxyz.pcd")
+    open(p2, "wb").write(("VERSION 0.7\nFIELDS rgb x y z normal\nSIZE 4 4 4 4 4\nTYPE U F F F F\nCOUNT 1 1 1 1 2\nWIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA binary\n" % (n, n)).encode()
+                         + rec2.tobytes())
+    lay = engine_mod.pcd_probe(p2)
+    assert (lay.record_bytes, lay.x_offset) == (24, 4)
+    check(p2, pts[::-1])
+    small = pts[:40_000]
+    for mode in (True, False, "compressed"):          # packed binary (direct), ascii and compressed (host loader)
+        q = str(tmp_path / ("small_%s.pcd" % mode))
+        engine_mod.save_pcd(q, small, binary=mode)
+        check(q, small)
+    # a planner on the streamed cloud gives the list of a planner on the loaded one
+    plate, cfg = synth.make_config("small_40k")
+    q = str(tmp_path / "plate.pcd")
+    engine_mod.save_pcd(q, plate, binary=True)
+    for eng in (e, ref):
+        eng.set_params(tool_radius=6.0)
+    e.set_cloud_pcd(q); ref.set_cloud(plate)
+    for eng in (e, ref):
+        eng.gen_path(); eng.get_path()
+    assert np.array_equal(e.waypoints().view(np.uint32), ref.waypoints().view(np.uint32))
+    # refused files leave an error, not a half-loaded cloud
+    open(p, "r+b").truncate(os.path.getsize(p) - 100)
+    with pytest.raises(engine_mod.PPPError):
+        e.set_cloud_pcd(p)
+    with pytest.raises(engine_mod.PPPError):
+        e.set_cloud_pcd(str(tmp_path / "missing.pcd"))
+    e.set_cloud_pcd(q)
+    e.gen_path(); e.get_path()
+    assert np.array_equal(e.waypoints().view(np.uint32), ref.waypoints().view(np.uint32))
+
+
 def test_planners_of_one_process_share_engine_handles(engine_mod, tmp_path):
     """A planner per workpiece, one after the other in one process (examples/workpieces.cpp): the second and third take the
     handle the one before gave back (ppp::HandlePool in ppp_planner.hpp).  Nothing of an earlier workpiece may show: every

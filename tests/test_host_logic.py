@@ -305,6 +305,35 @@ def test_pcd_with_extra_fields_and_double_xyz(engine_mod, tmp_path):
     assert np.allclose(xyz[:, 0], rec["x"]) and np.allclose(xyz[:, 1], 0.5) and np.allclose(xyz[:, 2], rec["z"])
 
 
+def test_pcd_probe_reports_the_record_layout(engine_mod, tmp_path):
+    """ppp_pcd_probe: the header alone -- what ppp_set_cloud_pcd decides on (records streamed straight to HBM only for
+    `DATA binary` with x, y, z as consecutive float32 fields)."""
+    n = 7
+    rec = np.zeros(n, dtype=[("rgb", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("curvature", "<f4"), ("label", "<u2"), ("pad", "<u2")])
+    p = tmp_path / "a.pcd"
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS rgb x y z curvature label pad\nSIZE 4 4 4 4 4 2 2\nTYPE U F F F F U U\nCOUNT 1 1 1 1 1 1 1\n"
+           "WIDTH %d\nHEIGHT 1\nVIEWPOINT 1 2 3 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n))
+    p.write_bytes(hdr.encode() + rec.tobytes())
+    lay = engine_mod.pcd_probe(str(p))
+    assert (lay.data_kind, lay.points, lay.record_bytes, lay.x_offset, lay.y_offset, lay.z_offset, lay.xyz_float32) == (1, n, 24, 4, 8, 12, 1)
+    assert lay.data_offset == len(hdr) and list(lay.viewpoint) == [1, 2, 3, 1, 0, 0, 0]
+    rec8 = np.zeros(n, dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8")])
+    hdr8 = "VERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA binary\n" % (n, n)
+    p.write_bytes(hdr8.encode() + rec8.tobytes())
+    lay = engine_mod.pcd_probe(str(p))
+    assert (lay.data_kind, lay.record_bytes, lay.xyz_float32, lay.z_offset) == (1, 24, 0, 16)
+    pts = np.arange(3 * n, dtype=np.float32).reshape(n, 3)
+    for mode, kind in ((False, 0), (True, 1), ("compressed", 2)):
+        engine_mod.save_pcd(str(p), pts, binary=mode)
+        lay = engine_mod.pcd_probe(str(p))
+        assert (lay.data_kind, lay.points, lay.record_bytes, lay.x_offset, lay.xyz_float32) == (kind, n, 12, 0, 1)
+    p.write_bytes(hdr8.encode() + rec8.tobytes()[:-1])          # a record short: refused by the header check already
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.pcd_probe(str(p))
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.pcd_probe(str(tmp_path / "missing.pcd"))
+
+
 def test_pcd_errors(engine_mod, tmp_path):
     with pytest.raises(engine_mod.PPPError) as ei:
         engine_mod.load_pcd(str(tmp_path / "missing.pcd"))
