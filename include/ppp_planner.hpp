@@ -98,8 +98,9 @@ public:
     }
 
 private:
-    static std::mutex &mu() { static std::mutex m; return m; }
-    static std::vector<std::pair<int, ppp_handle>> &free_list() { static std::vector<std::pair<int, ppp_handle>> f; return f; }
+    /* (never destroyed: a planner with static storage may hand its handle back after main() has returned) */
+    static std::mutex &mu() { static std::mutex *m = new std::mutex; return *m; }
+    static std::vector<std::pair<int, ppp_handle>> &free_list() { static auto *f = new std::vector<std::pair<int, ppp_handle>>; return *f; }
     static size_t &reused() { static size_t r = 0; return r; }
     static size_t &limit()
     {

@@ -55,7 +55,9 @@ size_t lzf_decompress(const unsigned char *in, size_t in_len, unsigned char *out
         if (ctrl < 32) {
             ctrl++;
             if (op + ctrl > out_end || ip + ctrl > in_end) return 0;
-            memcpy(op, ip, ctrl);
+            /* a run is 1..32 bytes: away from the buffers' ends two fixed 16-byte moves beat a variable-length copy */
+            if ((size_t)(out_end - op) >= 32 && (size_t)(in_end - ip) >= 32) { memcpy(op, ip, 16); memcpy(op + 16, ip + 16, 16); }
+            else memcpy(op, ip, ctrl);
             op += ctrl; ip += ctrl;
         } else {
             size_t len = ctrl >> 5;
@@ -65,7 +67,8 @@ size_t lzf_decompress(const unsigned char *in, size_t in_len, unsigned char *out
             len += 2;
             if (dist > (size_t)(op - out) || op + len > out_end) return 0;
             const unsigned char *ref = op - dist;
-            for (size_t k = 0; k < len; ++k) op[k] = ref[k]; /* may overlap: byte by byte */
+            if (dist >= len) memcpy(op, ref, len);
+            else for (size_t k = 0; k < len; ++k) op[k] = ref[k]; /* overlapping: byte by byte */
             op += len;
         }
     }
@@ -294,30 +297,64 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
             cols += std::max(1, fields[i].count);
         }
         const int last_col = std::max(col_x, std::max(col_y, col_z));
-        size_t got = 0;
-        const char *p = text, *end = text + len;
-        while (got < points && p < end) {
-            const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
-            if (!eol) eol = end;
-            float v[3] = {NAN, NAN, NAN};
-            int col = 0;
-            const char *q = p;
-            bool any = false;
-            while (col <= last_col) { /* (columns are separated by blanks; any control character counts as one) */
-                while (q < eol && (unsigned char)*q <= ' ') ++q;
-                if (q >= eol) break;
-                any = true;
-                if (col == col_x || col == col_y || col == col_z) {
-                    const char *te;
-                    v[col == col_x ? 0 : (col == col_y ? 1 : 2)] = parse_float_token(q, eol, &te);
-                    q = te;
-                } else while (q < eol && (unsigned char)*q > ' ') ++q;
-                ++col;
+        /* rows of [p, end): parsed into dst (at most max_rows of them) or, without dst, counted -- a line with no token is no row */
+        auto walk = [&](const char *p, const char *end, float *dst, size_t max_rows) -> size_t {
+            size_t got = 0;
+            while (got < max_rows && p < end) {
+                const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+                if (!eol) eol = end;
+                const char *q = p;
+                p = eol < end ? eol + 1 : end;
+                if (!dst) {
+                    while (q < eol && (unsigned char)*q <= ' ') ++q;
+                    if (q < eol) ++got;
+                    continue;
+                }
+                float v[3] = {NAN, NAN, NAN};
+                int col = 0;
+                bool any = false;
+                while (col <= last_col) { /* (columns are separated by blanks; any control character counts as one) */
+                    while (q < eol && (unsigned char)*q <= ' ') ++q;
+                    if (q >= eol) break;
+                    any = true;
+                    if (col == col_x || col == col_y || col == col_z) {
+                        const char *te;
+                        v[col == col_x ? 0 : (col == col_y ? 1 : 2)] = parse_float_token(q, eol, &te);
+                        q = te;
+                    } else while (q < eol && (unsigned char)*q > ' ') ++q;
+                    ++col;
+                }
+                if (!any) continue; /* an empty line */
+                memcpy(dst + 3 * got, v, 12);
+                ++got;
             }
-            p = eol < end ? eol + 1 : end;
-            if (!any) continue; /* an empty line */
-            memcpy(out + 3 * got, v, 12);
-            ++got;
+            return got;
+        };
+        size_t got = 0;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t parts = len >= ((size_t)4 << 20) ? std::min<size_t>(hw ? hw : 1, 8) : 1;
+        if (parts <= 1) got = walk(text, text + len, out, points);
+        else { /* big files: the text cut at line ends into one piece per thread; rows counted first, so every piece knows where its rows go */
+            std::vector<const char *> cut(parts + 1);
+            cut[0] = text; cut[parts] = text + len;
+            for (size_t t = 1; t < parts; ++t) {
+                const char *c = std::max<const char *>(cut[t - 1], text + len * t / parts);
+                const char *nl = (const char *)memchr(c, '\n', (size_t)(text + len - c));
+                cut[t] = nl ? nl + 1 : text + len;
+            }
+            std::vector<size_t> rows(parts, 0), first(parts + 1, 0);
+            auto on_all = [&](auto &&fn) {
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < parts; ++t) th.emplace_back(fn, t);
+                fn((size_t)0);
+                for (auto &x : th) x.join();
+            };
+            on_all([&](size_t t) { rows[t] = walk(cut[t], cut[t + 1], nullptr, (size_t)-1); });
+            for (size_t t = 0; t < parts; ++t) first[t + 1] = first[t] + rows[t];
+            on_all([&](size_t t) {
+                if (first[t] < points) walk(cut[t], cut[t + 1], out + 3 * first[t], std::min(rows[t], points - first[t]));
+            });
+            got = std::min(first[parts], points); /* (rows beyond POINTS are ignored, as in the single walk) */
         }
         free(text);
         if (got != points) { free(out); return PPP_ERR_IO; }
@@ -518,8 +555,13 @@ static char *format_g6(char *o, float vf)
             if (!exact && std::fabs(fr - 0.5) < 1e-7) break; /* too close to call here */
             if (fr > 0.5 || (fr == 0.5 && (n & 1))) ++n; /* to nearest, ties to even */
             if (n >= 1000000) { n = 100000; ++X; }
-            char d[6];
-            for (int i = 5; i >= 0; --i) { d[i] = (char)('0' + n % 10); n /= 10; }
+            char d[6]; /* the six digits, two at a time */
+            {
+                static const char PAIRS[201] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+                                               "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+                const unsigned u = (unsigned)n, hi = u / 10000, lo = u % 10000;
+                memcpy(d, PAIRS + 2 * hi, 2); memcpy(d + 2, PAIRS + 2 * (lo / 100), 2); memcpy(d + 4, PAIRS + 2 * (lo % 100), 2);
+            }
             int last = 5;
             while (last > 0 && d[last] == '0') --last; /* %g drops trailing zeros */
             if (X < -4 || X >= 6) {

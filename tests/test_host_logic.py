@@ -305,6 +305,35 @@ def test_pcd_with_extra_fields_and_double_xyz(engine_mod, tmp_path):
     assert np.allclose(xyz[:, 0], rec["x"]) and np.allclose(xyz[:, 1], 0.5) and np.allclose(xyz[:, 2], rec["z"])
 
 
+def test_big_ascii_pcd_is_cut_into_pieces_at_line_ends(engine_mod, tmp_path):
+    """Ascii files of 4 MB and more are parsed by several threads, the text cut at line ends: rows counted per piece first, then
+    parsed to their places.  Blank and blank-only lines are no rows wherever they fall, rows beyond POINTS are ignored, a file
+    with fewer rows than POINTS is refused -- as in the single walk small files take."""
+    rng = np.random.default_rng(8)
+    n = 260_000
+    pts = (rng.standard_normal((n, 3)) * [1.5, 0.1, 0.02]).astype(np.float32)
+    rows = ["%.9g %.9g %.9g 4.2e+06" % tuple(r) for r in pts]
+    hdr = ("# .PCD v0.7\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+           "POINTS %d\nDATA ascii\n")
+    body = []
+    blanks = set(rng.integers(0, n, 3000).tolist())
+    for i, r in enumerate(rows):
+        if i in blanks:
+            body.append("" if i % 2 else "  \t ")
+        body.append(r)
+    p = tmp_path / "big.pcd"
+    p.write_text(hdr % (n, n) + "\n".join(body) + "\n")
+    assert p.stat().st_size > (8 << 20)
+    xyz, _ = engine_mod.load_pcd(str(p))
+    assert np.array_equal(xyz.view(np.uint32), pts.view(np.uint32))
+    p.write_text(hdr % (n - 1000, n - 1000) + "\n".join(body) + "\n")      # more rows than POINTS
+    xyz, _ = engine_mod.load_pcd(str(p))
+    assert np.array_equal(xyz.view(np.uint32), pts[: n - 1000].view(np.uint32))
+    p.write_text(hdr % (n + 1, n + 1) + "\n".join(body) + "\n")            # one row short
+    with pytest.raises(engine_mod.PPPError):
+        engine_mod.load_pcd(str(p))
+
+
 def test_pcd_probe_reports_the_record_layout(engine_mod, tmp_path):
     """ppp_pcd_probe: the header alone -- what ppp_set_cloud_pcd decides on (records streamed straight to HBM only for
     `DATA binary` with x, y, z as consecutive float32 fields)."""
