@@ -226,6 +226,14 @@ struct ppp_handle_s {
     size_t pcd_stage_bytes = 0;
     hipEvent_t pcd_ev[2] = {nullptr, nullptr}; /* ... and the event behind each one's copy */
     bool meta_in_flight = false;
+    /* A cloud set while the handle holds a window plan of an earlier cloud of the same size and parameters does not wait for its
+       bounds: the conversion pass is enqueued, the plan stays, and the pass of the new cloud may be enqueued right
+       behind it -- the device checks walk length, pad, bounds and capacities against the record that pass leaves, and hands a
+       pass back whose plan does not fit.  plan_deferred: that record has not been read yet (resolve_deferred does, at the first
+       call that is not one of the three enqueue-only entry points). */
+    bool plan_deferred = false, deferred_census = false;
+    bool rec_current = false;   /* plan_auto holds the record of the resident cloud (it came through k_ingest_minmax and was not altered since) */
+    bool plan_walk_ok = false;  /* the window plan's S, pad and plane table are the device's own, bit for bit (plan_window: census that came with the cloud, or inherited) */
     bool meta_fresh = false; /* hmeta is the device's block as of now: nothing was launched on this handle since it was fetched (every launch clears it) */
     bool chain_calls = false;       /* GenPath is followed by getPath in the same enqueue: its meta copy is skipped */
     float *out2 = nullptr;          /* batched form: the emitting launch also writes the list here (at most out2_cap rows) */
@@ -532,6 +540,7 @@ int win_pick_threads(const ppp_handle h, long long wgs)
 int plan_window(ppp_handle h, int S, double per)
 {
     h->win_path = false;
+    h->plan_walk_ok = false;
     const int step = (int)(h->P.tool_radius * 2);
     if (!h->win_allowed || h->win_disabled || getenv("PPP_NO_WINDOW_PATH")) return PPP_OK;
     if (h->P.dynamic_adjustment || h->aligned || h->big_path) return PPP_OK; /* (both pairings: kd and v1's brute-force greedy) */
@@ -561,6 +570,7 @@ int plan_window(ppp_handle h, int S, double per)
                          h->sb == 0 && h->se == S;
     h->auto_valid = false; h->auto_px_only = false;
     h->plan_inherited = false;
+    h->plan_walk_ok = from_auto || inherit;
     int *census = nullptr;
     std::vector<int> inherited;
     if (from_auto) census = (int *)(h->pin + PIN_CENSUS);
@@ -697,6 +707,7 @@ WinArgs win_args(const ppp_handle h)
     A.wp_cnt = h->wp_cnt.p; A.wp_off = h->wp_off.p; A.tail = h->tail.p;
     A.wps_xyz = h->wps_xyz.p; A.wps_normal = h->wps_normal.p; A.wps_nn = h->wps_nn.p; A.wps_pre = h->wps_pre.p; A.wps_rec = h->wps_rec.p;
     A.wp_pre = h->wp_pre.p; A.wp_smooth = h->wp_smooth.p; A.wp_out = h->wp_out.p; A.out2 = h->out2; A.out2_cap = h->out2_cap;
+    A.plan_rec = (h->rec_current && h->plan_walk_ok) ? h->plan_auto.p : nullptr;
     A.meta_host = h->hmeta_pinned; A.fin_ticket = h->fin_ticket.p; /* (a member of a batch of several publishes into the batch's pinned array: upload_members_win) */
     return A;
 }
@@ -1040,13 +1051,28 @@ int enqueue_dynamic(ppp_handle h)
 }
 
 /* work enqueued for this handle by a batch graph runs on the lead handle's stream */
-int settle(ppp_handle h)
+int settle_streams(ppp_handle h)
 {
     if (h->pending_stream) {
         HIPCHK(h, hipStreamSynchronize(h->pending_stream));
         h->pending_stream = nullptr;
     }
     return PPP_OK;
+}
+int resolve_deferred(ppp_handle h);
+/* every entry point but the three that only enqueue a pass: nothing pending on another stream, and the plan is this cloud's */
+int settle(ppp_handle h)
+{
+    int rc = settle_streams(h);
+    if (rc == PPP_OK && h->plan_deferred) rc = resolve_deferred(h);
+    return rc;
+}
+/* ppp_run_async / ppp_gen_path_async / ppp_get_path_async: a pass may be enqueued on the plan a cloud was set under (window
+   path, same size and parameters) before that cloud's bounds have come back */
+int settle_enqueue_only(ppp_handle h)
+{
+    if (h->plan_deferred && h->planned && h->win_path) return settle_streams(h);
+    return settle(h);
 }
 
 int fetch_meta(ppp_handle h)
@@ -1157,6 +1183,7 @@ int ensure_index(ppp_handle h)
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
+    { int rcs = settle(h); if (rcs) return rcs; }
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     if (!h->index_built) { int rc = enqueue_index(h); if (rc) return rc; }
     return PPP_OK;
@@ -1185,6 +1212,18 @@ bool window_params_ok(const ppp_handle h)
    raw != nullptr: the cloud has just arrived and is converted in the same pass (k_ingest_minmax); the bounds come back reduced, in
    pinned memory, and where the window path may apply its census follows in the same stream: two launches, one wait, no copy or
    fill command (each of those costs the host 10-20 us here; this path was 150 us for 30 us of kernels) */
+/* what k_ingest_minmax (and the census behind it) left in pinned memory for the host: bounds, count, the device's walk */
+int adopt_ingest_record(ppp_handle h, bool census, bool reuse)
+{
+    const PlanAuto *rec0 = (const PlanAuto *)(h->pin + PIN_REC0), *rec1 = (const PlanAuto *)(h->pin + PIN_REC1);
+    if (rec0->S == -2) return fail(h, PPP_ERR_HIP, "the bounds of the new cloud did not arrive");
+    h->h_nvalid = rec0->fin.cnt;
+    for (int d = 0; d < 3; ++d) { h->h_mn[d] = rec0->fin.mn[d]; h->h_mx[d] = rec0->fin.mx[d]; }
+    if (census && !reuse && rec1->census == 1) { h->auto_valid = true; h->auto_S = rec1->S; h->auto_pad = rec1->pad; }
+    if (reuse && rec0->S >= 1 && rec0->S <= WIN_AUTO_SCAP) { h->auto_px_only = true; h->auto_S = rec0->S; h->auto_pad = rec0->pad; }
+    return PPP_OK;
+}
+
 int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stride_bytes = 0)
 {
     const size_t n = h->n;
@@ -1225,6 +1264,20 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
                                    (float *)(h->pin + PIN_PX), (int *)(h->pin + PIN_CENSUS));
                 HIPCHK(h, hipGetLastError());
             }
+            h->rec_current = true;
+            /* The handle's plan is a window plan for a cloud of this size and these parameters, made from the device's own walk:
+               no wait.  The plan stays and a pass of the new cloud may follow the conversion pass in the stream at once
+               (settle_enqueue_only); walk length, pad, bounds and every capacity are checked on the device against the record
+               this launch leaves (win_verify_body), and the first call that needs the host's view of the cloud reads it
+               (resolve_deferred). */
+            if (reuse && h->planned && h->win_path && h->plan_walk_ok && !h->ranged && !h->use_part && h->sb == 0 && h->se == h->S_cap &&
+                h->inh_S == h->S_cap && !getenv("PPP_NO_DEFERRED_PLAN")) {
+                h->plan_deferred = true; h->deferred_census = census;
+                h->have_cloud = true;
+                h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false; h->list_final = false;
+                h->normals_valid = false;
+                return PPP_OK;
+            }
 #ifdef PPP_TUNING
             const auto t_enq = std::chrono::steady_clock::now();
 #endif
@@ -1235,12 +1288,9 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
                 fprintf(stderr, "[ppp cold] wait for ingest%s: %.1f us\n", census ? " + census" : "", std::chrono::duration<double, std::micro>(t_syn - t_enq).count());
             }
 #endif
-            if (rec0->S == -2) return fail(h, PPP_ERR_HIP, "the bounds of the new cloud did not arrive");
-            h->h_nvalid = rec0->fin.cnt;
-            for (int d = 0; d < 3; ++d) { h->h_mn[d] = rec0->fin.mn[d]; h->h_mx[d] = rec0->fin.mx[d]; }
-            if (census && !reuse && rec1->census == 1) { h->auto_valid = true; h->auto_S = rec1->S; h->auto_pad = rec1->pad; }
-            if (reuse && rec0->S >= 1 && rec0->S <= WIN_AUTO_SCAP) { h->auto_px_only = true; h->auto_S = rec0->S; h->auto_pad = rec0->pad; }
+            { int rca = adopt_ingest_record(h, census, reuse); if (rca) return rca; }
         } else {
+            h->rec_current = false; /* (the cloud was altered on the device: the conversion pass's record is another cloud's) */
             hipLaunchKernelGGL(k_minmax<false>, dim3(g), dim3(MM_T), 0, h->stream, h->X.p, h->Y.p, h->Z.p, (int)n, h->mm_part.p, 0.f, 0.f, 0,
                                (int *)nullptr, 0.f, 0.f, (int *)nullptr);
             HIPCHK(h, hipGetLastError());
@@ -1271,6 +1321,47 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
     }
 #endif
     return make_plan(h);
+}
+
+/* The cloud was set on a plan of an earlier cloud (refresh_bounds_and_plan): now the host's view of it.  Waits for the stream
+   (the conversion pass and whatever pass was enqueued behind it), takes the record, and plans the cloud exactly as a waiting
+   ppp_set_cloud* would have.  A pass that already ran keeps its results when that plan asks for the launches and buffers the
+   pass used (the rule for a cloud of the same kind: capacities are inherited either way); else it runs again on the right plan.
+   What the device found wrong with the pass itself (WIN_FLAG_*) is in its meta block and handled where every pass's is. */
+int resolve_deferred(ppp_handle h)
+{
+    if (!h->plan_deferred) return PPP_OK;
+    h->plan_deferred = false;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const bool ran = h->gen_done, had_path = h->path_done, was_final = h->list_final;
+    auto signature = [](ppp_handle q) {
+        WinArgs A = win_args(q);
+        memset(&A.P, 0, sizeof(A.P)); /* the parameters are the same by the rule of refresh_bounds_and_plan; what of them follows the bounds is a hint */
+        A.y0 = A.yscale = A.px0 = 0.f; /* bucket mapping and lattice origin: any monotone mapping sorts alike, the origin is read from the table */
+        for (int d = 0; d < 3; ++d) A.plan_mn[d] = A.plan_mx[d] = 0.f;
+        A.plan_nvalid = 0;             /* (compared on the device against the record) */
+        A.out2 = nullptr; A.out2_cap = 0;
+        return A;
+    };
+    const WinArgs before = signature(h);
+    const bool was_window = h->win_path;
+    { int rca = adopt_ingest_record(h, h->deferred_census, true); if (rca) return rca; }
+    int rc = make_plan(h);
+    if (rc) return rc;
+    if (!ran) return PPP_OK;
+    const WinArgs after = signature(h);
+    if (was_window && h->win_path && memcmp(&before, &after, sizeof(WinArgs)) == 0) {
+        h->gen_done = true; h->path_done = had_path; h->list_final = was_final; /* (make_plan withdrew them) */
+        return PPP_OK;
+    }
+    if (getenv("PPP_WIN_DEBUG")) fprintf(stderr, "[ppp] the pass enqueued ahead of this cloud's bounds ran on another plan than the cloud's own: repeated\n");
+    ++h->internal;
+    rc = ppp_gen_path_async(h);
+    h->out2 = h->last_out2; h->out2_cap = h->last_out2_cap; /* (the caller's output buffer of the first attempt) */
+    if (rc == PPP_OK && had_path) rc = ppp_get_path_async(h);
+    h->out2 = nullptr; h->out2_cap = 0;
+    --h->internal;
+    return rc;
 }
 
 int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
@@ -1575,6 +1666,7 @@ int ppp_set_cloud_part(ppp_handle h, const float *xyz_host, size_t n_part, size_
     h->win_disabled = false;
     h->big_path = false;
     h->have_cloud = true;
+    h->rec_current = false; /* (no conversion pass of the window plan's kind: the bounds came with the call) */
     h->planned = false; h->index_built = false; h->gen_done = false; h->meta_fresh = false; h->path_done = false;
     h->normals_valid = false;
     h->drop_graph();
@@ -1948,7 +2040,7 @@ int ppp_gen_path_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcs = settle(h); if (rcs) return rcs; }
+    { int rcs = settle_enqueue_only(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->internal) { h->last_out2 = nullptr; h->last_out2_cap = 0; } /* a plain call: the list stays in the handle */
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
@@ -2006,7 +2098,7 @@ int ppp_get_path_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcs = settle(h); if (rcs) return rcs; }
+    { int rcs = settle_enqueue_only(h); if (rcs) return rcs; }
     if (!h->gen_done) return fail(h, PPP_ERR_ARG, "call ppp_gen_path_async first");
     if (h->win_path) { /* the per-waypoint half ran with the slices: offsets, compaction and getPath's list-wide second half */
         int rcw = enqueue_window_finish(h);
@@ -2081,7 +2173,7 @@ int ppp_run_async(ppp_handle h)
 {
     if (!h) return PPP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    { int rcs = settle(h); if (rcs) return rcs; }
+    { int rcs = settle_enqueue_only(h); if (rcs) return rcs; }
     if (!h->have_cloud) return fail(h, PPP_ERR_ARG, "no cloud set");
     if (!h->planned) { int rc = make_plan(h); if (rc) return rc; }
     h->last_out2 = nullptr; h->last_out2_cap = 0;
@@ -3170,6 +3262,7 @@ int ppp_smooth_sweeps(ppp_handle h, int *sweeps)
 int ppp_set_plan_reuse(ppp_handle h, int on)
 {
     if (!h) return PPP_ERR_ARG;
+    if (h->plan_deferred) { HIPCHK(h, hipSetDevice(h->device)); int rcs = settle(h); if (rcs) return rcs; } /* (a cloud set under the old setting) */
     h->plan_reuse = on != 0;
     if (!h->plan_reuse) h->inh_valid = false;
     return PPP_OK;
@@ -3194,6 +3287,7 @@ int ppp_set_fast_path(ppp_handle h, int on)
 int ppp_get_fast_path(ppp_handle h, int *active)
 {
     if (!h || !active) return PPP_ERR_ARG;
+    if (h->have_cloud) { HIPCHK(h, hipSetDevice(h->device)); int rcs = settle(h); if (rcs) return rcs; }
     if (h->have_cloud && !h->planned) { int rc = make_plan(h); if (rc) return rc; }
     *active = (h->have_cloud && h->win_path) ? 1 : 0;
     return PPP_OK;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void win_scatter_body(const WinArgs &A, const int bx)
             cnt++;
             /* the slice whose plane is nearest: within one of the lattice guess (the planes are `step` apart up to the
                rounding of the float walks and the off-lattice centre plane of the centre-out integer walk) */
-            const float fj = fminf(fmaxf(floorf((x - A.px0) * A.inv_step + 0.5f), 0.f), (float)(S - 1));
+            const float fj = fminf(fmaxf(floorf((x - s_px[0]) * A.inv_step + 0.5f), 0.f), (float)(S - 1)); /* (the table's own first plane: a pass may run on a plan made before this cloud's bounds were known) */
             const int j = (int)fj;
             const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
             const float da = fabsf(x - s_px[ja]), dj = fabsf(x - s_px[j]), db = fabsf(x - s_px[jb]);
@@ -212,7 +212,7 @@ __device__ __forceinline__ void win_scatter_staged_loop(const WinArgs &A, const 
                 mn[1] = fminf(mn[1], p[k].y); mx[1] = fmaxf(mx[1], p[k].y);
                 mn[2] = fminf(mn[2], p[k].z); mx[2] = fmaxf(mx[2], p[k].z);
                 cnt++;
-                const float fj = fminf(fmaxf(floorf((x - A.px0) * A.inv_step + 0.5f), 0.f), (float)(S - 1));
+                const float fj = fminf(fmaxf(floorf((x - s_px[0]) * A.inv_step + 0.5f), 0.f), (float)(S - 1));
                 const int j = (int)fj;
                 const int ja = j > 0 ? j - 1 : j, jb = j + 1 < S ? j + 1 : j;
                 const float da = fabsf(x - s_px[ja]), dj = fabsf(x - s_px[j]), db = fabsf(x - s_px[jb]);
@@ -727,7 +727,7 @@ __device__ __forceinline__ void win_slice_body(const WinArgs &A, const int bx)
         if (tot < 3) set_err(m, DERR_SLICE, s); /* gsl_spline_alloc needs >= 3 knots */
         int cnt = 0;
         if (kept && tot >= 1) cnt = sample_count((double)knot[0].x, (double)knot[tot - 1].x, P.trim, P.path_resolution, A.stride);
-        if (cnt > A.stride) { set_err(m, DERR_CAPACITY, s); cnt = 0; }
+        if (cnt > A.stride) { win_flag(m, WIN_FLAG_OVERFLOW); cnt = 0; } /* (the slots per slice are the plan's: one made ahead of this cloud's bounds may have fewer than its y extent needs) */
         if (tot < 3) cnt = 0;
         s_cnt = cnt;
         if (kept) A.wp_cnt[k] = cnt;
@@ -1013,8 +1013,14 @@ __device__ __forceinline__ void win_verify_body(const WinArgs &A)
             for (int d = 0; d < 3; ++d) { if (c && (rmn[d] < P.g_mn[d] || rmx[d] > P.g_mx[d])) bad = 1; rmn[d] = P.g_mn[d]; rmx[d] = P.g_mx[d]; }
             c = P.g_nvalid;
         }
-        for (int d = 0; d < 3; ++d) if (rmn[d] != A.plan_mn[d] || rmx[d] != A.plan_mx[d]) bad = 1;
-        if (c != A.plan_nvalid) bad = 1;
+        if (A.plan_rec) { /* the record the conversion pass of THIS cloud left on the device: the plan may be older than the cloud */
+            const PlanAuto R = *A.plan_rec;
+            for (int d = 0; d < 3; ++d) if (rmn[d] != R.fin.mn[d] || rmx[d] != R.fin.mx[d]) bad = 1;
+            if (c != R.fin.cnt || R.S != A.S || __float_as_int(R.pad) != __float_as_int(A.pad)) bad = 1;
+        } else {
+            for (int d = 0; d < 3; ++d) if (rmn[d] != A.plan_mn[d] || rmx[d] != A.plan_mx[d]) bad = 1;
+            if (c != A.plan_nvalid) bad = 1;
+        }
         int S = c ? slice_walk_device(P.walk, rmn[0], rmx[0], P.tool_radius, s_px, A.S, s_front, 2048) : 0;
         if (S != A.S) bad = 1;
         for (int d = 0; d < 3; ++d) { m->mn[d] = rmn[d]; m->mx[d] = rmx[d]; m->mn_ord[d] = f2ord(rmn[d]); m->mx_ord[d] = f2ord(rmx[d]); }

@@ -55,6 +55,7 @@ struct WinArgs {
     int out2_cap;
     DevMeta *meta_host; /* pinned host memory: the last workgroup of the finish launch leaves the meta block there (no copy command behind a pass) */
     int *fin_ticket;    /* arrivals of that launch's workgroups (cleared by the last) */
+    const PlanAuto *plan_rec; /* device record of the cloud's conversion pass (bounds, walk length, pad), or NULL: what the checker compares the pass with instead of plan_mn / plan_mx / plan_nvalid */
 };
 
 __host__ __device__ inline size_t win_slice_lds_bytes(int capw, int cap_el, int NB)
