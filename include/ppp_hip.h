@@ -331,7 +331,13 @@ int ppp_write_path_file(const char *path, const float *wp6, size_t W);
  * slice walk has the same length and pad, inherits those capacities (+4 %) and skips that launch -- a planner that is fed one scan
  * after the other (the constructors of the reference's planner classes: src/Path_Alg/path_slicing_alg.cpp:3-30) saves it on every
  * workpiece.  The pass checks every window against its capacity on the device; one that does not fit makes the engine plan this
- * cloud again from its own census and repeat the pass (same results, one wasted pass).  0 turns the reuse off. */
+ * cloud again from its own census and repeat the pass (same results, one wasted pass).
+ * Such a later cloud is not waited for either: while the handle holds that window plan, ppp_set_cloud* only enqueues the
+ * conversion pass and returns, and ppp_run_async / ppp_gen_path_async / ppp_get_path_async put the new cloud's pass behind it on
+ * the earlier plan; bounds, walk and capacities are checked on the device against the record the conversion pass leaves, and any
+ * other call (ppp_sync included) first reads that record and plans the cloud as a waiting ppp_set_cloud* would have -- a pass the
+ * plan did not fit is repeated by the engine.  An error of the new cloud itself (no finite point, ...) then surfaces at that
+ * call instead of at ppp_set_cloud*.  0 turns both off (PPP_NO_DEFERRED_PLAN=1 in the environment: the waiting only). */
 int ppp_set_plan_reuse(ppp_handle h, int on);
 /* The engine has two launch sequences for the same hot path, with the same results up to the last bits of the normals'
  * float sums (both within the tolerances of tests/): the WINDOW path (three launches: every point binned once into the

@@ -284,7 +284,51 @@ def one_case_hard(rng, i, only=None, verbose=False, big=None):
             res = sharded_matches(e, pts, kw, S, int(rng2.integers(2, 6)), viewpoint)
             if res:
                 return res, desc
+    if pre is None and not sor:
+        res = next_cloud_matches(e, pts, kw, viewpoint, np.random.default_rng(1000003 * i + len(pts)))
+        if res:
+            return res, desc
     return None, desc
+
+
+def next_cloud_matches(e, pts, kw, viewpoint, rng3):
+    """The handle of the case takes a second cloud of the same size -- the same plate scanned again, shifted, stretched, with
+    dropped points -- and plans it at once (ppp_run_async right behind ppp_set_cloud: on the window path that pass is enqueued
+    on the first cloud's plan, before the second cloud's bounds are known).  Its list, slice count and error must be those of a
+    fresh handle that waits for its bounds and takes its own census."""
+    how = int(rng3.integers(0, 7))
+    p2 = pts[rng3.permutation(len(pts))].copy()
+    span = np.nanmax(pts, axis=0) - np.nanmin(pts, axis=0)
+    if how == 1: p2[:, 0] += np.float32(rng3.uniform(-0.05, 0.05) * (1000.0 if kw.get("change_range", 1) == 0 else 1.0))
+    if how == 2: p2[:, 1] *= np.float32(rng3.uniform(0.8, 1.3))
+    if how == 3: p2[:, 0] *= np.float32(rng3.uniform(0.85, 1.15))
+    if how == 4: p2[rng3.integers(0, len(p2), max(1, len(p2) // 100))] = np.nan
+    if how == 5: p2[:, 2] += (rng3.standard_normal(len(p2)) * 1e-4 * max(float(span[2]), 1e-3)).astype(np.float32)
+    def result(g):
+        try:
+            g.run_async(); g.sync()
+            return ("ok", g.num_slices(), g.waypoints().copy(), g.tail_index().tobytes(), g.fast_path())
+        except engine.PPPError as ex:
+            return ("error", ex.code, g.failed_slice())
+    e.set_cloud(p2, viewpoint=viewpoint)
+    got = result(e)
+    f = engine.Engine(0, **kw)
+    f.set_plan_reuse(False)
+    f.set_cloud(p2, viewpoint=viewpoint)
+    want = result(f)
+    f.close()
+    if got[0] != want[0] or got[1] != want[1]:
+        return "second cloud on the handle (kind %d): %s, a fresh handle: %s" % (how, got[:2], want[:2])
+    if got[0] == "error":
+        return None if got == want else "second cloud on the handle (kind %d): fails at slice %d, a fresh handle at %d" % (how, got[2], want[2])
+    if got[3] != want[3] or got[2].shape != want[2].shape:
+        return "second cloud on the handle (kind %d): TailIndex / W differ from a fresh handle's" % how
+    if got[4] == want[4]:
+        if got[2].tobytes() != want[2].tobytes():
+            return "second cloud on the handle (kind %d): list differs from a fresh handle's by %.3e" % (how, float(np.nanmax(np.abs(got[2] - want[2]))))
+    elif len(got[2]) and not (np.nan_to_num(np.abs(got[2][:, :3] - want[2][:, :3])).max() <= 2e-6 * (1000.0 if kw.get("change_range", 1) == 0 else 1.0)):
+        return "second cloud on the handle (kind %d, other launch path): positions differ from a fresh handle's" % how
+    return None
 
 
 def one_case(rng, i, only=None, verbose=False, big=None):
