@@ -594,7 +594,7 @@ def measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, e
         d.copy_(src)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        ec.set_cloud_device(d.data_ptr(), int(p2.shape[0]), 12)
+        ec.set_cloud_device_async(d.data_ptr(), int(p2.shape[0]), 12)   # (d stays as it is until ec.sync() below has returned)
         t1 = time.perf_counter()
         ec.run_async()
         ec.sync()
@@ -605,7 +605,7 @@ def measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, e
     return {"replay_one_cloud_hostwait_ms": one, "rotate_clouds": K, "rotate_hostwait_ms": rot,
             "cold_first_ms": cold[0][0], "cold_ms": min(c[0] for c in cold[1:]), "cold_median_ms": float(np.median([c[0] for c in cold[1:]])),
             "cold_split_ms": {"set_cloud_device": min(c[1] for c in cold[1:]), "first_run_async_and_wait": min(c[2] for c in cold[1:])},
-            "note": "host wait after every step in both loops; cold = set_cloud_device + first run_async + wait on a never-seen cloud "
+            "note": "host wait after every step in both loops; cold = set_cloud_device_async + first run_async + wait on a never-seen cloud "
                     "already in device memory (cold_first also pays the handle's buffer allocations)"}
 
 

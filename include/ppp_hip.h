@@ -102,6 +102,12 @@ int ppp_set_params(ppp_handle h, const ppp_params *p);
 int ppp_set_cloud(ppp_handle h, const float *xyz_host, size_t n, size_t stride_bytes, const float *viewpoint);
 /* same, the buffer already lives on this handle's device */
 int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
+/* same, without waiting for the conversion pass where the handle can do without (see ppp_set_plan_reuse: it holds a window plan
+ * of an earlier cloud of this size and these parameters): returns as soon as that pass is enqueued on the handle's stream, and a
+ * pass of the new cloud may be enqueued right behind it.  xyz_dev must stay as it is until a call that waits has returned
+ * (ppp_sync, any getter) -- or, for a caller that orders its own work after the handle's stream (ppp_get_stream), until that
+ * stream has passed this point.  Where the handle cannot do without the bounds this is ppp_set_cloud_device. */
+int ppp_set_cloud_device_async(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint);
 /* The constructors' first line and their loop in one call (pcl::io::loadPCDFile<PointXYZRGB>(name, *cloud) + the x1000 loop:
  * path_slicing_alg.cpp:10-25, path_dynamic_alg.cpp:12-28, Path_Generation.cpp:8-34): the file's records go straight to HBM.
  * A `DATA binary` file whose x, y, z are consecutive float32 fields is streamed in pieces through two pinned buffers that
@@ -332,12 +338,12 @@ int ppp_write_path_file(const char *path, const float *wp6, size_t W);
  * after the other (the constructors of the reference's planner classes: src/Path_Alg/path_slicing_alg.cpp:3-30) saves it on every
  * workpiece.  The pass checks every window against its capacity on the device; one that does not fit makes the engine plan this
  * cloud again from its own census and repeat the pass (same results, one wasted pass).
- * Such a later cloud is not waited for either: while the handle holds that window plan, ppp_set_cloud* only enqueues the
- * conversion pass and returns, and ppp_run_async / ppp_gen_path_async / ppp_get_path_async put the new cloud's pass behind it on
+ * Such a later cloud need not be waited for either: while the handle holds that window plan, ppp_set_cloud_device_async and
+ * ppp_set_cloud_pcd (the calls whose points no caller takes back at once) only enqueue the conversion pass and return, and ppp_run_async / ppp_gen_path_async / ppp_get_path_async put the new cloud's pass behind it on
  * the earlier plan; bounds, walk and capacities are checked on the device against the record the conversion pass leaves, and any
  * other call (ppp_sync included) first reads that record and plans the cloud as a waiting ppp_set_cloud* would have -- a pass the
  * plan did not fit is repeated by the engine.  An error of the new cloud itself (no finite point, ...) then surfaces at that
- * call instead of at ppp_set_cloud*.  0 turns both off (PPP_NO_DEFERRED_PLAN=1 in the environment: the waiting only). */
+ * call instead of at the call that set the cloud.  0 turns both off (PPP_NO_DEFERRED_PLAN=1 in the environment: the waiting only). */
 int ppp_set_plan_reuse(ppp_handle h, int on);
 /* The engine has two launch sequences for the same hot path, with the same results up to the last bits of the normals'
  * float sums (both within the tolerances of tests/): the WINDOW path (three launches: every point binned once into the

@@ -1224,7 +1224,7 @@ int adopt_ingest_record(ppp_handle h, bool census, bool reuse)
     return PPP_OK;
 }
 
-int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stride_bytes = 0)
+int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stride_bytes = 0, bool may_defer = false)
 {
     const size_t n = h->n;
     h->auto_valid = false; h->auto_px_only = false;
@@ -1265,12 +1265,13 @@ int refresh_bounds_and_plan(ppp_handle h, const char *raw = nullptr, size_t stri
                 HIPCHK(h, hipGetLastError());
             }
             h->rec_current = true;
-            /* The handle's plan is a window plan for a cloud of this size and these parameters, made from the device's own walk:
-               no wait.  The plan stays and a pass of the new cloud may follow the conversion pass in the stream at once
+            /* The caller lets go of the raw points only when it is told to (ppp_set_cloud_device_async, or they are the handle's own:
+               ppp_set_cloud_pcd), and the handle's plan is a window plan for a cloud of this size and these parameters, made from
+               the device's own walk: no wait.  The plan stays and a pass of the new cloud may follow the conversion pass in the stream at once
                (settle_enqueue_only); walk length, pad, bounds and every capacity are checked on the device against the record
                this launch leaves (win_verify_body), and the first call that needs the host's view of the cloud reads it
                (resolve_deferred). */
-            if (reuse && h->planned && h->win_path && h->plan_walk_ok && !h->ranged && !h->use_part && h->sb == 0 && h->se == h->S_cap &&
+            if (may_defer && reuse && h->planned && h->win_path && h->plan_walk_ok && !h->ranged && !h->use_part && h->sb == 0 && h->se == h->S_cap &&
                 h->inh_S == h->S_cap && !getenv("PPP_NO_DEFERRED_PLAN")) {
                 h->plan_deferred = true; h->deferred_census = census;
                 h->have_cloud = true;
@@ -1364,7 +1365,7 @@ int resolve_deferred(ppp_handle h)
     return rc;
 }
 
-int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_bytes, const float *viewpoint, bool may_defer = false)
 {
     if (n > 0x7fffffffu / 8) return fail(h, PPP_ERR_CAPACITY, "cloud too large");
     h->n = n;
@@ -1373,7 +1374,7 @@ int set_cloud_common(ppp_handle h, const char *raw_dev, size_t n, size_t stride_
     if (h->back) { delete h->back; h->back = nullptr; }
     if (viewpoint) memcpy(h->vp, viewpoint, 12); else h->vp[0] = h->vp[1] = h->vp[2] = 0.f;
     HIPCHK(h, h->X.ensure(n)); HIPCHK(h, h->Y.ensure(n)); HIPCHK(h, h->Z.ensure(n));
-    return n ? refresh_bounds_and_plan(h, raw_dev, stride_bytes) : refresh_bounds_and_plan(h);
+    return n ? refresh_bounds_and_plan(h, raw_dev, stride_bytes, may_defer) : refresh_bounds_and_plan(h);
 }
 
 
@@ -1597,7 +1598,7 @@ int ppp_set_cloud_pcd(ppp_handle h, const char *path, size_t *n_out, float viewp
         if (he != hipSuccess) return fail(h, PPP_ERR_HIP, std::string("PCD upload: ") + hipGetErrorString(he));
         return fail(h, PPP_ERR_IO, std::string("short read: ") + path);
     }
-    rc = set_cloud_common(h, h->scratch.p + L.x_offset, L.points, L.record_bytes, L.viewpoint);
+    rc = set_cloud_common(h, h->scratch.p + L.x_offset, L.points, L.record_bytes, L.viewpoint, true); /* (the records are in the handle's own buffer: no caller to hand them back to) */
     if (rc == PPP_OK && n_out) *n_out = L.points;
     return rc;
 }
@@ -1608,6 +1609,14 @@ int ppp_set_cloud_device(ppp_handle h, const float *xyz_dev, size_t n, size_t st
     HIPCHK(h, hipSetDevice(h->device));
     { int rcs = settle(h); if (rcs) return rcs; }
     return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint);
+}
+
+int ppp_set_cloud_device_async(ppp_handle h, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint)
+{
+    if (!h || (!xyz_dev && n) || stride_bytes < 12 || (stride_bytes & 3)) return fail(h, PPP_ERR_ARG, "bad cloud arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rcs = settle(h); if (rcs) return rcs; }
+    return set_cloud_common(h, (const char *)xyz_dev, n, stride_bytes, viewpoint, true);
 }
 
 int ppp_range_interval(const ppp_params *p, float min_x, float max_x, float *lo, float *hi, int *num_slices)

@@ -667,6 +667,14 @@ __device__ __forceinline__ void slab_sort_body(const float4 *__restrict__ unsort
     } else {
         if (c > cap) {
             if (threadIdx.x == 0) big_list[atomicAdd(&m->big_slabs, 1)] = b;
+            /* Until the arena pass has sorted it the slab holds its points in arrival order, an empty y-bucket row and no x
+               bounds.  The kernels behind this launch in the stream (whole-cloud normals, the Area2Cloud searches of the dynamic
+               adjustment) walk the whole index before the host knows that it is incomplete and runs the pass again: whatever a
+               slab's places and row held from an earlier plan -- cloud indices, offsets -- sent them outside their buffers
+               (found by a randomised case: an aligned 123 x 124 plate, brute pairing, dynamic adjustment). */
+            for (int i = threadIdx.x; i < c; i += blockDim.x) sorted4[s0 + i] = unsorted4[s0 + i];
+            if (ytab) for (int q = threadIdx.x; q <= YTB; q += blockDim.x) ytab[(size_t)b * (YTB + 1) + q] = 0;
+            if (threadIdx.x == 0) { slab_xmin[b] = -INFINITY; slab_xmax[b] = INFINITY; }
             return;
         }
         NB = min(cap, next_pow2(c));

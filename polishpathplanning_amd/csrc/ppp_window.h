@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void win_verify_body(const WinArgs &A)
         m->n_valid = c;
         m->S = S > A.S ? A.S : S;
         m->first_kept = P.drop_ends ? 1 : 0;
-        { const int nk = P.drop_ends ? S - 2 : S; m->nkept = nk < 0 ? 0 : nk; }
+        { const int Sc = S > A.S ? A.S : S, nk = P.drop_ends ? Sc - 2 : Sc; m->nkept = nk < 0 ? 0 : nk; } /* (never beyond the plan's tables: whoever reads the block walks them by these counts) */
         m->sb = A.sb; m->se = A.se;
         m->incl_lo = P.incl_lo; m->incl_hi = P.incl_hi;
         s_S = S > A.S ? A.S : S;
@@ -1065,9 +1065,9 @@ __device__ __forceinline__ void win_finish_body(const WinArgs &A, const int bx)
     DevMeta *m = A.m;
     const DevParams &P = A.P;
     const int nk = A.nkept, tid = (int)threadIdx.x;
-    if (tid == 0) { s_err = m->err; s_run = 0; s_short = 0; }
+    if (tid == 0) { s_err = m->err | m->win_flag; s_run = 0; s_short = 0; }
     __syncthreads();
-    if (s_err) return;
+    if (s_err) return; /* a failed slice -- or a pass that is handed back (its slots and counts are another plan's: nothing list-wide may walk them) */
     /* a9 bookkeeping: every workgroup scans the waypoint counts of all kept slices (left by the slice workgroups) */
     const int res_i = (int)P.rpy_resolution;
     for (int base = 0; base < nk; base += blockDim.x) {

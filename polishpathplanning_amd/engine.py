@@ -79,7 +79,7 @@ EXPORTS = [
     "ppp_get_kernel_times", "ppp_load_pcd", "ppp_save_pcd", "ppp_free", "ppp_default_config", "ppp_read_config",
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
-    "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse", "ppp_set_cloud_pcd", "ppp_pcd_probe",
+    "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse", "ppp_set_cloud_pcd", "ppp_pcd_probe", "ppp_set_cloud_device_async",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
         L.ppp_set_params.argtypes = [vp, C.POINTER(Params)]
         L.ppp_set_cloud.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device.argtypes = [vp, vp, sz, sz, fp]
+        L.ppp_set_cloud_device_async.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_num_points.argtypes = [vp, szp]
         L.ppp_range_interval.argtypes = [C.POINTER(Params), C.c_float, C.c_float, fp, fp, ip]
         L.ppp_set_cloud_part.argtypes = [vp, vp, sz, sz, fp, ip, fp, fp, sz, C.c_float, C.c_float]
@@ -415,6 +416,13 @@ class Engine:
         self._chk(self.L.ppp_set_cloud_part(self.h, xyz.ctypes.data, xyz.shape[0], xyz.shape[1] * 4, vp, idx, _f(mn), _f(mx),
                                             int(n_valid_total), float(part_lo), float(part_hi)))
         self.n = xyz.shape[0]
+
+    def set_cloud_device_async(self, dptr, n, stride_bytes, viewpoint=None):
+        """ppp_set_cloud_device_async: no wait for the conversion pass where the handle's plan allows; the buffer must stay untouched
+        until a call that waits (sync, any getter) has returned."""
+        vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+        self._chk(self.L.ppp_set_cloud_device_async(self.h, C.c_void_p(dptr), n, stride_bytes, vp))
+        self.n = n
 
     def set_cloud_device(self, dptr, n, stride_bytes, viewpoint=None):
         vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))

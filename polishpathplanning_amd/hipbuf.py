@@ -24,6 +24,14 @@ class DeviceBuffer:
             raise MemoryError("hipMalloc(%d) failed: %d" % (nbytes, rc))
         self.ptr, self.nbytes = p.value, int(nbytes)
 
+    def upload(self, arr):
+        """Synchronous copy of a C-contiguous array into the buffer."""
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        rc = _rt().hipMemcpy(C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1)
+        if rc:
+            raise RuntimeError("hipMemcpy H2D failed: %d" % rc)
+
     def to_host(self, nfloats):
         out = np.empty(int(nfloats), np.float32)
         if nfloats:

@@ -1842,8 +1842,8 @@ def test_plan_reuse_for_a_stream_of_clouds_of_one_size(engine_mod, oracle_mod):
 
 
 def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
-    """A handle that holds a window plan of an earlier cloud of the same size and parameters does not wait for a new cloud's
-    bounds: set_cloud enqueues the conversion pass and returns, run_async may follow at once on the earlier plan, and walk length,
+    """A handle that holds a window plan of an earlier cloud of the same size and parameters need not wait for a new cloud's
+    bounds: ppp_set_cloud_device_async enqueues the conversion pass and returns, run_async may follow at once on the earlier plan, and walk length,
     pad, bounds and capacities are checked on the device against the record the conversion pass leaves.  Whatever the new cloud
     looks like -- the same kind, shifted by two and a half slices, taller (more waypoints per slice than the plan has slots),
     wider (another slice count), with dropped points, all points dropped -- the list is the one a fresh, waiting handle makes,
@@ -1854,7 +1854,12 @@ def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
         import sys, numpy as np
         sys.path.insert(0, %r)
         from polishpathplanning_amd import engine, synth
+        from polishpathplanning_amd.hipbuf import DeviceBuffer
         base, cfg = synth.make_config("small_40k")
+        dbuf = DeviceBuffer(base.nbytes)
+        def set_async(h, p):                  # the cloud in device memory, handed over without a wait (dbuf is rewritten only after a waiting call)
+            dbuf.upload(np.ascontiguousarray(p, np.float32))
+            h.set_cloud_device_async(dbuf.ptr, len(p), 12)
         def variant(kind):
             p = synth.make_config("small_40k", seed=100 + kind)[0].copy()
             if kind == 1: p[:, 0] += np.float32(0.031)                      # two and a half slices along x
@@ -1879,7 +1884,7 @@ def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
         deferred = 0
         for rnd, kind in enumerate([0, 7, 1, 8, 2, 9, 3, 10, 4, 11, 5, 12, 6, 13, 0]):
             p = variant(kind)
-            h.set_cloud(p)                      # no wait from the second same-size cloud on
+            set_async(h, p)                     # no wait from the second same-size cloud on
             h.run_async()                       # ... and the pass right behind it
             try:
                 h.sync()
@@ -1892,7 +1897,7 @@ def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
         for kind in (14, 3, 15):
             p = variant(kind)
             f = engine.Engine(0, tool_radius=6.0); f.set_plan_reuse(False); f.set_cloud(p)
-            h.set_cloud(p)
+            set_async(h, p)
             assert all(np.array_equal(a, b) for a, b in zip(h.minmax(), f.minmax()))
             q = p[::1000] * 1000 + np.float32(0.01)
             assert np.array_equal(h.nearest(q), f.nearest(q))
@@ -1900,18 +1905,18 @@ def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
             assert h.waypoints().tobytes() == f.waypoints().tobytes()
             f.close()
         # two clouds set in a row, parameters changed under a cloud that was not waited for, preprocessing right after it
-        h.set_cloud(variant(16)); h.set_cloud(variant(17)); h.run_async(); h.sync()
+        set_async(h, variant(16)); h.sync(); set_async(h, variant(17)); h.run_async(); h.sync()
         assert (h.num_slices(), h.waypoints().tobytes()) == fresh_result(variant(17))[:2]
-        h.set_cloud(variant(18)); h.set_params(tool_radius=7.0); h.run_async(); h.sync()
+        set_async(h, variant(18)); h.set_params(tool_radius=7.0); h.run_async(); h.sync()
         f = engine.Engine(0, tool_radius=7.0); f.set_plan_reuse(False); f.set_cloud(variant(18)); f.run_async(); f.sync()
         assert h.waypoints().tobytes() == f.waypoints().tobytes(); f.close()
         h.set_params(tool_radius=6.0); h.set_cloud(variant(19)); h.run_async(); h.sync()
-        h.set_cloud(variant(20)); n_left = h.remove_outlier(50, 1.0)[0]; h.run_async(); h.sync()
+        set_async(h, variant(20)); n_left = h.remove_outlier(50, 1.0)[0]; h.run_async(); h.sync()
         f = engine.Engine(0, tool_radius=6.0); f.set_plan_reuse(False); f.set_cloud(variant(20)); assert f.remove_outlier(50, 1.0)[0] == n_left
         f.run_async(); f.sync()
         assert h.waypoints().tobytes() == f.waypoints().tobytes(); f.close()
         # GenPath / getPath as separate calls, and a replay on the inherited plan before anything was asked
-        h.set_cloud(variant(21)); h.gen_path_async(); h.get_path_async(); h.run_async(); h.run_async(); h.sync()
+        set_async(h, variant(21)); h.gen_path_async(); h.get_path_async(); h.run_async(); h.run_async(); h.sync()
         assert (h.num_slices(), h.waypoints().tobytes()) == fresh_result(variant(21))[:2]
         print("same lists")
     """ % root)

@@ -293,7 +293,7 @@ def one_case_hard(rng, i, only=None, verbose=False, big=None):
 
 def next_cloud_matches(e, pts, kw, viewpoint, rng3):
     """The handle of the case takes a second cloud of the same size -- the same plate scanned again, shifted, stretched, with
-    dropped points -- and plans it at once (ppp_run_async right behind ppp_set_cloud: on the window path that pass is enqueued
+    dropped points -- and plans it at once (ppp_run_async right behind ppp_set_cloud_device_async: on the window path that pass is enqueued
     on the first cloud's plan, before the second cloud's bounds are known).  Its list, slice count and error must be those of a
     fresh handle that waits for its bounds and takes its own census."""
     how = int(rng3.integers(0, 7))
@@ -304,14 +304,33 @@ def next_cloud_matches(e, pts, kw, viewpoint, rng3):
     if how == 3: p2[:, 0] *= np.float32(rng3.uniform(0.85, 1.15))
     if how == 4: p2[rng3.integers(0, len(p2), max(1, len(p2) // 100))] = np.nan
     if how == 5: p2[:, 2] += (rng3.standard_normal(len(p2)) * 1e-4 * max(float(span[2]), 1e-3)).astype(np.float32)
+    dbg = os.environ.get("PPP_FUZZ_DEBUG_NEXT") == "1"
+    def say(*a):
+        if dbg:
+            print("[next]", *a, file=sys.stderr, flush=True)
+    say("kind", how, "n", len(p2), "params", {k: kw[k] for k in ("tool_radius", "walk", "pairing", "dynamic_adjustment") if k in kw}, "fast path before", e.fast_path())
     def result(g):
         try:
-            g.run_async(); g.sync()
-            return ("ok", g.num_slices(), g.waypoints().copy(), g.tail_index().tobytes(), g.fast_path())
+            g.run_async(); say("enqueued"); g.sync(); say("synced")
+            r = ("ok", g.num_slices(), g.waypoints().copy(), g.tail_index().tobytes(), g.fast_path()); say("read", r[1], r[4])
+            return r
         except engine.PPPError as ex:
             return ("error", ex.code, g.failed_slice())
-    e.set_cloud(p2, viewpoint=viewpoint)
+    from polishpathplanning_amd.hipbuf import DeviceBuffer
+    p2 = np.ascontiguousarray(p2, np.float32)
+    dbuf = DeviceBuffer(p2.nbytes)
+    dbuf.upload(p2)
+    say("uploaded")
+    e.set_cloud_device_async(dbuf.ptr, len(p2), 12, viewpoint=viewpoint)   # (dbuf lives until the results are in)
+    say("set")
+    if dbg:
+        from polishpathplanning_amd.hipbuf import _rt
+        _rt().hipDeviceSynchronize(); say("conversion pass done")
+        e.gen_path_async(); _rt().hipDeviceSynchronize(); say("gen done")
+        e.get_path_async(); _rt().hipDeviceSynchronize(); say("get done")
     got = result(e)
+    dbuf.free()
+    say("fresh handle")
     f = engine.Engine(0, **kw)
     f.set_plan_reuse(False)
     f.set_cloud(p2, viewpoint=viewpoint)

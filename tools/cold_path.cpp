@@ -1,5 +1,5 @@
 // The cold path as a C caller sees it (tools/cold_path.py measures it through ctypes): clouds already in device memory,
-// ppp_set_cloud_device + ppp_run_async + ppp_sync per never-seen cloud.   usage: cold_path a.pcd b.pcd ...  (same size, >= 3 files)
+// ppp_set_cloud_device_async (PPP_COLD_WAITING_CALL=1: ppp_set_cloud_device) + ppp_run_async + ppp_sync per never-seen cloud.   usage: cold_path a.pcd b.pcd ...  (same size, >= 3 files)
 // build: hipcc -O2 -std=c++17 -I include -o /tmp/cold_path tools/cold_path.cpp -L polishpathplanning_amd -lppp_hip -Wl,-rpath,$PWD/polishpathplanning_amd
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -39,7 +39,7 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < dev.size(); ++i) {
         if (copy_before) { if (hipMemcpy(dev[i], host[i], ns[i] * 12, hipMemcpyHostToDevice) != hipSuccess) return 1; (void)hipDeviceSynchronize(); }
         const auto t0 = std::chrono::steady_clock::now();
-        int rc = ppp_set_cloud_device(h, dev[i], ns[i], 12, nullptr);
+        int rc = std::getenv("PPP_COLD_WAITING_CALL") ? ppp_set_cloud_device(h, dev[i], ns[i], 12, nullptr) : ppp_set_cloud_device_async(h, dev[i], ns[i], 12, nullptr);
         const auto t1 = std::chrono::steady_clock::now();
         if (rc == PPP_OK) rc = ppp_run_async(h);
         const auto t2 = std::chrono::steady_clock::now();

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The path of a never-seen cloud that is already in device memory: ppp_set_cloud_device (conversion, bounds, walk, census, plan) +
+"""The path of a never-seen cloud that is already in device memory: ppp_set_cloud_device_async (conversion, bounds, walk, census, plan) +
 the first ppp_run_async + the wait for the list, without torch in the process; splits per call and the kernels' own durations.
 usage: python tools/cold_path.py [--lib libppp_hip_x.so] [config]"""
 import os, sys, time
@@ -25,7 +25,7 @@ for k in range(7):
     assert rc == 0
     _rt().hipDeviceSynchronize()
     t0 = time.perf_counter()
-    e.set_cloud_device(buf.ptr, int(pts.shape[0]), 12)
+    e.set_cloud_device_async(buf.ptr, int(pts.shape[0]), 12)   # (buf is written again only after e.sync() below)
     t1 = time.perf_counter()
     e.run_async()
     t2 = time.perf_counter()

@@ -17,7 +17,7 @@ for k in range(8):
 PY
 /opt/rocm/bin/hipcc -O2 -std=c++17 -I include -o "$D/cold_path" tools/cold_path.cpp -L polishpathplanning_amd -lppp_hip -Wl,-rpath,"$PWD/polishpathplanning_amd"
 "$D/cold_path" "$D"/c*.pcd
-PPP_NO_DEFERRED_PLAN=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/waiting for the bounds (PPP_NO_DEFERRED_PLAN=1): /'
+PPP_COLD_WAITING_CALL=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/waiting for the bounds (ppp_set_cloud_device): /'
 PPP_COLD_COPY_BEFORE=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/each cloud copied to the device right before it is timed: /'
-PPP_COLD_COPY_BEFORE=1 PPP_NO_DEFERRED_PLAN=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/  ... and waiting for the bounds: /'
+PPP_COLD_COPY_BEFORE=1 PPP_COLD_WAITING_CALL=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/  ... and waiting for the bounds: /'
 rm -rf "$D"
