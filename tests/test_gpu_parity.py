@@ -891,6 +891,42 @@ def test_dynamic_adjustment_pipeline(engine_mod, oracle_mod, name, walk):
         e.boundary(S)
 
 
+def test_dense_slabs_under_dynamic_adjustment_wait_for_the_arena_pass(engine_mod, oracle_mod):
+    """A square plate lying diagonally in x/y: the x-slabs through its middle hold twice the mean population -- more than a slab's
+    LDS sort takes --, so the first index of the pass is incomplete and the engine repeats the pass with the arena sort.  With the
+    dynamic adjustment the whole-cloud normals and the Area2Cloud searches run behind that first index in the stream: until the arena
+    pass such a slab must hold valid points, an empty y-bucket row and open x bounds (a slab that kept what an earlier plan had left
+    there sent the normals' stores outside their buffer: found by a randomised case).  The handle plans a larger cloud first, so
+    that its index buffers are full of another plan's data.  Knots and list against the oracle."""
+    big, _ = synth.make_config("small_40k")
+    grid = synth.make_plate(200, 200, kind="dome", amp=12.0, seed=5)
+    c, s_ = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    ctr = grid[:, :2].mean(axis=0)
+    xy = (grid[:, :2] - ctr) @ np.array([[c, -s_], [s_, c]], np.float64).T
+    pts = np.ascontiguousarray(np.column_stack([xy[:, 0] + 0.35, xy[:, 1], grid[:, 2]]).astype(np.float32))
+    for kw in (dict(tool_radius=7.5, walk=3, pairing=1, dynamic_adjustment=1, curvature_k=10, depth=0.005), dict(tool_radius=6.0, walk=1, dynamic_adjustment=1)):
+        e = engine_mod.Engine(0, **kw)
+        e.set_cloud(big)
+        try:
+            e.gen_path(); e.get_path()
+        except engine_mod.PPPError:
+            pass
+        o = oracle_mod.Oracle(pts, **kw)
+        e.set_cloud(pts)
+        So = o.gen_path()
+        try:
+            S = e.gen_path()
+        except engine_mod.PPPError:
+            assert So < 0 and e.failed_slice() == -(So + 1)      # (the tips of the diamond: both sides give up at the same slice)
+            continue
+        assert S == So > 10
+        for s in range(S):
+            assert all(np.array_equal(a, b) for a, b in zip(e.nodes(s), o.nodes(s))), s
+        W, Wo = e.get_path(), o.get_path()
+        assert W == Wo and np.nan_to_num(np.linalg.norm(e.waypoints()[:, :3] - o.waypoints()[:, :3], axis=1)).max() <= TOL_M
+        e.close()
+
+
 def test_dynamic_fit_paths_agree():
     """The fits of the chain (compute_boundary's std::map + end knots, dynamic_adjust_path's map + Spline::restart) take one
     of three paths: samples already in knot order, equal y to merge, unsorted.  The synthetic clouds mostly take the
