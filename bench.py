@@ -602,11 +602,42 @@ def measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, e
         cold.append(((t2 - t) * 1e3, (t1 - t) * 1e3, (t2 - t1) * 1e3))
     ec.close()
     del d
+    c_caller = cold_path_from_c(args, engine, synth, base_seed)
     return {"replay_one_cloud_hostwait_ms": one, "rotate_clouds": K, "rotate_hostwait_ms": rot,
             "cold_first_ms": cold[0][0], "cold_ms": min(c[0] for c in cold[1:]), "cold_median_ms": float(np.median([c[0] for c in cold[1:]])),
             "cold_split_ms": {"set_cloud_device": min(c[1] for c in cold[1:]), "first_run_async_and_wait": min(c[2] for c in cold[1:])},
+            "cold_c_caller_ms": c_caller[0], "cold_c_caller_median_ms": c_caller[1],
             "note": "host wait after every step in both loops; cold = set_cloud_device_async + first run_async + wait on a never-seen cloud "
-                    "already in device memory (cold_first also pays the handle's buffer allocations)"}
+                    "already in device memory (cold_first also pays the handle's buffer allocations); cold_ms is timed around the ctypes "
+                    "calls of this process, cold_c_caller_ms by tools/cold_path (the same three calls from C, a child process, the cloud "
+                    "copied to the device right before it is timed; null when that binary was not built)"}
+
+
+def cold_path_from_c(args, engine, synth, base_seed):
+    """The cold path without this process's ctypes layer: tools/cold_path (built by __graft_entry__.build() from tools/cold_path.cpp)
+    on six never-seen clouds of the workload, written as binary PCDs to a temporary directory.  (min, median) in ms, or (None, None)."""
+    import subprocess, tempfile
+    exe = os.path.join(ROOT, "tools", "cold_path")
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if not os.path.exists(exe) or profiled:   # (no child process under a profiler's preloaded library)
+        return None, None
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            names = []
+            for k in range(6):
+                p2, _ = synth.make_config(args.config, seed=base_seed + 15485863 * (k + 1))
+                names.append(os.path.join(d, "c%d.pcd" % k))
+                engine.save_pcd(names[-1], np.ascontiguousarray(p2), binary=True)
+            r = subprocess.run([exe] + names, env=dict(os.environ, PPP_COLD_COPY_BEFORE="1"), capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            sys.stderr.write("bench: tools/cold_path failed (%d): %s\n" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+            return None, None
+        last = r.stdout.strip().splitlines()[-1]              # "... total min 88.8, median 89.7 us"
+        a = last.split("total min ")[1]
+        return float(a.split(",")[0]) / 1e3, float(a.split("median ")[1].split(" ")[0]) / 1e3
+    except Exception as ex:
+        sys.stderr.write("bench: tools/cold_path: %r\n" % (ex,))
+        return None, None
 
 
 def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth):
