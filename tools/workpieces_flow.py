@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--config", default="cfg2_1m_s256")
     ap.add_argument("--count", type=int, default=5)
     ap.add_argument("--format", default="binary", choices=["binary", "ascii", "compressed"])
+    ap.add_argument("--dynamic", action="store_true", help="Dynamic_adjustment = true (the reference's config.txt default)")
     a = ap.parse_args()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "workpieces"], stdout=subprocess.DEVNULL)
     pts, cfg = synth.make_config(a.config)
@@ -28,15 +29,15 @@ def main():
         out = os.path.join(d, "WayPoints.txt")
         conf = os.path.join(d, "config.txt")
         open(conf, "w").write("Tool_Radius = %g\npathFile = %s\nPathResolution = 7\nRPYresolution = 7\nEnd effector length = 0.3\n"
-                              "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = false\n"
-                              "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n" % (cfg.get("tool_radius", 6.0), out))
+                              "Smooth = false\nAlignment = false\nChangeRange = true\nRemoveOutlier = false\nDynamic_adjustment = %s\n"
+                              "Adjust_Threshold = 1\ntoolthickness = 10\ndepth = 0.01\n" % (cfg.get("tool_radius", 6.0), out, "true" if a.dynamic else "false"))
         for label, extra in (("handle pool", {}), ("no pool", {"PPP_NO_HANDLE_POOL": "1"})):
             r = subprocess.run([os.path.join(ROOT, "examples", "workpieces")] + names, env=dict(os.environ, PPP_CONFIG=conf, **extra),
                                capture_output=True, text=True, timeout=600, cwd=d)
             if r.returncode != 0:
                 print(r.stdout[-2000:], r.stderr[-2000:])
                 raise SystemExit("workpieces failed")
-            print("%s, %s, %d x %s:" % (label, a.format, a.count, a.config))
+            print("%s, %s, %d x %s%s:" % (label, a.format, a.count, a.config, ", Dynamic_adjustment = true" if a.dynamic else ""))
             for ln in r.stdout.splitlines():
                 if ln.startswith("workpieces:"):
                     print("   " + ln)
