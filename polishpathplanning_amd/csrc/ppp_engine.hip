@@ -1536,7 +1536,12 @@ bool read_piece(int fd, char *buf, size_t len, long long pos)
     const int nt = len >= ((size_t)1 << 20) ? PCD_READERS : 1;
     const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) { const size_t a = std::min(len, per * t), b = std::min(len, per * (t + 1)); if (a < b) th.emplace_back(part, a, b); }
+    th.reserve((size_t)nt);
+    for (int t = 1; t < nt; ++t) {
+        const size_t a = std::min(len, per * t), b = std::min(len, per * (t + 1));
+        if (a >= b) continue;
+        try { th.emplace_back(part, a, b); } catch (...) { part(a, b); } /* (no thread to be had: read it here) */
+    }
     part(0, std::min(len, per));
     for (auto &t : th) t.join();
     return ok;

@@ -155,6 +155,20 @@ static float parse_float_token(const char *t0, const char *lim, const char **tok
     tmp[tl] = 0;
     return strtof(tmp, nullptr); /* 0 for no number at all, nan / inf in any spelling, hex */
 }
+/* fn(0) .. fn(parts - 1), the first on this thread, the others on threads of their own; a thread that cannot be started has its
+   part run here instead (nothing is left joinable behind an exception) */
+template <typename F>
+static void run_parts(size_t parts, F &&fn)
+{
+    std::vector<std::thread> th;
+    th.reserve(parts);
+    std::vector<size_t> here(1, 0);
+    for (size_t t = 1; t < parts; ++t) {
+        try { th.emplace_back(fn, t); } catch (...) { here.push_back(t); }
+    }
+    for (size_t t : here) fn(t);
+    for (auto &x : th) x.join();
+}
 } // namespace
 
 extern "C" {
@@ -343,15 +357,9 @@ static int load_pcd_impl(const char *path, float **xyz, size_t *n, float viewpoi
                 cut[t] = nl ? nl + 1 : text + len;
             }
             std::vector<size_t> rows(parts, 0), first(parts + 1, 0);
-            auto on_all = [&](auto &&fn) {
-                std::vector<std::thread> th;
-                for (size_t t = 1; t < parts; ++t) th.emplace_back(fn, t);
-                fn((size_t)0);
-                for (auto &x : th) x.join();
-            };
-            on_all([&](size_t t) { rows[t] = walk(cut[t], cut[t + 1], nullptr, (size_t)-1); });
+            run_parts(parts, [&](size_t t) { rows[t] = walk(cut[t], cut[t + 1], nullptr, (size_t)-1); });
             for (size_t t = 0; t < parts; ++t) first[t + 1] = first[t] + rows[t];
-            on_all([&](size_t t) {
+            run_parts(parts, [&](size_t t) {
                 if (first[t] < points) walk(cut[t], cut[t + 1], out + 3 * first[t], std::min(rows[t], points - first[t]));
             });
             got = std::min(first[parts], points); /* (rows beyond POINTS are ignored, as in the single walk) */
@@ -603,9 +611,11 @@ static int write_path_file_impl(const char *path, const float *wp6, size_t W)
     const size_t parts = W >= 16384 ? std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), W / 8192)) : 1;
     std::vector<std::unique_ptr<char[]>> text(parts);
     std::vector<size_t> len(parts, 0);
+    try { /* (every allocation here, on this thread: nothing in a worker may throw) */
+        for (size_t pi = 0; pi < parts; ++pi) text[pi].reset(new char[std::max<size_t>(W * (pi + 1) / parts - W * pi / parts, 1) * per]);
+    } catch (...) { fclose(f); return PPP_ERR_IO; }
     auto run = [&](size_t pi) {
         const size_t w0 = W * pi / parts, w1 = W * (pi + 1) / parts;
-        text[pi].reset(new char[std::max<size_t>(w1 - w0, 1) * per]);
         char *o = text[pi].get();
         for (size_t w = w0; w < w1; ++w) {
             for (int i = 0; i < 6; i++) {
@@ -616,12 +626,7 @@ static int write_path_file_impl(const char *path, const float *wp6, size_t W)
         }
         len[pi] = (size_t)(o - text[pi].get());
     };
-    {
-        std::vector<std::thread> th;
-        for (size_t pi = 1; pi < parts; ++pi) th.emplace_back(run, pi);
-        run(0);
-        for (auto &t : th) t.join();
-    }
+    run_parts(parts, run);
     bool ok = true;
     for (size_t pi = 0; pi < parts && ok; ++pi) ok = fwrite(text[pi].get(), 1, len[pi], f) == len[pi];
     return (fclose(f) == 0 && ok) ? PPP_OK : PPP_ERR_IO;
