@@ -84,8 +84,8 @@ def emit_record(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default=None,
                     help="workload (polishpathplanning_amd.synth.CONFIGS); default: cfg2_1m_s256 on one GPU (BASELINE configs[1]), "
                          "cfg4_2m_s256 per GPU for --gpus N > 1 (configs[3]), cfg5_10m_s1024 for --mode slices (configs[4])")
@@ -95,6 +95,9 @@ def main():
                     help="N > 1: one workpiece per GPU (weak scaling, default) or the slice ranges of ONE cloud (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=20)
+    ap.add_argument("--no-single-handle", action="store_true", help="skip the one-handle loop that is timed beside the steps taking turns (profiling runs)")
+    ap.add_argument("--handles", type=int, default=0,
+                    help="engine handles (= HIP streams) the steps of a one-GPU, one-workpiece run take turns on; 0 = 3 where that applies, else 1")
     ap.add_argument("--rotate", type=int, default=None,
                     help="also report the step time over K distinct resident clouds planned round-robin (K x working set beyond "
                          "the 256 MiB Infinity Cache) and the cold time of a never-seen cloud; 0 = off, the default run uses 8")
@@ -205,6 +208,36 @@ def main():
         # branch ends by writing its WayPointsList to its place in the gather buffer
         engine.run_batch_async(engines, gatherers[k % 2].send.data_ptr(), offs, w_all)
 
+    # ---- one GPU, one workpiece per step: consecutive steps are independent workpieces, so they take turns on H handles.
+    # A handle is a HIP stream with its own buffers: step k's binning launch runs beside step k-1's per-slice kernel instead
+    # of behind its finish launch (three dependent launches per pass leave most of the chip idle most of the time).  Every
+    # replica holds the same resident cloud and plans the whole pass; each writes its list to a buffer of its own.
+    # (Not with an exchange in the step -- N > 1, the one-rank rehearsal --: untested on several GPUs, those runs keep one handle.)
+    turns = args.handles if args.handles > 0 else 3
+    if world > 1 or force_dist or args.batch != 1 or args.dynamic or host_waits or os.environ.get("PPP_BENCH_EVENT_ORDER") == "1":
+        turns = 1
+    replicas, outs = [eng], []
+    if turns > 1:
+        for _ in range(turns - 1):
+            e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+            e.set_cloud(pts)
+            if (e.gen_path(), e.get_path()) != (S, W):
+                raise SystemExit("a replica of the workpiece planned another list")
+            replicas.append(e)
+        outs = [torch.empty((max(W, 1), 6), dtype=torch.float32, device=dev) for _ in range(turns)]
+
+    def plan_turn(k):
+        engine.run_batch_async([replicas[k % turns]], outs[k % turns].data_ptr(), offs, w_all)
+
+    def run_turns(count):
+        if count <= 0:
+            return None
+        for k in range(count):
+            plan_turn(k)
+        engine.sync_batch(replicas)
+        torch.cuda.current_stream().synchronize()
+        return [outs[(count - 1) % turns][:W]]
+
     def run_steps(count):
         """`count` full steps: every step's robot path is planned and gathered on rank 0 before this returns.
         Steps alternate between two send/receive buffer pairs.  Step k's collective is enqueued behind step k's
@@ -229,13 +262,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
+    timed = run_turns if turns > 1 else run_steps
+    timed(args.warmup)
     fence()
     t0 = time.perf_counter()
-    blocks = run_steps(args.steps)
+    blocks = timed(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     w_local = w_step
+    single = None
+    if turns > 1 and not args.no_single_handle:   # the same K steps on ONE handle, back to back (rounds 1-3's loop), for the record
+        run_steps(args.warmup)
+        fence()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        e1 = time.perf_counter() - t1
+        single = {"ms_per_step": e1 / args.steps * 1e3, "value": w_step * args.steps / e1,
+                  "replicas_equal": bool(all(np.array_equal(r.waypoints(), eng.waypoints()) for r in replicas[1:])),
+                  "note": "the same steps enqueued back to back on one handle (one stream): what rounds 1-3 report as the headline"}
 
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     ww = torch.tensor([float(w_local)], dtype=torch.float64, device=dev)
@@ -323,6 +368,25 @@ def main():
         eng.enable_timing(False)
         kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}  # per pass, summed over that kernel's launches
         dom = max(kern_ms, key=kern_ms.get)
+        # ... and the same launches while the steps take turns on the handles of the timed loop: a launch then shares the chip with
+        # the launches of the neighbouring steps, its own wall time (HIP events on ITS stream) grows while the loop's throughput does too
+        kern_ms_turns = None
+        if turns > 1:
+            for r in replicas:
+                r.enable_timing(True)
+            acc2 = {}
+            rounds = max(2, args.profile_passes // 2)
+            for _ in range(rounds):
+                for k in range(2 * turns):
+                    engine.run_batch_async([replicas[k % turns]], outs[k % turns].data_ptr(), offs, w_all)
+                engine.sync_batch(replicas)
+                for r in replicas:
+                    kt2, kl2 = r.kernel_times(with_launches=True)   # (summed over the passes this handle ran since the last call)
+                    for k2, v2 in kt2.items():
+                        acc2.setdefault(k2, []).append(v2 / 2.0)
+            for r in replicas:
+                r.enable_timing(False)
+            kern_ms_turns = {k2: float(np.mean(v2)) for k2, v2 in acc2.items()}
         # 12 B per point read once + 24 B per waypoint written once; one launch processes the whole batch
         alg_bytes = 12.0 * float(sum(int(c.shape[0]) for c in clouds)) + 24.0 * float(sum(w_all))
         achieved = alg_bytes / (kern_ms[dom] * 1e-3) / 1e9
@@ -335,8 +399,15 @@ def main():
                     "traffic_total": load_traffic_total(launches, workload_key)[0],
                     "launches_per_pass": launches.get(dom, 1),
                     "avg_launch_ms": kern_ms[dom] / max(1, launches.get(dom, 1)),
+                    "avg_launch_ms_steps_taking_turns": (kern_ms_turns.get(dom) / max(1, launches.get(dom, 1))) if kern_ms_turns and dom in kern_ms_turns else None,
+                    "frac_steps_taking_turns": (alg_bytes / (kern_ms_turns[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms_turns and dom in kern_ms_turns else None,
+                    "kernel_ms_steps_taking_turns": ({k: round(v, 5) for k, v in sorted(kern_ms_turns.items(), key=lambda kv: -kv[1])} if kern_ms_turns else None),
+                    "pipeline_frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                     "note": "one pass = one launch of every stage over the %d workpiece(s) of a step; kernel_ms are per pass (summed "
-                            "over a kernel's launches); algorithmic_bytes = 12 B x points + 24 B x waypoints of the step; traffic = HBM bytes "
+                            "over a kernel's launches), a launch alone on the device (achieved / frac / avg_launch_ms: as in rounds 1-3); "
+                            "*_steps_taking_turns: the same launches measured while consecutive steps overlap on the timed loop's handles "
+                            "(a launch's own duration grows, the loop's throughput -- pipeline_gbs, pipeline_frac -- grows too); "
+                            "algorithmic_bytes = 12 B x points + 24 B x waypoints of the step; traffic = HBM bytes "
                             "of the dominant kernel's launches, traffic_total = of every launch of the pass (committed PMC summaries)" % args.batch,
                     "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
                     "algorithmic_bytes": alg_bytes,
@@ -419,7 +490,13 @@ def main():
                        "waypoints_per_workpiece": int(w_all[0]), "workpieces": world * args.batch, "batch_per_gpu": args.batch,
                        "parallelism": "one workpiece per GPU, RCCL gather of robot_path to rank 0" if world > 1 else "single GPU",
                        "pairing": "kd", "walk": "center_int (connect)", "tool_radius_mm": cfg["tool_radius"],
-                       "dynamic_adjustment": bool(args.dynamic)},
+                       "dynamic_adjustment": bool(args.dynamic),
+                       "handles_taking_turns": turns,
+                       "step_order": ("consecutive steps (independent workpieces) take turns on %d engine handles = %d HIP streams, each with the "
+                                      "same resident cloud and buffers of its own: a step's binning launch runs beside the step before's per-slice "
+                                      "kernel; K steps enqueued, one host wait at the end" % (turns, turns)) if turns > 1 else
+                                     "steps enqueued back to back on one handle (one HIP stream), one host wait at the end"},
+            "single_handle": single,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "path_l2_err": err,
@@ -474,6 +551,27 @@ def measure_other_config(args, engine, synth, local_rank, name, nb, n_checked):
         dt = (time.perf_counter() - t) / steps
         best = dt if best is None else min(best, dt)
     eng = engines[0]
+    turns_ms = None
+    if nb == 1:   # one workpiece per step: the steps take turns on three handles, as in the headline's loop
+        reps, bufs = [eng], [buf]
+        for _ in range(2):
+            e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+            e.set_cloud(clouds[0]); e.gen_path(); e.get_path()
+            reps.append(e); bufs.append(DeviceBuffer(int(sum(w_all)) * 24))
+        for k in range(6):
+            engine.run_batch_async([reps[k % 3]], bufs[k % 3].ptr, offs, w_all)
+        engine.sync_batch(reps)
+        for _ in range(3):
+            t = time.perf_counter()
+            for k in range(3 * steps):
+                engine.run_batch_async([reps[k % 3]], bufs[k % 3].ptr, offs, w_all)
+            engine.sync_batch(reps)
+            dt = (time.perf_counter() - t) / (3 * steps)
+            turns_ms = dt * 1e3 if turns_ms is None else min(turns_ms, dt * 1e3)
+        for e in reps[1:]:
+            e.close()
+        for b in bufs[1:]:
+            b.free()
     eng.enable_timing(True)
     acc, launches = {}, {}
     for _ in range(5):
@@ -496,7 +594,9 @@ def measure_other_config(args, engine, synth, local_rank, name, nb, n_checked):
            "dominant_kernel_frac": alg_bytes / (kern_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "kernel_ms": {k: round(v, 5) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])},
            "traffic_total": load_traffic_total(launches, workload_key)[0],
-           "note": "best of 3 runs of `steps` steps enqueued back to back, one host wait per run; kernel_ms from HIP events around every "
+           "ms_per_step_three_handles": turns_ms, "waypoints_per_s_three_handles": (float(sum(w_all)) / (turns_ms * 1e-3)) if turns_ms else None,
+           "note": "best of 3 runs of `steps` steps enqueued back to back, one host wait per run (ms_per_step: on one handle; ms_per_step_three_handles: "
+                   "the steps taking turns on three handles with the same resident cloud, as in the headline's loop); kernel_ms from HIP events around every "
                    "launch of a pass enqueued directly (full-width launches; the timed loop's graph may run a batch as two halves)"}
     if n_checked:
         from oracle import ppo

@@ -51,6 +51,36 @@ int main(int argc, char **argv)
         std::printf("cloud %zu: set_cloud_device %.1f  run_async %.1f  sync %.1f  total %.1f us   W %zu\n", i, us(t0, t1), us(t1, t2), us(t2, t3), us(t0, t3), W);
         if (i >= 2) { tot.push_back(us(t0, t3)); a_.push_back(us(t0, t1)); b_.push_back(us(t1, t2)); c_.push_back(us(t2, t3)); }
     }
+    if (std::getenv("PPP_COLD_STREAM")) {
+        /* a stream of never-seen clouds through TWO handles taking turns: a handle waits for its own pass of two clouds ago (and
+           reads that cloud's bounds: the plan made ahead of them is settled there), takes the next cloud without waiting and
+           enqueues its pass; the other handle's pass runs meanwhile.  Per cloud = the whole loop / clouds. */
+        ppp_handle h2 = nullptr;
+        if (ppp_create(0, &h2) != PPP_OK || ppp_set_params(h2, &p) != PPP_OK) return 1;
+        ppp_handle H[2] = {h, h2};
+        for (int w = 0; w < 2; ++w) /* both handles warm: a plan of this size each */
+            for (size_t i = 0; i < 2; ++i)
+                if (ppp_set_cloud_device(H[w], dev[i], ns[i], 12, nullptr) != PPP_OK || ppp_run_async(H[w]) != PPP_OK || ppp_sync(H[w]) != PPP_OK) return 1;
+        const int rounds = 40;
+        size_t Wsum = 0;
+        const auto s0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < rounds; ++k) {
+            ppp_handle g = H[k & 1];
+            size_t W = 0;
+            int rc = ppp_sync(g);
+            if (rc == PPP_OK) rc = ppp_num_waypoints(g, &W);
+            Wsum += W;
+            const size_t i = (size_t)k % dev.size();
+            if (rc == PPP_OK) rc = ppp_set_cloud_device_async(g, dev[i], ns[i], 12, nullptr);
+            if (rc == PPP_OK) rc = ppp_run_async(g);
+            if (rc != PPP_OK) { std::printf("stream: error %d: %s\n", rc, ppp_last_error(g)); return 1; }
+        }
+        if (ppp_sync(H[0]) != PPP_OK || ppp_sync(H[1]) != PPP_OK) return 1;
+        const double total = us(s0, std::chrono::steady_clock::now());
+        std::printf("stream of never-seen clouds, two handles taking turns: %d clouds in %.1f us = %.1f us per cloud (%zu waypoints read back on the way)\n",
+                    rounds, total, total / rounds, Wsum);
+        ppp_destroy(h2);
+    }
     std::sort(tot.begin(), tot.end());
     std::printf("C caller, clouds 2..: min set_cloud_device %.1f, run_async %.1f, sync %.1f; total min %.1f, median %.1f us\n", *std::min_element(a_.begin(), a_.end()),
                 *std::min_element(b_.begin(), b_.end()), *std::min_element(c_.begin(), c_.end()), tot.front(), tot[tot.size() / 2]);

@@ -20,4 +20,5 @@ PY
 PPP_COLD_WAITING_CALL=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/waiting for the bounds (ppp_set_cloud_device): /'
 PPP_COLD_COPY_BEFORE=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/each cloud copied to the device right before it is timed: /'
 PPP_COLD_COPY_BEFORE=1 PPP_COLD_WAITING_CALL=1 "$D/cold_path" "$D"/c*.pcd | tail -1 | sed 's/^/  ... and waiting for the bounds: /'
+PPP_COLD_STREAM=1 "$D/cold_path" "$D"/c*.pcd | grep "^stream"
 rm -rf "$D"
