@@ -2683,6 +2683,13 @@ int ppp_get_stream(ppp_handle h, void **stream)
 int ppp_sync_batch(ppp_handle *hs, size_t count, size_t *failed)
 {
     if (!hs || !count) return PPP_ERR_ARG;
+    /* the members' meta blocks travel side by side: every handle that has none on its way gets its copy enqueued first (a copy and
+       a wait per handle, one after the other, cost three handles 90 us at the end of a loop) */
+    for (size_t i = 0; i < count; ++i) {
+        ppp_handle h = hs[i];
+        if (h && h->have_cloud && !h->plan_deferred && !h->pending_stream && !h->meta_in_flight && !h->meta_fresh && hipSetDevice(h->device) == hipSuccess)
+            (void)enqueue_meta_copy(h);
+    }
     for (size_t i = 0; i < count; ++i) {
         int rc = ppp_sync(hs[i]);
         if (rc) { if (failed) *failed = i; return rc; }
