@@ -635,9 +635,31 @@ def measure_dynamic(args, engine, cfg, pts, local_rank, check):
         e.run_async()
     e.sync()
     ms = (time.perf_counter() - t) / steps * 1e3
+    # ... and as a stream of workpieces: the chain of one workpiece fills a quarter of the chip (one wave per Area2Cloud evaluation), the
+    # chains of three workpieces on three handles run side by side
+    reps = [e]
+    for _ in range(2):
+        r = engine.Engine(local_rank, tool_radius=cfg["tool_radius"], dynamic_adjustment=1)
+        r.set_cloud(pts); r.gen_path(); r.get_path()
+        r.run_async(); r.sync()
+        reps.append(r)
+    ms3 = None
+    for _ in range(2):
+        t = time.perf_counter()
+        for k in range(3 * steps):
+            reps[k % 3].run_async()
+        for r in reps:
+            r.sync()
+        dt = (time.perf_counter() - t) / (3 * steps) * 1e3
+        ms3 = dt if ms3 is None else min(ms3, dt)
+    same = bool(all(np.array_equal(r.waypoints(), e.waypoints()) for r in reps[1:]))
+    for r in reps[1:]:
+        r.close()
     out = {"ms_per_step": ms, "waypoints_per_s": W / (ms * 1e-3), "waypoints": int(W), "steps": steps,
+           "ms_per_step_three_handles": ms3, "waypoints_per_s_three_handles": W / (ms3 * 1e-3), "replicas_equal": same,
            "note": "Dynamic_adjustment = true (the reference's config.txt default): slice s is re-fitted against the boundary of slice s-1, "
-                   "so the slices form a chain of dependent launches"}
+                   "so the slices form a chain of dependent launches; ms_per_step: one workpiece at a time on one handle; "
+                   "ms_per_step_three_handles: consecutive workpieces taking turns on three handles (their chains run side by side)"}
     if check == "oracle":
         from oracle import ppo
         o = ppo.Oracle(pts, tool_radius=cfg["tool_radius"], dynamic_adjustment=1)

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Steps of the headline workload enqueued on N handles taking turns (each handle = its own stream and buffers, the same resident
 cloud on each): what overlapping consecutive, independent passes is worth against one handle's back-to-back steps.
-usage: python tools/two_handles.py [config] [steps]"""
+usage: python tools/two_handles.py [config] [steps] [--dynamic]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from polishpathplanning_amd import engine, synth
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg2_1m_s256"
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+args = [a for a in sys.argv[1:] if a != "--dynamic"]
+dyn = 1 if "--dynamic" in sys.argv else 0          # Dynamic_adjustment = true: a chain of dependent steps that fills a quarter of the chip
+name = args[0] if len(args) > 0 else "cfg2_1m_s256"
+steps = int(args[1]) if len(args) > 1 else 200
 pts, cfg = synth.make_config(name)
-for nh in (1, 2, 3, 4):
-    hs = [engine.Engine(0, tool_radius=cfg["tool_radius"]) for _ in range(nh)]
+for nh in ((1, 2, 3, 4, 6, 8) if dyn else (1, 2, 3, 4)):
+    hs = [engine.Engine(0, tool_radius=cfg["tool_radius"], dynamic_adjustment=dyn) for _ in range(nh)]
     for h in hs:
         h.set_cloud(pts)
         for _ in range(3):
@@ -25,6 +27,6 @@ for nh in (1, 2, 3, 4):
             h.sync()
         best = min(best, (time.perf_counter() - t) / steps * 1e3)
     W = hs[0].num_waypoints()
-    print("%s: %d handle(s) taking turns: %.4f ms per step, %.3e waypoints/s" % (name, nh, best, W / (best * 1e-3)), flush=True)
+    print("%s%s: %d handle(s) taking turns: %.4f ms per step, %.3e waypoints/s" % (name, " with Dynamic_adjustment" if dyn else "", nh, best, W / (best * 1e-3)), flush=True)
     for h in hs:
         h.close()
