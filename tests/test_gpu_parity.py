@@ -1773,6 +1773,35 @@ def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):
     assert d["assembled_path"]["rank0_block_equals_its_list"] and d["roofline"]["kernel"].startswith("k_")
 
 
+def test_bench_line_of_a_one_gpu_run(tmp_path):
+    """The default form of bench.py on one GPU (a small workload here): ONE JSON line with the contract's fields; consecutive steps take
+    turns on three engine handles, every replica's list is the first handle's byte for byte, the one-handle loop is timed beside it, the
+    oracle is the checker (path_l2_err) and the CPU baseline, and the roofline object names the dominant kernel with its duration alone
+    on the device and under the loop's overlap."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small_40k", "--steps", "12", "--warmup", "3", "--rotate", "2",
+                        "--no-other-configs", "--profile-passes", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["vs_baseline"] is None and d["unit"] == "waypoints/s" and d["higher_is_better"] is True
+    assert d["config"]["handles_taking_turns"] == 3 and d["single_handle"]["replicas_equal"] is True
+    assert abs(d["value"] - d["config"]["waypoints_per_workpiece"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["single_handle"]["ms_per_step"] > 0 and d["assembled_path"]["rank0_block_equals_its_list"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"].startswith("k_win_") and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["avg_launch_ms_steps_taking_turns"] > 0 and 0 < rf["pipeline_frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert d["path_l2_err"]["waypoints_equal"] and d["path_l2_err"]["max_m"] <= TOL_M
+    assert d["dynamic"]["replicas_equal"] and d["dynamic"]["ms_per_step_three_handles"] > 0
+    assert d["latency"]["cold_ms"] > 0
+
+
 @pytest.mark.parametrize("name,walk,kw", [("small_40k", 1, {}), ("small_40k", 0, {}), ("small_40k", 2, {}), ("small_40k", 3, {}), ("small_40k", 4, {}),
                                           ("cfg3_250k_s128", 1, {}), ("small_40k", 1, dict(trim=5.0, drop_ends=0, smooth=0)),
                                           ("small_40k", 1, dict(path_resolution=3.0, rpy_resolution=0.0)), ("small_40k", 1, dict(change_range=0)),
