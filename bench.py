@@ -212,10 +212,13 @@ def main():
     # A handle is a HIP stream with its own buffers: step k's binning launch runs beside step k-1's per-slice kernel instead
     # of behind its finish launch (three dependent launches per pass leave most of the chip idle most of the time).  Every
     # replica holds the same resident cloud and plans the whole pass; each writes its list to a buffer of its own.
-    # (Not with an exchange in the step -- N > 1, the one-rank rehearsal --: untested on several GPUs, those runs keep one handle.)
+    # With an exchange in the step (N > 1, the one-rank rehearsal) every handle has a buffer pair and a planner stream of its own; the
+    # framework runs the collectives one after the other on the communicator's stream, in the order they are called (run_chained_steps).
     turns = args.handles if args.handles > 0 else 3
-    if world > 1 or force_dist or args.batch != 1 or args.dynamic or host_waits or os.environ.get("PPP_BENCH_EVENT_ORDER") == "1":
+    with_exchange = world > 1 or force_dist
+    if args.batch != 1 or args.dynamic or host_waits or os.environ.get("PPP_BENCH_EVENT_ORDER") == "1":
         turns = 1
+
     replicas, outs = [eng], []
     if turns > 1:
         for _ in range(turns - 1):
@@ -224,7 +227,12 @@ def main():
             if (e.gen_path(), e.get_path()) != (S, W):
                 raise SystemExit("a replica of the workpiece planned another list")
             replicas.append(e)
-        outs = [torch.empty((max(W, 1), 6), dtype=torch.float32, device=dev) for _ in range(turns)]
+        if with_exchange:   # a buffer pair and a planner stream per handle; the collectives run in call order on the communicator's own stream
+            turn_gatherers = [RobotPathGatherer(sum(w_all), dist, dev, force_collective=force_dist) for _ in range(turns)]
+            outs = [g.send for g in turn_gatherers]
+            turn_streams = [torch.cuda.ExternalStream(r.stream_ptr(), device=dev) for r in replicas]
+        else:
+            outs = [torch.empty((max(W, 1), 6), dtype=torch.float32, device=dev) for _ in range(turns)]
 
     def plan_turn(k):
         engine.run_batch_async([replicas[k % turns]], outs[k % turns].data_ptr(), offs, w_all)
@@ -232,6 +240,11 @@ def main():
     def run_turns(count):
         if count <= 0:
             return None
+        if with_exchange:
+            blocks = run_chained_steps(count, plan_turn, turn_gatherers, turn_streams)
+            engine.sync_batch(replicas)
+            torch.cuda.current_stream().synchronize()
+            return blocks
         for k in range(count):
             plan_turn(k)
         engine.sync_batch(replicas)

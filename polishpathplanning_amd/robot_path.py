@@ -207,25 +207,34 @@ def run_streamed_steps(count, plan, gatherers, order, on_blocks=None):
 
 
 def run_chained_steps(count, plan, gatherers, planner_stream=None, on_blocks=None):
-    """`count` plan+gather steps on ONE stream order: step k's collective is enqueued behind step k's planning in the
-    planner's own stream (asynchronously: the planner does not wait for it), and the planner waits for it only two steps
-    later, just before it plans into the same buffer pair again -- by then it has long finished.  No second framework
-    stream and no host wait inside the loop; the collective of step k still overlaps the planning of step k+1.
+    """`count` plan+gather steps: step k's collective is enqueued behind step k's planning in the planner's own stream
+    (asynchronously: the planner does not wait for it), and the planner waits for it only when it plans into the same buffer
+    pair again, len(gatherers) steps later -- by then it has long finished.  No second framework stream and no host wait inside
+    the loop; the collective of step k overlaps the planning of the steps behind it.
     (Measured on one GPU with a one-rank RCCL group, cfg 2: 0.166 ms per step, against 0.177 ms with the collective on the
     framework's default stream and events in between -- a third active hardware queue slows every dispatch -- and 0.156 ms
     with the planner waiting for each collective at once, which is the better choice only while the collective is as
     short as a one-rank copy.  Without any exchange a step takes 0.144 ms.)
 
-    plan(k)           enqueues step k's planning into gatherers[k % 2].send on planner_stream
-    planner_stream    torch.cuda.ExternalStream around Engine.stream_ptr(); None for synchronous back ends (gloo tests)
+    plan(k)           enqueues step k's planning into gatherers[k % H].send on the planner stream of step k
+    gatherers         H >= 2 buffer pairs, used in turn
+    planner_stream    torch.cuda.ExternalStream around Engine.stream_ptr() -- or a list of H of them when the steps take turns on
+                      H engine handles (step k plans on handle k % H: its stream, its buffer pair; the framework runs the
+                      collectives themselves one after the other on the communicator's own stream, in the order they are
+                      called here, which is the same on every rank); None for synchronous back ends (gloo tests)
     on_blocks(k, b)   optional: called with step k's blocks once its collective has been waited for (None off rank 0)
-    The caller synchronises the planner stream once at the end.  Returns the last step's blocks."""
+    The caller synchronises the planner stream(s) once at the end.  Returns the last step's blocks."""
     import contextlib
-    assert len(gatherers) == 2
+    H = len(gatherers)
+    assert H >= 2
     torch = gatherers[0].torch
-    ctx = (lambda: torch.cuda.stream(planner_stream)) if planner_stream is not None else contextlib.nullcontext
-    works = [None, None]
-    pending = [None, None]      # step number whose collective is in flight on buffer b
+    streams = planner_stream if isinstance(planner_stream, (list, tuple)) else [planner_stream] * H
+    assert len(streams) == H
+
+    def ctx(b):
+        return torch.cuda.stream(streams[b]) if streams[b] is not None else contextlib.nullcontext()
+    works = [None] * H
+    pending = [None] * H        # step number whose collective is in flight on buffer pair b
     blocks = None
 
     def finish(b):
@@ -233,7 +242,7 @@ def run_chained_steps(count, plan, gatherers, planner_stream=None, on_blocks=Non
         if pending[b] is None:
             return
         if works[b] is not None:
-            with ctx():
+            with ctx(b):
                 works[b].wait()              # a stream wait (the host goes on), or a host wait for synchronous back ends
         blocks = gatherers[b].blocks()
         if on_blocks:
@@ -241,14 +250,13 @@ def run_chained_steps(count, plan, gatherers, planner_stream=None, on_blocks=Non
         works[b] = None; pending[b] = None
 
     for k in range(count):
-        b = k % 2
+        b = k % H
         finish(b)
         plan(k)
-        works[b] = gatherers[b].gather_async(planner_stream)
+        works[b] = gatherers[b].gather_async(streams[b])
         pending[b] = k
-    for k in (count - 2, count - 1):         # the last two steps, in order
-        if k >= 0:
-            finish(k % 2)
+    for k in range(max(0, count - H), count):    # the last H steps, in order
+        finish(k % H)
     return blocks
 
 

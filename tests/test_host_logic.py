@@ -206,6 +206,24 @@ def _pipeline_worker(rank, world, port, q):
             assert (last is None) == (count == 0)
         else:
             assert last is None
+    # the same chain with THREE buffer pairs taken in turn (bench.py's steps on three engine handles, each with its own pair): every
+    # step's blocks arrive once, in step order, from both ranks
+    g3 = [RobotPathGatherer(w, dist, torch.device("cpu")) for _ in range(3)]
+
+    def plan3(k):
+        g3[k % 3].send[:w] = (torch.arange(w, dtype=torch.float32)[:, None] + 100.0 * k + 1000.0 * rank).expand(w, 6)
+    for count in (0, 1, 2, 3, 4, 7):
+        del seen[:]
+        last = run_chained_steps(count, plan3, g3, [None, None, None], on_blocks)
+        if rank == 0:
+            assert [k for k, _ in seen] == list(range(count))
+            for k, blocks in seen:
+                for r, b in enumerate(blocks):
+                    want = (torch.arange(b.shape[0], dtype=torch.float32)[:, None] + 100.0 * k + 1000.0 * r).expand(-1, 6)
+                    assert b.shape[0] == [4, 9][r] and torch.equal(b, want), (count, k, r)
+            assert (last is None) == (count == 0)
+        else:
+            assert last is None
     if rank == 0:
         q.put("ok")
     dist.barrier()
