@@ -742,10 +742,12 @@ def measure_rotation_and_cold(args, torch, dev, engine, synth, cfg, base_seed, e
             "cold_first_ms": cold[0][0], "cold_ms": min(c[0] for c in cold[1:]), "cold_median_ms": float(np.median([c[0] for c in cold[1:]])),
             "cold_split_ms": {"set_cloud_device": min(c[1] for c in cold[1:]), "first_run_async_and_wait": min(c[2] for c in cold[1:])},
             "cold_c_caller_ms": c_caller[0], "cold_c_caller_median_ms": c_caller[1],
+            "new_clouds_through_queue_ms_by_lanes": c_caller[2],
             "note": "host wait after every step in both loops; cold = set_cloud_device_async + first run_async + wait on a never-seen cloud "
                     "already in device memory (cold_first also pays the handle's buffer allocations); cold_ms is timed around the ctypes "
                     "calls of this process, cold_c_caller_ms by tools/cold_path (the same three calls from C, a child process, the cloud "
-                    "copied to the device right before it is timed; null when that binary was not built)"}
+                    "copied to the device right before it is timed; null when that binary was not built); new_clouds_through_queue_ms_by_lanes: a stream "
+                    "of never-seen clouds through ppp_queue_* (handles taking turns), ms per cloud by number of lanes, same child process"}
 
 
 def cold_path_from_c(args, engine, synth, base_seed):
@@ -755,7 +757,7 @@ def cold_path_from_c(args, engine, synth, base_seed):
     exe = os.path.join(ROOT, "tools", "cold_path")
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
     if not os.path.exists(exe) or profiled:   # (no child process under a profiler's preloaded library)
-        return None, None
+        return None, None, None
     try:
         with tempfile.TemporaryDirectory() as d:
             names = []
@@ -763,16 +765,21 @@ def cold_path_from_c(args, engine, synth, base_seed):
                 p2, _ = synth.make_config(args.config, seed=base_seed + 15485863 * (k + 1))
                 names.append(os.path.join(d, "c%d.pcd" % k))
                 engine.save_pcd(names[-1], np.ascontiguousarray(p2), binary=True)
-            r = subprocess.run([exe] + names, env=dict(os.environ, PPP_COLD_COPY_BEFORE="1"), capture_output=True, text=True, timeout=120)
+            r = subprocess.run([exe] + names, env=dict(os.environ, PPP_COLD_COPY_BEFORE="1", PPP_COLD_STREAM="1"), capture_output=True, text=True, timeout=120)
         if r.returncode != 0:
             sys.stderr.write("bench: tools/cold_path failed (%d): %s\n" % (r.returncode, (r.stdout + r.stderr)[-300:]))
-            return None, None
-        last = r.stdout.strip().splitlines()[-1]              # "... total min 88.8, median 89.7 us"
+            return None, None, None
+        lines = r.stdout.strip().splitlines()
+        last = [ln for ln in lines if ln.startswith("C caller")][-1]              # "... total min 88.8, median 89.7 us"
         a = last.split("total min ")[1]
-        return float(a.split(",")[0]) / 1e3, float(a.split("median ")[1].split(" ")[0]) / 1e3
+        stream = {}
+        for ln in lines:                                                          # "stream ... planner queue, 2 lane(s): 60 clouds in 2988.0 us = 49.8 us per cloud ..."
+            if ln.startswith("stream of never-seen clouds") and " lane(s):" in ln:
+                stream[int(ln.split("queue, ")[1].split(" lane")[0])] = float(ln.split(" = ")[1].split(" us per cloud")[0]) / 1e3
+        return float(a.split(",")[0]) / 1e3, float(a.split("median ")[1].split(" ")[0]) / 1e3, (stream or None)
     except Exception as ex:
         sys.stderr.write("bench: tools/cold_path: %r\n" % (ex,))
-        return None, None
+        return None, None, None
 
 
 def bench_slices(args, rank, local_rank, world, dev, dist, torch, engine, synth):

@@ -331,6 +331,25 @@ int ppp_read_config(const char *path, ppp_config *c);
 /* pathFile writer (path_translation_alg.cpp:216-228): "x y z r p y " per line, ostream defaults */
 int ppp_write_path_file(const char *path, const float *wp6, size_t W);
 
+/* ---- a planner queue: workpieces in, lists out, a few handles behind it taking turns ----
+ * A pass is three dependent launches that leave most of the chip idle most of the time; passes enqueued on different handles (HIP
+ * streams) overlap.  The queue keeps `lanes` handles (0 = 2: best for a stream of new clouds, 50 us per 1 M-point cloud against 88 on one
+ * lane and 62 on three; replays of resident clouds do best on three handles, four and more collide on the runtime's hardware queues)
+ * with the given parameters and gives workpiece k to lane k mod lanes: ppp_queue_submit waits for that lane's earlier pass,
+ * takes the cloud -- already in device memory, untouched until ppp_queue_wait of this ticket has returned -- without waiting for
+ * its bounds where the lane's plan allows (ppp_set_cloud_device_async) and enqueues its pass; ppp_queue_wait returns the finished
+ * list (device pointer into the lane, W rows of 6 floats; valid until `lanes` more workpieces have been submitted) or the error the
+ * workpiece ended with.  Everything a caller could do with the handles itself (ppp_queue_lane gives them out, e.g. for
+ * ppp_get_waypoints of the lane that holds a ticket); not thread-safe: one submitting thread. */
+typedef struct ppp_queue_s *ppp_queue;
+int ppp_queue_create(int device, int lanes, const ppp_params *params, ppp_queue *q);
+void ppp_queue_destroy(ppp_queue q);
+int ppp_queue_submit(ppp_queue q, const float *xyz_dev, size_t n, size_t stride_bytes, const float *viewpoint, long long *ticket);
+int ppp_queue_wait(ppp_queue q, long long ticket, size_t *W, const float **list_dev);
+int ppp_queue_lanes(ppp_queue q);
+ppp_handle ppp_queue_lane(ppp_queue q, int i);
+const char *ppp_queue_last_error(ppp_queue q);
+
 /* ---- which launch sequence plans a cloud ---- */
 /* Plan reuse (default on).  The first cloud of a handle sizes the window path's LDS capacities from a census of its own windows
  * (one more launch behind the conversion pass of ppp_set_cloud*).  A later cloud with the same point count and parameters, whose

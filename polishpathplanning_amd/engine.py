@@ -80,6 +80,7 @@ EXPORTS = [
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
     "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse", "ppp_set_cloud_pcd", "ppp_pcd_probe", "ppp_set_cloud_device_async",
+    "ppp_queue_create", "ppp_queue_destroy", "ppp_queue_submit", "ppp_queue_wait", "ppp_queue_lanes", "ppp_queue_lane", "ppp_queue_last_error",
 ]
 
 
@@ -117,6 +118,13 @@ def lib():
         L.ppp_set_cloud.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device_async.argtypes = [vp, vp, sz, sz, fp]
+        L.ppp_queue_create.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.POINTER(vp)]
+        L.ppp_queue_destroy.argtypes = [vp]; L.ppp_queue_destroy.restype = None
+        L.ppp_queue_submit.argtypes = [vp, vp, sz, sz, fp, C.POINTER(C.c_longlong)]
+        L.ppp_queue_wait.argtypes = [vp, C.c_longlong, szp, C.POINTER(vp)]
+        L.ppp_queue_lanes.argtypes = [vp]
+        L.ppp_queue_lane.argtypes = [vp, C.c_int]; L.ppp_queue_lane.restype = vp
+        L.ppp_queue_last_error.argtypes = [vp]; L.ppp_queue_last_error.restype = C.c_char_p
         L.ppp_num_points.argtypes = [vp, szp]
         L.ppp_range_interval.argtypes = [C.POINTER(Params), C.c_float, C.c_float, fp, fp, ip]
         L.ppp_set_cloud_part.argtypes = [vp, vp, sz, sz, fp, ip, fp, fp, sz, C.c_float, C.c_float]
@@ -212,6 +220,57 @@ def load_pcd(path):
     xyz = np.ctypeslib.as_array(p, shape=(max(n.value, 1) * 3,))[: n.value * 3].reshape(-1, 3).copy()
     L.ppp_free(p)
     return xyz, vp
+
+
+class PlannerQueue:
+    """ppp_queue_*: workpieces in, lists out, `lanes` engine handles (default 2) behind it taking turns -- the passes of neighbouring
+    workpieces overlap on the device.  submit(dptr, n) takes a cloud that is already in device memory (untouched until wait() of its
+    ticket has returned) and returns a ticket; wait(ticket) returns (W, device pointer of the W x 6 list) -- valid until `lanes` more
+    workpieces have been submitted -- or raises what that workpiece ended with."""
+
+    def __init__(self, device=0, lanes=0, **params):
+        self.L = lib()
+        p = Params()
+        self.L.ppp_default_params(C.byref(p))
+        for k, v in params.items():
+            if k == "handeye":
+                for j, x in enumerate(v):
+                    p.handeye[j] = x
+            else:
+                setattr(p, k, v)
+        q = C.c_void_p()
+        rc = self.L.ppp_queue_create(device, lanes, C.byref(p), C.byref(q))
+        if rc:
+            raise PPPError(rc, "ppp_queue_create failed")
+        self.q = q
+        self.lanes = self.L.ppp_queue_lanes(q)
+
+    def _chk(self, rc):
+        if rc:
+            raise PPPError(rc, self.L.ppp_queue_last_error(self.q).decode())
+
+    def submit(self, dptr, n, stride_bytes=12, viewpoint=None):
+        t = C.c_longlong()
+        vp = None if viewpoint is None else _f(np.ascontiguousarray(viewpoint, np.float32))
+        self._chk(self.L.ppp_queue_submit(self.q, C.c_void_p(dptr), n, stride_bytes, vp, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        W = C.c_size_t()
+        d = C.c_void_p()
+        self._chk(self.L.ppp_queue_wait(self.q, ticket, C.byref(W), C.byref(d)))
+        return W.value, d.value
+
+    def close(self):
+        if self.q:
+            self.L.ppp_queue_destroy(self.q)
+            self.q = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PcdLayout(C.Structure):

@@ -1773,6 +1773,61 @@ def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):
     assert d["assembled_path"]["rank0_block_equals_its_list"] and d["roofline"]["kernel"].startswith("k_")
 
 
+def test_planner_queue_lists_equal_fresh_handles(engine_mod):
+    """ppp_queue_*: a stream of workpieces through three lanes (handles) taking turns -- same-size clouds (handed over without a wait for
+    their bounds, their passes overlapping on the device), a cloud of another size in between, one without a single finite point.
+    Every ticket's list is the list a fresh handle plans for that cloud, byte for byte; the empty cloud ends in its own error and
+    the queue goes on; a ticket whose lane has been given a later workpiece is refused."""
+    from polishpathplanning_amd.hipbuf import DeviceBuffer
+    import ctypes as C
+    base, cfg = synth.make_config("small_40k")
+    clouds = [synth.make_config("small_40k", seed=300 + k)[0] for k in range(8)]
+    clouds[3] = synth.make_config("tiny_5k")[0]                       # another size: planned from scratch in its lane
+    clouds[5] = np.full_like(clouds[5], np.nan)                        # nothing to plan
+    bufs = []
+    for c in clouds:
+        b = DeviceBuffer(c.nbytes); b.upload(np.ascontiguousarray(c, np.float32)); bufs.append(b)
+    q0 = engine_mod.PlannerQueue(0, tool_radius=6.0)
+    assert q0.lanes == 2                                                       # the default: a stream of new clouds
+    q0.close()
+    q = engine_mod.PlannerQueue(0, lanes=3, tool_radius=6.0)
+    assert q.lanes == 3
+    tickets = [q.submit(bufs[k].ptr, len(clouds[k])) for k in range(3)]       # three in flight
+    results = {}
+    for k in range(3, len(clouds) + 3):
+        t = tickets[k - 3]
+        try:
+            W, dptr = q.wait(t)
+            tmp = DeviceBuffer(max(W, 1) * 24); 
+            from polishpathplanning_amd.hipbuf import _rt
+            assert _rt().hipMemcpy(C.c_void_p(tmp.ptr), C.c_void_p(dptr), C.c_size_t(W * 24), 3) == 0
+            results[t] = tmp.to_host(6 * W).reshape(-1, 6)
+            tmp.free()
+        except engine_mod.PPPError as ex:
+            results[t] = ("error", ex.code)
+        if k < len(clouds):
+            tickets.append(q.submit(bufs[k].ptr, len(clouds[k])))
+    assert tickets == list(range(len(clouds)))
+    with pytest.raises(engine_mod.PPPError):
+        q.wait(tickets[1])                                                     # its lane has planned two workpieces since
+    for k, c in enumerate(clouds):
+        f = engine_mod.Engine(0, tool_radius=6.0); f.set_plan_reuse(False)
+        try:
+            f.set_cloud(c); f.run_async(); f.sync()
+            want = f.waypoints()
+        except engine_mod.PPPError as ex:
+            want = ("error", ex.code)
+        f.close()
+        got = results[tickets[k]]
+        if isinstance(want, tuple):
+            assert got == want, (k, got, want)
+        else:
+            assert not isinstance(got, tuple) and got.shape == want.shape and got.tobytes() == want.tobytes(), k
+    q.close()
+    for b in bufs:
+        b.free()
+
+
 def test_bench_line_of_a_one_gpu_run(tmp_path):
     """The default form of bench.py on one GPU (a small workload here): ONE JSON line with the contract's fields; consecutive steps take
     turns on three engine handles, every replica's list is the first handle's byte for byte, the one-handle loop is timed beside it, the

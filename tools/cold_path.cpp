@@ -52,34 +52,33 @@ int main(int argc, char **argv)
         if (i >= 2) { tot.push_back(us(t0, t3)); a_.push_back(us(t0, t1)); b_.push_back(us(t1, t2)); c_.push_back(us(t2, t3)); }
     }
     if (std::getenv("PPP_COLD_STREAM")) {
-        /* a stream of never-seen clouds through TWO handles taking turns: a handle waits for its own pass of two clouds ago (and
-           reads that cloud's bounds: the plan made ahead of them is settled there), takes the next cloud without waiting and
-           enqueues its pass; the other handle's pass runs meanwhile.  Per cloud = the whole loop / clouds. */
-        ppp_handle h2 = nullptr;
-        if (ppp_create(0, &h2) != PPP_OK || ppp_set_params(h2, &p) != PPP_OK) return 1;
-        ppp_handle H[2] = {h, h2};
-        for (int w = 0; w < 2; ++w) /* both handles warm: a plan of this size each */
-            for (size_t i = 0; i < 2; ++i)
-                if (ppp_set_cloud_device(H[w], dev[i], ns[i], 12, nullptr) != PPP_OK || ppp_run_async(H[w]) != PPP_OK || ppp_sync(H[w]) != PPP_OK) return 1;
-        const int rounds = 40;
-        size_t Wsum = 0;
-        const auto s0 = std::chrono::steady_clock::now();
-        for (int k = 0; k < rounds; ++k) {
-            ppp_handle g = H[k & 1];
-            size_t W = 0;
-            int rc = ppp_sync(g);
-            if (rc == PPP_OK) rc = ppp_num_waypoints(g, &W);
-            Wsum += W;
-            const size_t i = (size_t)k % dev.size();
-            if (rc == PPP_OK) rc = ppp_set_cloud_device_async(g, dev[i], ns[i], 12, nullptr);
-            if (rc == PPP_OK) rc = ppp_run_async(g);
-            if (rc != PPP_OK) { std::printf("stream: error %d: %s\n", rc, ppp_last_error(g)); return 1; }
+        /* a stream of never-seen clouds through the planner queue (ppp_queue_*: handles taking turns; a lane waits for its own pass of
+           `lanes` clouds ago, takes the next cloud without waiting for its bounds and enqueues its pass while the other lanes' passes
+           run).  Per cloud = the whole loop / clouds; every list's row count is read back on the way. */
+        for (int lanes = 1; lanes <= 3; ++lanes) {
+            ppp_queue q = nullptr;
+            if (ppp_queue_create(0, lanes, &p, &q) != PPP_OK) return 1;
+            const int rounds = 60;
+            std::vector<long long> tk((size_t)rounds, -1);
+            size_t Wsum = 0;
+            auto run = [&](int count) -> int {
+                for (int k = 0; k < count; ++k) {
+                    if (k >= lanes) { size_t W = 0; if (ppp_queue_wait(q, tk[(size_t)(k - lanes)], &W, nullptr) != PPP_OK) return 1; Wsum += W; }
+                    const size_t i = (size_t)k % dev.size();
+                    if (ppp_queue_submit(q, dev[i], ns[i], 12, nullptr, &tk[(size_t)k]) != PPP_OK) return 1;
+                }
+                for (int k = std::max(0, count - lanes); k < count; ++k) { size_t W = 0; if (ppp_queue_wait(q, tk[(size_t)k], &W, nullptr) != PPP_OK) return 1; Wsum += W; }
+                return 0;
+            };
+            if (run(3 * lanes)) { std::printf("stream: %s\n", ppp_queue_last_error(q)); return 1; } /* every lane warm: a plan of this size each */
+            Wsum = 0;
+            const auto s0 = std::chrono::steady_clock::now();
+            if (run(rounds)) { std::printf("stream: %s\n", ppp_queue_last_error(q)); return 1; }
+            const double total = us(s0, std::chrono::steady_clock::now());
+            std::printf("stream of never-seen clouds through the planner queue, %d lane(s): %d clouds in %.1f us = %.1f us per cloud (%zu waypoints)\n", lanes, rounds, total,
+                        total / rounds, Wsum);
+            ppp_queue_destroy(q);
         }
-        if (ppp_sync(H[0]) != PPP_OK || ppp_sync(H[1]) != PPP_OK) return 1;
-        const double total = us(s0, std::chrono::steady_clock::now());
-        std::printf("stream of never-seen clouds, two handles taking turns: %d clouds in %.1f us = %.1f us per cloud (%zu waypoints read back on the way)\n",
-                    rounds, total, total / rounds, Wsum);
-        ppp_destroy(h2);
     }
     std::sort(tot.begin(), tot.end());
     std::printf("C caller, clouds 2..: min set_cloud_device %.1f, run_async %.1f, sync %.1f; total min %.1f, median %.1f us\n", *std::min_element(a_.begin(), a_.end()),
