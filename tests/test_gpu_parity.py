@@ -2038,6 +2038,15 @@ def test_pass_enqueued_ahead_of_the_new_clouds_bounds(tmp_path):
         # GenPath / getPath as separate calls, and a replay on the inherited plan before anything was asked
         set_async(h, variant(21)); h.gen_path_async(); h.get_path_async(); h.run_async(); h.run_async(); h.sync()
         assert (h.num_slices(), h.waypoints().tobytes()) == fresh_result(variant(21))[:2]
+        # a captured pass (two run_async on one plan) and then a cloud seen from the other side: the viewpoint travels by value in the
+        # launches, so the capture must not be replayed for it
+        h.set_cloud(variant(22)); h.run_async(); h.run_async(); h.sync()
+        p = variant(23); dbuf.upload(np.ascontiguousarray(p, np.float32))
+        h.set_cloud_device_async(dbuf.ptr, len(p), 12, viewpoint=[0.0, 0.0, 5000.0]); h.run_async(); h.sync()
+        f = engine.Engine(0, tool_radius=6.0); f.set_plan_reuse(False); f.set_cloud(p, viewpoint=[0.0, 0.0, 5000.0]); f.run_async(); f.sync()
+        g = engine.Engine(0, tool_radius=6.0); g.set_cloud(p); g.run_async(); g.sync()
+        assert h.waypoints().tobytes() == f.waypoints().tobytes() and h.waypoints().tobytes() != g.waypoints().tobytes()
+        f.close(); g.close()
         print("same lists")
     """ % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PPP_WIN_DEBUG="1"), capture_output=True, text=True, timeout=900)
