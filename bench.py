@@ -221,8 +221,11 @@ def main():
 
     replicas, outs = [eng], []
     if turns > 1:
+        # (the first handle takes part: a fourth stream in the process -- even an idle one -- shares a hardware queue with one of the
+        #  three, 0.039 -> 0.048 ms per step; it is told about its neighbours for these loops only, see side_by_side below)
         for _ in range(turns - 1):
             e = engine.Engine(local_rank, tool_radius=cfg["tool_radius"])
+            e.set_side_by_side(turns)
             e.set_cloud(pts)
             if (e.gen_path(), e.get_path()) != (S, W):
                 raise SystemExit("a replica of the workpiece planned another list")
@@ -275,7 +278,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def side_by_side(n):
+        # how many passes share the device: from two on the plan keeps the slice workgroups of small windows at 512 threads, which leaves
+        # room on a CU for a neighbouring pass's binning and finish workgroups (ppp_set_side_by_side); the first handle is switched back
+        # for the one-handle loop and for the launches' durations alone on the device
+        if turns > 1:
+            eng.set_side_by_side(n)
+
     timed = run_turns if turns > 1 else run_steps
+    side_by_side(turns)
     timed(args.warmup)
     fence()
     t0 = time.perf_counter()
@@ -284,6 +295,7 @@ def main():
     elapsed = time.perf_counter() - t0
     w_local = w_step
     single = None
+    side_by_side(1)
     if turns > 1 and not args.no_single_handle:   # the same K steps on ONE handle, back to back (rounds 1-3's loop), for the record
         run_steps(args.warmup)
         fence()
@@ -385,6 +397,7 @@ def main():
         # the launches of the neighbouring steps, its own wall time (HIP events on ITS stream) grows while the loop's throughput does too
         kern_ms_turns = None
         if turns > 1:
+            side_by_side(turns)
             for r in replicas:
                 r.enable_timing(True)
             acc2 = {}
@@ -399,6 +412,7 @@ def main():
                         acc2.setdefault(k2, []).append(v2 / 2.0)
             for r in replicas:
                 r.enable_timing(False)
+            side_by_side(1)
             kern_ms_turns = {k2: float(np.mean(v2)) for k2, v2 in acc2.items()}
         # 12 B per point read once + 24 B per waypoint written once; one launch processes the whole batch
         alg_bytes = 12.0 * float(sum(int(c.shape[0]) for c in clouds)) + 24.0 * float(sum(w_all))

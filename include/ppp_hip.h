@@ -364,6 +364,11 @@ const char *ppp_queue_last_error(ppp_queue q);
  * plan did not fit is repeated by the engine.  An error of the new cloud itself (no finite point, ...) then surfaces at that
  * call instead of at the call that set the cloud.  0 turns both off (PPP_NO_DEFERRED_PLAN=1 in the environment: the waiting only). */
 int ppp_set_plan_reuse(ppp_handle h, int on);
+/* How many handles the caller runs side by side on this device (default 1).  From two on the plan trades a little of a pass's own
+ * latency for room on the CUs: the per-slice workgroups of small windows stay at 512 threads, so that a neighbouring pass's binning
+ * and finish workgroups fit beside them (1 M points / 256 slices on three handles: 0.038 -> 0.029 ms per workpiece; one pass alone
+ * 0.065 -> 0.068 ms).  Same lists either way.  ppp_queue_create sets it on its lanes. */
+int ppp_set_side_by_side(ppp_handle h, int handles);
 /* The engine has two launch sequences for the same hot path, with the same results up to the last bits of the normals'
  * float sums (both within the tolerances of tests/): the WINDOW path (three launches: every point binned once into the
  * window of its slice, one fused per-slice kernel, the finish; kd pairing, no dynamic adjustment / alignment, tool steps

@@ -231,6 +231,7 @@ struct ppp_handle_s {
        behind it -- the device checks walk length, pad, bounds and capacities against the record that pass leaves, and hands a
        pass back whose plan does not fit.  plan_deferred: that record has not been read yet (resolve_deferred does, at the first
        call that is not one of the three enqueue-only entry points). */
+    int side_by_side = 1; /* handles the caller runs side by side on this device (ppp_set_side_by_side): from two on the slice workgroups of small windows stay at 512 threads */
     bool plan_deferred = false, deferred_census = false;
     bool rec_current = false;   /* plan_auto holds the record of the resident cloud (it came through k_ingest_minmax and was not altered since) */
     bool plan_walk_ok = false;  /* the window plan's S, pad and plane table are the device's own, bit for bit (plan_window: census that came with the cloud, or inherited) */
@@ -525,6 +526,12 @@ int win_pick_threads(const ppp_handle h, long long wgs)
         if (const char *ev = tuning_env("PPP_WIN_WAVES_CU")) waves_cu = std::max(4, atoi(ev)); /* tuning runs only */
         T = std::min(wide, 64 * std::max(1, waves_cu / conc));
     }
+    /* Several handles side by side (ppp_set_side_by_side): the launches of neighbouring passes share the CUs, and two 1024-thread slice
+       workgroups fill a CU's 2048 thread slots -- no room for a binning or finish workgroup of another pass.  512-thread workgroups
+       leave it (1 M points / 256 slices, three handles: 0.0377 -> 0.0286 ms per step; alone a pass is 5 % slower: 0.065 -> 0.068).
+       Only where a window is small enough for six staged points per thread: at 2 M points / 256 slices (704 threads at least) and at
+       10 M / 1024 narrower workgroups were slower side by side too. */
+    if (h->side_by_side >= 2 && !win_throughput_launch(h, wgs) && capw <= 3072) T = std::min(T, 512);
     T = std::max(T, tmin);
     if (const char *ev = tuning_env("PPP_WIN_T")) { /* tuning runs only */
         const int tv = atoi(ev);
@@ -3298,6 +3305,22 @@ int ppp_set_plan_reuse(ppp_handle h, int on)
     if (h->plan_deferred) { HIPCHK(h, hipSetDevice(h->device)); int rcs = settle(h); if (rcs) return rcs; } /* (a cloud set under the old setting) */
     h->plan_reuse = on != 0;
     if (!h->plan_reuse) h->inh_valid = false;
+    return PPP_OK;
+}
+
+int ppp_set_side_by_side(ppp_handle h, int handles)
+{
+    if (!h || handles < 1) return PPP_ERR_ARG;
+    if (handles == h->side_by_side) return PPP_OK;
+    const bool changes = (handles >= 2) != (h->side_by_side >= 2);
+    h->side_by_side = handles;
+    if (changes && h->have_cloud) {
+        HIPCHK(h, hipSetDevice(h->device));
+        int rcs = settle(h);
+        if (rcs) return rcs;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return make_plan(h);
+    }
     return PPP_OK;
 }
 

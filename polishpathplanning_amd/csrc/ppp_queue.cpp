@@ -38,6 +38,7 @@ int queue_create(int device, int lanes, const ppp_params *params, ppp_queue *out
     for (auto &l : q->lanes) {
         int rc = ppp_create(device, &l.h);
         if (rc == PPP_OK && params) rc = ppp_set_params(l.h, params);
+        if (rc == PPP_OK) rc = ppp_set_side_by_side(l.h, lanes);
         if (rc != PPP_OK) {
             for (auto &m : q->lanes) if (m.h) ppp_destroy(m.h);
             delete q;

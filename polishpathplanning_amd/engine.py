@@ -80,7 +80,7 @@ EXPORTS = [
     "ppp_write_path_file", "ppp_run_batch_async", "ppp_sync_batch", "ppp_get_stream", "ppp_gather_waypoints", "ppp_get_cloud", "ppp_remove_outlier", "ppp_voxel_down", "ppp_smooth_mls", "ppp_trans2center", "ppp_get_waypoint_counts", "ppp_copy_stage_to_device", "ppp_finish_path_async",
     "ppp_save_pcd_rgb", "ppp_range_interval", "ppp_set_cloud_part", "ppp_spline_create", "ppp_spline_restart", "ppp_spline_eval", "ppp_spline_range", "ppp_spline_destroy",
     "ppp_set_fast_path", "ppp_get_fast_path", "ppp_set_plan_reuse", "ppp_set_cloud_pcd", "ppp_pcd_probe", "ppp_set_cloud_device_async",
-    "ppp_queue_create", "ppp_queue_destroy", "ppp_queue_submit", "ppp_queue_wait", "ppp_queue_lanes", "ppp_queue_lane", "ppp_queue_last_error",
+    "ppp_set_side_by_side", "ppp_queue_create", "ppp_queue_destroy", "ppp_queue_submit", "ppp_queue_wait", "ppp_queue_lanes", "ppp_queue_lane", "ppp_queue_last_error",
 ]
 
 
@@ -118,6 +118,7 @@ def lib():
         L.ppp_set_cloud.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device.argtypes = [vp, vp, sz, sz, fp]
         L.ppp_set_cloud_device_async.argtypes = [vp, vp, sz, sz, fp]
+        L.ppp_set_side_by_side.argtypes = [vp, C.c_int]
         L.ppp_queue_create.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.POINTER(vp)]
         L.ppp_queue_destroy.argtypes = [vp]; L.ppp_queue_destroy.restype = None
         L.ppp_queue_submit.argtypes = [vp, vp, sz, sz, fp, C.POINTER(C.c_longlong)]
@@ -412,6 +413,11 @@ class Engine:
         """ppp_set_plan_reuse: False makes every new cloud take its own window census (the default lets a cloud of the same size and
         parameters inherit the capacities of the handle's earlier plan and skip that launch)."""
         self._chk(self.L.ppp_set_plan_reuse(self.h, 1 if on else 0))
+
+    def set_side_by_side(self, handles):
+        """ppp_set_side_by_side: how many handles the caller runs side by side on this device (from two on: narrower slice workgroups where
+        the windows are small, room for the neighbouring passes' launches)."""
+        self._chk(self.L.ppp_set_side_by_side(self.h, int(handles)))
 
     def fast_path(self):
         """True when the current plan runs the window path (three launches), False for the slab-index path."""
