@@ -1773,6 +1773,25 @@ def test_bench_one_rank_rehearsal_reports_what_the_collective_saw(tmp_path):
     assert d["assembled_path"]["rank0_block_equals_its_list"] and d["roofline"]["kernel"].startswith("k_")
 
 
+@pytest.mark.parametrize("name", ["small_40k", "cfg3_250k_s128", "cfg2_1m_s256"])
+def test_side_by_side_hint_changes_the_launch_not_the_list(engine_mod, name):
+    """ppp_set_side_by_side(h, 3): the plan keeps the slice workgroups of small windows at 512 threads (room on a CU for the launches of
+    the passes next door).  Knots, list and stage outputs are those of the default plan, byte for byte -- set before the cloud, after
+    it, and taken back."""
+    pts, cfg = synth.make_config(name)
+    a = engine_mod.Engine(0, tool_radius=cfg["tool_radius"]); a.set_cloud(pts); a.run_async(); a.sync()
+    b = engine_mod.Engine(0, tool_radius=cfg["tool_radius"]); b.set_side_by_side(3); b.set_cloud(pts); b.run_async(); b.sync()
+    def same(x, y):
+        assert x.num_slices() == y.num_slices() and x.waypoints().tobytes() == y.waypoints().tobytes()
+        assert x.stage(engine_mod.STAGE_WP_NN).tobytes() == y.stage(engine_mod.STAGE_WP_NN).tobytes()
+        for s in (0, x.num_slices() // 2, x.num_slices() - 1):
+            assert all(np.array_equal(p, q) for p, q in zip(x.nodes(s), y.nodes(s)))
+    same(a, b)
+    a.set_side_by_side(2); a.run_async(); a.sync(); same(a, b)        # told later: planned again, same list
+    b.set_side_by_side(1); b.run_async(); b.sync(); same(a, b)        # and taken back
+    assert a.fast_path() and b.fast_path()
+
+
 def test_planner_queue_lists_equal_fresh_handles(engine_mod):
     """ppp_queue_*: a stream of workpieces through three lanes (handles) taking turns -- same-size clouds (handed over without a wait for
     their bounds, their passes overlapping on the device), a cloud of another size in between, one without a single finite point.
